@@ -1,0 +1,285 @@
+"""TEST INFRASTRUCTURE — CPU restatement (numpy) of matchmaker's interaction-scoring path.
+
+This file is the parity ORACLE.  It is NOT product code: only tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import it; nothing under
+matchmaker_amd/ does, and the product path raises if the HIP library is missing.
+
+Every function restates one reference function op-by-op (same op order, same
+intermediate dtypes) and cites the reference lines it follows.  Pinning status:
+  * the reference holds NO golden vectors / tests for this path, so the
+    oracle is pinned against outputs of the reference itself, run in the build container
+    (oracle/ref_harness.py -> tests/golden/*.npz, generator tests/golden/gen_golden.py);
+  * the cosine match matrix is third-party arithmetic (allennlp==2.5.1.dev20210625,
+    pip-requirements.txt:1, not vendored): restated from its published formula, anchored on
+    the reference call sites ecai20_tk.py:105 / sigir20_tkl.py:184.  No reference test pins
+    that boundary -> for the cosine itself parity is "unpinned" beyond the shimmed reference run.
+
+`dtype=np.float64` gives the accumulation-order-independent variant used to bound fp noise
+in rank-order checks.
+"""
+import numpy as np
+
+# ----------------------------------------------------------------------------- ColBERT
+
+
+def maxsim_paired(q, d, q_mask, d_mask, dtype=np.float32):
+    """ColBERT.forward scoring block — matchmaker/models/colbert.py:68-75.
+
+    q [B,Q,E], d [B,D,E]; q_mask [B,Q], d_mask [B,D] (any dtype, nonzero = real token).
+    score[b] = sum_{i: q_mask} max_j ( d_mask[b,j] ? <q_i, d_j> : -1000 )
+    """
+    q = np.asarray(q, dtype=dtype)
+    d = np.asarray(d, dtype=dtype)
+    s = np.matmul(q, np.swapaxes(d, 1, 2))                       # :68  bmm -> [B,Q,D]
+    dm = np.asarray(d_mask) != 0
+    s = np.where(dm[:, None, :], s, dtype(-1000))                # :69  doc pad -> -1000 (not -inf)
+    m = s.max(-1)                                                # :71  max over D
+    qm = np.asarray(q_mask) != 0
+    m = np.where(qm, m, dtype(0))                                # :73  query pad -> 0
+    return m.sum(-1, dtype=dtype)                                # :75
+
+
+def maxsim_unmasked(q, d, dtype=np.float32):
+    """ColBERT.forward_aggregation — matchmaker/models/colbert.py:100-112 (no masks)."""
+    q = np.asarray(q, dtype=dtype)
+    d = np.asarray(d, dtype=dtype)
+    s = np.matmul(q, np.swapaxes(d, 1, 2))                       # :101
+    return s.max(-1).sum(-1, dtype=dtype)                        # :104, :108
+
+
+def maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False, dtype=np.float32):
+    """ColBERT.forward_inbatch_aggregation — matchmaker/models/colbert.py:154-162.
+
+    q [Bq,Q,E], d [Bd,D,E] -> [Bq,Bd].  The reference (:158) expands the document mask as
+    [Bd,1,1,D] -> (-1, Bd, Q, -1), i.e. score[i,j] is masked with doc *i*'s mask and the call
+    needs Bq == Bd.  bug_compatible=True reproduces that; False masks with doc j's mask.
+    """
+    q = np.asarray(q, dtype=dtype)
+    d = np.asarray(d, dtype=dtype)
+    Bq, Q, E = q.shape
+    Bd, D, _ = d.shape
+    s = (q.reshape(-1, E) @ d.reshape(-1, E).T).reshape(Bq, Q, Bd, D)   # :154
+    s = np.swapaxes(s, 1, 2)                                            # :156 [Bq,Bd,Q,D]
+    dm = np.asarray(d_mask) != 0
+    if bug_compatible:
+        if Bq != Bd:
+            raise ValueError("reference shape error: forward_inbatch_aggregation needs Bq == Bd")
+        mask = dm[:, None, None, :]                                     # :158 (row i's doc)
+    else:
+        mask = dm[None, :, None, :]
+    s = np.where(mask, s, dtype(-1000))
+    m = s.max(-1)                                                       # :159
+    qm = np.asarray(q_mask) != 0
+    m = np.where(qm[:, None, :], m, dtype(0))                           # :160
+    return m.sum(-1, dtype=dtype)                                       # :161
+
+
+# ----------------------------------------------------------------------------- cosine
+
+
+def cosine_matrix(a, b, dtype=np.float32):
+    """allennlp CosineMatrixAttention.forward (allennlp 2.5.1, published source), as called at
+    ecai20_tk.py:105 and sigir20_tkl.py:184:  x/(||x||_2 + 1e-13) on both sides, then bmm.
+    tiny is added to the NORM (not the squared norm); an all-zero vector gives cosine 0."""
+    a = np.asarray(a, dtype=dtype)
+    b = np.asarray(b, dtype=dtype)
+    tiny = dtype(1e-13)
+    an = a / (np.sqrt((a * a).sum(-1, keepdims=True, dtype=dtype)) + tiny)
+    bn = b / (np.sqrt((b * b).sum(-1, keepdims=True, dtype=dtype)) + tiny)
+    return np.matmul(an, np.swapaxes(bn, -1, -2))
+
+
+# ----------------------------------------------------------------------------- TK
+
+
+def tk_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, dtype=np.float32,
+                   return_per_kernel=False):
+    """ECAI20_TK.forward kernel-pooling block — published/ecai20_tk.py:105-124.
+
+    q [B,Q,E], d [B,D,E] are the *contextualised* embeddings (:95-96 stay in PyTorch).
+    mu, sigma [K]; alpha = kernel_alpha_scaler [K]; w = kernel_bin_weights.weight[0] [K].
+    """
+    cos = cosine_matrix(q, d, dtype)                                             # :105
+    mu = np.asarray(mu, dtype=dtype).reshape(1, 1, 1, -1)
+    sigma = np.asarray(sigma, dtype=dtype).reshape(1, 1, 1, -1)
+    raw = np.exp(-np.power(cos[..., None] - mu, 2) / (2 * np.power(sigma, 2)))   # :112
+    dm = np.asarray(d_mask, dtype=dtype)
+    masked = raw * dm[:, None, :, None]                                          # :114
+    pkq = masked.sum(2, dtype=dtype)                                             # :120 [B,Q,K]
+    alpha = np.asarray(alpha, dtype=dtype).reshape(1, 1, -1)
+    lg = np.log(np.maximum(pkq * alpha, dtype(1e-10)))                           # :121
+    qm = np.asarray(q_mask, dtype=dtype)
+    lg = lg * qm[..., None]                                                      # :122
+    per_kernel = lg.sum(1, dtype=dtype)                                          # :123 [B,K]
+    score = per_kernel @ np.asarray(w, dtype=dtype).reshape(-1)                  # :124
+    if return_per_kernel:
+        return score, per_kernel
+    return score
+
+
+# ----------------------------------------------------------------------------- TKL
+
+TKL_CHUNK = 40       # sigir20_tkl.py:52
+TKL_OVERLAP = 5      # :53
+TKL_EXT = 50         # :54
+TKL_WINDOW = 30      # :56
+TKL_STRIDE = 2       # :209 unfold(2, 30, 2)
+TKL_TOPK = 3         # :57
+
+
+def tkl_chunk(d, d_mask):
+    """Chunking in front of the hot path — sigir20_tkl.py:142-162 (stays host/PyTorch side in
+    the product; restated here so the oracle can run end-to-end with a bypassed contextualiser).
+
+    Returns chunks [B*C,50,E], chunk_mask [B*C,50], packed_indices [B*C] bool, C."""
+    d = np.asarray(d)
+    m = np.asarray(d_mask)
+    B, D, E = d.shape
+    if D > TKL_OVERLAP:
+        need = TKL_EXT - ((D - TKL_OVERLAP) % TKL_CHUNK)                         # :143
+    else:
+        need = TKL_EXT - TKL_OVERLAP - D                                         # :145
+    dp = np.pad(d, ((0, 0), (TKL_OVERLAP, need), (0, 0)))                        # :147
+    mp = np.pad(m, ((0, 0), (TKL_OVERLAP, need)))                                # :148
+    L = dp.shape[1]
+    C = (L - TKL_EXT) // TKL_CHUNK + 1                                           # unfold(1,50,40)
+    idx = (np.arange(C)[:, None] * TKL_CHUNK + np.arange(TKL_EXT)[None, :])      # [C,50]
+    chunks = dp[:, idx, :].reshape(B * C, TKL_EXT, E)                            # :150,:156
+    cmask = mp[:, idx].reshape(B * C, TKL_EXT)                                   # :151,:157
+    packed = cmask[:, TKL_OVERLAP:-TKL_OVERLAP].sum(-1) != 0                     # :159
+    return chunks, cmask, packed, C
+
+
+def tkl_window_scores(q_ctx, q_mask, centre, centre_mask, packed_indices, B, params,
+                      saturation="embedding", dtype=np.float32):
+    """TKL match + windowed kernel pooling + saturation — sigir20_tkl.py:180-252.
+
+    q_ctx [B,Q,E]        contextualised query, already multiplied by its mask (:306)
+    centre [P,40,E]      documents_unique_again (:174), centre_mask [P,40] (:175)
+    packed_indices [B*C] bool, P = packed_indices.sum()
+    params: dict with mu, sigma [K]; dense_w [K]; sat_w{1,2,3} [2], sat_b{1,2,3} scalar;
+            ln_w, ln_b [2]; emb_reduce_w [E]; kernel_mult0 [K] (log saturation).
+    Returns score [B,W] *before* the ==0 -> -9900 rewrite of :257 (and W, for checks).
+    """
+    q_ctx = np.asarray(q_ctx, dtype=dtype)
+    centre = np.asarray(centre, dtype=dtype)
+    packed_indices = np.asarray(packed_indices, dtype=bool)
+    Q = q_ctx.shape[1]
+    K = len(params["mu"])
+    BC = packed_indices.shape[0]
+    C = BC // B
+    # :180 query expanded to each kept chunk
+    pq = np.repeat(q_ctx[:, None], C, axis=1).reshape(BC, Q, -1)[packed_indices]
+    cos = cosine_matrix(pq, centre, dtype)                                       # :184 [P,Q,40]
+    mu = np.asarray(params["mu"], dtype=dtype).reshape(1, 1, 1, -1)
+    sigma = np.asarray(params["sigma"], dtype=dtype).reshape(1, 1, 1, -1)
+    raw = np.exp(-np.power(cos[..., None] - mu, 2) / (2 * np.power(sigma, 2)))   # :193
+    km = raw * np.asarray(centre_mask, dtype=dtype)[:, None, :, None]            # :194
+    act = np.zeros((BC, Q, TKL_CHUNK, K), dtype=dtype)                           # :196
+    act[packed_indices] = km                                                     # :197
+    act = act.transpose(0, 2, 1, 3).reshape(B, C * TKL_CHUNK, Q, K).transpose(0, 2, 1, 3)  # :199
+    Ptot = act.shape[2]
+    if Ptot < TKL_WINDOW:                                                        # :206-207
+        act = np.pad(act, ((0, 0), (0, 0), (0, TKL_WINDOW - Ptot), (0, 0)))
+        Ptot = TKL_WINDOW
+    W = (Ptot - TKL_WINDOW) // TKL_STRIDE + 1
+    widx = np.arange(W)[:, None] * TKL_STRIDE + np.arange(TKL_WINDOW)[None, :]   # [W,30]
+    unrolled = act[:, :, widx, :]                                                # :209 [B,Q,W,30,K]
+    lengths = (unrolled.sum(-1, dtype=dtype) != 0).sum(-1)                       # :210 [B,Q,W]
+    pkq = unrolled.sum(-2, dtype=dtype)                                          # :211 [B,Q,W,K]
+    qm = np.asarray(q_mask, dtype=dtype)
+    if saturation == "embedding":                                                # :224-234
+        e = (q_ctx @ np.asarray(params["emb_reduce_w"], dtype=dtype).reshape(-1))  # [B,Q]
+        infl = np.stack([np.broadcast_to(e[..., None], lengths.shape).astype(dtype),
+                         lengths.astype(dtype)], axis=-1)                        # [B,Q,W,2]
+        mean = infl.mean(-1, keepdims=True, dtype=dtype)
+        var = ((infl - mean) ** 2).mean(-1, keepdims=True, dtype=dtype)
+        infl = (infl - mean) / np.sqrt(var + dtype(1e-5))                        # LayerNorm(2) :228
+        infl = infl * np.asarray(params["ln_w"], dtype=dtype) + np.asarray(params["ln_b"], dtype=dtype)
+        lin = lambda w, b: (infl @ np.asarray(w, dtype=dtype).reshape(2, 1)) + dtype(b)
+        sat1 = lin(params["sat_w1"], params["sat_b1"])                           # :230
+        sat2 = dtype(1) / lin(params["sat_w2"], params["sat_b2"])                # :231
+        sat3 = lin(params["sat_w3"], params["sat_b3"])                           # :232
+        sat = sat1 * np.power(np.maximum(pkq, dtype(1e-10)), sat2) - sat3        # :234
+    elif saturation == "log":                                                    # :245-246
+        km0 = np.asarray(params["kernel_mult0"], dtype=dtype).reshape(1, 1, 1, -1)
+        sat = np.log(np.maximum(pkq * km0, dtype(1e-10)))
+    else:
+        # "idf"/"linear" (:214-222, :236-243) read `query_idfs`, which is not an argument of
+        # forward (:130 has it commented out): they raise NameError in the reference.
+        raise NotImplementedError("saturation %r is dead code in the reference" % saturation)
+    sat = sat * qm[:, :, None, None] * (lengths > 0).astype(dtype)[..., None]    # :248
+    per_kernel = sat.sum(1, dtype=dtype)                                         # :249 [B,W,K]
+    score = per_kernel @ np.asarray(params["dense_w"], dtype=dtype).reshape(-1)  # :251-252
+    return score.astype(dtype)
+
+
+def tkl_region_topk(score, chunk_scoring, dtype=np.float32):
+    """TKL top-3 non-overlapping regions — sigir20_tkl.py:254-286.  score [B,W] -> [B]."""
+    score = np.array(score, dtype=dtype, copy=True)
+    B = score.shape[0]
+    if score.shape[1] < TKL_TOPK:                                                # :254-255
+        score = np.pad(score, ((0, 0), (0, TKL_TOPK - score.shape[1])))
+    W = score.shape[1]
+    score[score == 0] = dtype(-9900)                                             # :257
+    work = score.copy()                                                          # :264
+    r = np.arange(W)
+    top = np.zeros((B, TKL_TOPK), dtype=np.int64)
+    for c in range(TKL_TOPK):                                                    # :268-273
+        best = work.argmax(1)            # first maximal index, like torch.argmax on CPU
+        top[:, c] = best
+        pool = np.abs(r[None, :] - best[:, None]) < TKL_WINDOW / 2
+        work[pool] = dtype(-10001 - c)
+    nb = np.concatenate([top, top - 1, top + 1, top - 2, top + 2], axis=1)       # :276
+    nb = np.clip(nb, 0, W - 1)                                                   # :277-278
+    vals = np.take_along_axis(score, nb, axis=1)                                 # :280-281
+    vals = np.where(vals <= -9900, dtype(0), vals)                               # :282
+    cs = np.asarray(chunk_scoring, dtype=dtype).reshape(1, -1)
+    return (vals * cs).sum(1, dtype=dtype)                                       # :286
+
+
+def tkl_forward_bypass(q, d, q_mask, d_mask, params, saturation="embedding", dtype=np.float32,
+                       return_windows=False):
+    """TKL_sigir20.forward (sigir20_tkl.py:128-294) with the contextualiser bypassed exactly as
+    oracle/ref_harness.TKLBypass does: forward_representation(x, m) = x * m[...,None] (:306)."""
+    q = np.asarray(q, dtype=dtype)
+    d = np.asarray(d, dtype=dtype)
+    qm = np.asarray(q_mask, dtype=dtype)
+    B = q.shape[0]
+    q_ctx = q * qm[..., None]                                                    # :139 / :306
+    chunks, cmask, packed, C = tkl_chunk(d, np.asarray(d_mask, dtype=dtype))     # :142-162
+    docs_packed = chunks[packed] * cmask[packed][..., None]                      # :172 / :306
+    centre = docs_packed[:, TKL_OVERLAP:-TKL_OVERLAP, :]                         # :174
+    centre_mask = cmask[packed][:, TKL_OVERLAP:-TKL_OVERLAP]                     # :175
+    win = tkl_window_scores(q_ctx, qm, centre, centre_mask, packed, B, params, saturation, dtype)
+    out = tkl_region_topk(win, params["chunk_scoring"], dtype)
+    if return_windows:
+        return out, win
+    return out
+
+
+def tkl_params_from_state(sd):
+    """Collect the hot-path parameters from a TKL_sigir20 state_dict (numpy arrays / tensors)."""
+    g = lambda k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k])
+    return {
+        "mu": g("mu").reshape(-1), "sigma": g("sigma").reshape(-1),
+        "dense_w": g("dense.weight").reshape(-1),
+        "sat_w1": g("saturation_linear.weight").reshape(-1), "sat_b1": float(g("saturation_linear.bias").reshape(-1)[0]),
+        "sat_w2": g("saturation_linear2.weight").reshape(-1), "sat_b2": float(g("saturation_linear2.bias").reshape(-1)[0]),
+        "sat_w3": g("saturation_linear3.weight").reshape(-1), "sat_b3": float(g("saturation_linear3.bias").reshape(-1)[0]),
+        "ln_w": g("sat_normer.weight").reshape(-1), "ln_b": g("sat_normer.bias").reshape(-1),
+        "emb_reduce_w": g("sat_emb_reduce1.weight").reshape(-1),
+        "kernel_mult0": g("kernel_mult")[0].reshape(-1),
+        "chunk_scoring": g("chunk_scoring").reshape(-1),
+    }
+
+
+# ----------------------------------------------------------------------------- ranking
+
+
+def rank_order(scores):
+    """Per-query ranking rule of the reference: stable sort by score, descending, arrival order
+    on ties — utils/core_metrics.py:502-511 (`sorted(..., key=score, reverse=True)` is stable).
+    scores [C] -> indices [C]."""
+    scores = np.asarray(scores)
+    return np.argsort(-scores, kind="stable")

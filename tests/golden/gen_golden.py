@@ -1,0 +1,154 @@
+"""Generates tests/golden/*.npz by running the REAL reference (imported read-only from
+/root/reference through oracle/ref_harness.py) on seeded synthetic inputs.
+
+Run in the build container only:   python tests/golden/gen_golden.py
+The .npz files are committed; the GPU box never needs /root/reference.
+
+Inputs are stored (not just seeds) so the fixtures do not depend on RNG stability:
+bf16-/fp16-representable fp32 values stored as 16-bit patterns to keep the files small.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_harness as R  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def bf16_bits(x: torch.Tensor) -> np.ndarray:
+    return x.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def fp16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16).to(torch.float32)
+
+
+def prefix_mask(lens, L, dtype):
+    return (torch.arange(L)[None, :] < lens[:, None]).to(dtype)
+
+
+def gen_colbert():
+    g = torch.Generator().manual_seed(2002)
+    B, Q, D, E = 8, 32, 180, 128
+    q = bf16_round(torch.nn.functional.normalize(torch.randn(B, Q, E, generator=g), dim=-1))
+    d = bf16_round(torch.nn.functional.normalize(torch.randn(B, D, E, generator=g), dim=-1))
+    q_len = torch.tensor([32, 32, 4, 17, 32, 1, 32, 9])
+    d_len = torch.tensor([180, 0, 70, 33, 1, 179, 64, 96])     # full, empty, ragged, block edges
+    qm = prefix_mask(q_len, Q, torch.int64)
+    dm = prefix_mask(d_len, D, torch.int64)
+    # one non-prefix ("holes") mask pair: reference semantics are per-position, not lengths
+    dm[3, 5] = 0
+    dm[3, 40] = 1
+    qm[3, 2] = 0
+    fwd = R.colbert_forward(q, d, qm, dm).numpy()                          # colbert.py:68-75
+    agg = R.colbert_forward_aggregation(q, d).numpy()                      # colbert.py:100-112
+    inb = R.colbert_forward_inbatch_aggregation(q, qm, d, dm).numpy()      # colbert.py:154-162 (bug incl.)
+    np.savez_compressed(os.path.join(OUT, "colbert_q32_d180_e128.npz"),
+                        q_bf16=bf16_bits(q), d_bf16=bf16_bits(d), q_mask=qm.numpy().astype(np.uint8),
+                        d_mask=dm.numpy().astype(np.uint8), forward=fwd, forward_aggregation=agg,
+                        forward_inbatch_aggregation=inb)
+
+    # odd shapes: Q not multiple of 32, D not multiple of 32, E = 64 / 768 (reference default dim)
+    for (B, Q, D, E, seed) in [(5, 13, 47, 64, 11), (3, 38, 200, 768, 12), (4, 70, 33, 32, 13)]:
+        g = torch.Generator().manual_seed(seed)
+        q = bf16_round(torch.randn(B, Q, E, generator=g) * 0.3)
+        d = bf16_round(torch.randn(B, D, E, generator=g) * 0.3)
+        q_len = torch.randint(1, Q + 1, (B,), generator=g)
+        d_len = torch.randint(0, D + 1, (B,), generator=g)
+        d_len[0] = D
+        qm = prefix_mask(q_len, Q, torch.int64)
+        dm = prefix_mask(d_len, D, torch.int64)
+        np.savez_compressed(os.path.join(OUT, f"colbert_q{Q}_d{D}_e{E}.npz"),
+                            q_bf16=bf16_bits(q), d_bf16=bf16_bits(d),
+                            q_mask=qm.numpy().astype(np.uint8), d_mask=dm.numpy().astype(np.uint8),
+                            forward=R.colbert_forward(q, d, qm, dm).numpy(),
+                            forward_aggregation=R.colbert_forward_aggregation(q, d).numpy(),
+                            forward_inbatch_aggregation=(
+                                R.colbert_forward_inbatch_aggregation(q, qm, d, dm).numpy()))
+
+
+def gen_tk():
+    # BASELINE.json config 1 shapes (1 query x candidates, Q=20/D=200/E=300), B cut to 4 for size
+    g = torch.Generator().manual_seed(1001)
+    B, Q, D, E = 4, 20, 200, 300
+    q1 = fp16_round(torch.randn(1, Q, E, generator=g))
+    q = q1.expand(B, Q, E).contiguous()                        # same query replicated per pair
+    d = fp16_round(torch.randn(B, D, E, generator=g))
+    # make some doc tokens near-duplicates of query tokens so the mu=1.0 / 0.9 bins are populated
+    d[0, 3] = q1[0, 1]
+    d[1, 7] = fp16_round(q1[0, 2] + 0.05 * torch.randn(E, generator=g))
+    d[2, 0] = 0.0                                              # zero vector -> cosine exactly 0
+    q_len = torch.tensor([11, 11, 11, 11])
+    d_len = torch.tensor([200, 10, 77, 133])
+    qm = prefix_mask(q_len, Q, torch.float32)
+    dm = prefix_mask(d_len, D, torch.float32)
+    m = R.make_tk(E, seed=5)
+    with torch.no_grad():
+        m.kernel_alpha_scaler.uniform_(0.5, 1.5, generator=g)
+    score, sec = R.tk_forward(m, q, d, qm, dm, secondary=True)             # ecai20_tk.py:105-129
+    np.savez_compressed(os.path.join(OUT, "tk_q20_d200_e300.npz"),
+                        q_fp16=q1.to(torch.float16).numpy(), d_fp16=d.to(torch.float16).numpy(),
+                        q_mask=qm.numpy(), d_mask=dm.numpy(),
+                        mu=m.mu.numpy().reshape(-1), sigma=m.sigma.numpy().reshape(-1),
+                        alpha=m.kernel_alpha_scaler.detach().numpy().reshape(-1),
+                        w=m.kernel_bin_weights.weight.detach().numpy().reshape(-1),
+                        score=score.numpy(), per_kernel=sec["per_kernel"].numpy())
+
+
+def gen_tkl():
+    for name, (B, Q, D, E, heads, seed, sat) in {
+        "tkl_d333_e300_embedding": (2, 20, 333, 300, 10, 3003, "embedding"),
+        "tkl_d2048_e64_embedding": (2, 20, 2048, 64, 8, 3004, "embedding"),
+        "tkl_d2048_e64_log": (2, 20, 2048, 64, 8, 3005, "log"),
+        "tkl_d20_e64_embedding": (3, 6, 20, 64, 8, 3006, "embedding"),     # single chunk, W small
+        "tkl_d4_e64_embedding": (2, 5, 4, 64, 8, 3007, "embedding"),       # D <= overlap branch (:145)
+    }.items():
+        g = torch.Generator().manual_seed(seed)
+        q = fp16_round(torch.randn(B, Q, E, generator=g))
+        d = fp16_round(torch.randn(B, D, E, generator=g))
+        q_len = torch.randint(1, Q + 1, (B,), generator=g)
+        d_len = torch.randint(1, D + 1, (B,), generator=g)
+        d_len[0] = D
+        if D > 1000:
+            d_len[1] = 90          # most chunks empty -> packed_indices drops them (:159-162)
+        qm = prefix_mask(q_len, Q, torch.float32)
+        dm = prefix_mask(d_len, D, torch.float32)
+        m = R.make_tkl(E, saturation_type=sat, att_heads=heads, seed=seed)
+        with torch.no_grad():
+            m.chunk_scoring.uniform_(0.5, 1.5, generator=g)
+            m.kernel_mult.uniform_(0.5, 1.5, generator=g)
+            m.sat_normer.weight.uniform_(0.5, 1.5, generator=g)
+            m.sat_normer.bias.uniform_(-0.5, 0.5, generator=g)
+        if sat == "embedding":
+            score, sec = R.tkl_forward(m, q, d, qm, dm, secondary=True)    # sigir20_tkl.py:128-294
+            extra = dict(orig_score=sec["orig_score"].numpy(),            # window scores, -9900 -> 0 (:284)
+                         top_idx=sec["top_non_overlapping_idx"].numpy())
+        else:
+            # secondary output raises UnboundLocalError for "log" in the reference (:290)
+            score = R.tkl_forward(m, q, d, qm, dm)
+            extra = {}
+        sd = {k: v.detach().numpy() for k, v in m.state_dict().items()
+              if not k.startswith("contextualizer") and not k.startswith("positional")}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                            q_fp16=q.to(torch.float16).numpy(), d_fp16=d.to(torch.float16).numpy(),
+                            q_mask=qm.numpy(), d_mask=dm.numpy(), saturation=np.array(sat),
+                            score=score.numpy(), **extra,
+                            **{"param." + k: v for k, v in sd.items()})
+
+
+if __name__ == "__main__":
+    gen_colbert()
+    gen_tk()
+    gen_tkl()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
