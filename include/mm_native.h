@@ -1,0 +1,151 @@
+/*
+ * mm_native.h — C ABI of libmm_native.so: MI355X (gfx950) interaction-scoring kernels for
+ * matchmaker's re-ranking forward pass.
+ *
+ * The reference (sebastian-hofstaetter/matchmaker) is pure Python: it has no FFI of its own.
+ * Its "operator API" for this path is the nn.Module protocol of SURVEY.md §8(b).  Each entry
+ * point below replaces the arithmetic of one reference method; the Python host side
+ * (matchmaker_amd/*.py) mirrors the method signatures and binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub a matchmaker maintainer would add).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless stated; tensors are dense, row-major,
+ *     innermost dimension contiguous, 16-byte aligned base;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
+ *   - return 0 on success, a negative MM_E* code otherwise; mm_last_error() gives a
+ *     thread-local message.  Nothing is allocated, retained or synchronised by the library.
+ */
+#ifndef MM_NATIVE_H
+#define MM_NATIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+/* element types of the embedding tensors */
+#define MM_F32 0
+#define MM_F16 1
+#define MM_BF16 2
+
+/* how a mask argument is encoded (the reference passes int64 HF attention masks to ColBERT —
+ * colbert.py:69,73 — and float {0,1} masks to TK/TKL — neuralIR_encoder.py:35-37) */
+#define MM_MASK_NONE 0    /* pointer ignored: every position is a real token              */
+#define MM_MASK_LEN_I32 1 /* int32[rows]: positions >= len are padding (prefix masks)      */
+#define MM_MASK_U8 2      /* uint8/bool[rows, L], nonzero = real token                     */
+#define MM_MASK_I64 3     /* int64[rows, L]   (HF tokenizer attention_mask)                */
+#define MM_MASK_F32 4     /* float[rows, L]   (matchmaker embedding-model masks)           */
+
+/* error codes */
+#define MM_OK 0
+#define MM_EINVAL -1       /* bad argument (null pointer, non-positive size, bad enum)     */
+#define MM_EUNSUPPORTED -2 /* shape/dtype outside what the kernels implement               */
+#define MM_EWORKSPACE -3   /* workspace missing or too small                               */
+#define MM_ELAUNCH -4      /* HIP reported a launch error                                  */
+
+int mm_abi_version(void);
+const char* mm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ColBERT late-interaction MaxSim.
+ *
+ *   out[p] = sum_{i < Q, q_mask[i]}  max_{j < D} ( d_mask[p, j] ? <q[i,:], d[p,j,:]> : -1000 )
+ *
+ * Replaces: ColBERT.forward scoring block            matchmaker/models/colbert.py:68-75
+ *           ColBERT.forward_aggregation (no masks)   matchmaker/models/colbert.py:100-112
+ *
+ *   q   [n_queries, Q, E]   n_queries = ceil(n_pairs / pairs_per_query)
+ *   d   [n_pairs,   D, E]   pair p uses query p / pairs_per_query
+ *   out [n_pairs] float32
+ *
+ * pairs_per_query = 1 is the reference's pair-per-row layout (query replicated per pair,
+ * eval.py:108); pairs_per_query = C is the "1 query x C candidates" re-ranking layout in which
+ * the query tile is read once per candidate list.
+ * q_mask rows follow q (n_queries rows), d_mask rows follow d (n_pairs rows).
+ * workspace: mm_maxsim_workspace_bytes() bytes of device scratch (may be 0 -> NULL allowed).
+ */
+size_t mm_maxsim_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                                 int q_mask_kind, int d_mask_kind);
+
+int mm_maxsim_fwd(const void* q, const void* d,
+                  const void* q_mask, int q_mask_kind,
+                  const void* d_mask, int d_mask_kind,
+                  float* out,
+                  int64_t n_pairs, int64_t pairs_per_query,
+                  int Q, int D, int E, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* All-pairs MaxSim: out[i, j] over query i x document j.
+ * Replaces ColBERT.forward_inbatch_aggregation       matchmaker/models/colbert.py:154-162
+ * bug_compatible != 0 reproduces the reference's mask expansion (:158), which masks
+ * score[i, j] with document i's mask and requires Bq == Bd (MM_EINVAL otherwise).
+ *   q [Bq, Q, E], d [Bd, D, E], out [Bq, Bd] float32 */
+size_t mm_maxsim_inbatch_workspace_bytes(int64_t Bq, int64_t Bd, int Q, int D,
+                                         int q_mask_kind, int d_mask_kind);
+
+int mm_maxsim_inbatch_fwd(const void* q, const void* d,
+                          const void* q_mask, int q_mask_kind,
+                          const void* d_mask, int d_mask_kind,
+                          float* out,
+                          int64_t Bq, int64_t Bd, int Q, int D, int E, int dtype,
+                          int bug_compatible,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TK kernel pooling (cosine match matrix + K RBF kernels + log-sum pooling + bin weights).
+ *
+ *   cos[i,j]  = <q_i, d_j> / ((|q_i| + 1e-13)(|d_j| + 1e-13))
+ *   pkq[i,k]  = sum_j d_mask[j] * exp(-(cos[i,j] - mu[k])^2 / (2 sigma[k]^2))
+ *   out[p]    = sum_k w[k] * sum_i q_mask[i] * log(max(pkq[i,k] * alpha[k], 1e-10))
+ *
+ * Replaces: ECAI20_TK.forward pooling block   matchmaker/models/published/ecai20_tk.py:105-124
+ *           (cosine = allennlp CosineMatrixAttention, call site ecai20_tk.py:105)
+ *
+ *   q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings
+ *   mu, sigma, alpha, w: float32[K] device pointers, K <= 16
+ *   per_kernel: optional float32 [n_pairs, K] (the reference's secondary output), may be NULL
+ */
+int mm_kernel_pool_fwd(const void* q, const void* d,
+                       const void* q_mask, int q_mask_kind,
+                       const void* d_mask, int d_mask_kind,
+                       const float* mu, const float* sigma, const float* alpha, const float* w,
+                       float* out, float* per_kernel,
+                       int64_t n_pairs, int64_t pairs_per_query,
+                       int Q, int D, int E, int K, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TKL: match + RBF kernels per document position, sliding-window (30, stride 2) pooling with
+ * learned saturation, per-window score; then top-3 non-overlapping region scoring.
+ *
+ * Replaces: TKL_sigir20.forward   matchmaker/models/published/sigir20_tkl.py:180-252 (windows)
+ *                                 matchmaker/models/published/sigir20_tkl.py:254-286 (regions)
+ *
+ *   q_ctx        [B, Q, E]   contextualised query, already multiplied by its mask (:306)
+ *   chunks       [P, 50, E]  contextualised packed chunks (output of :172); the 40 centre
+ *                            tokens of each are used (:174)
+ *   chunk_mask   [P, 50]     float {0,1} (padding_packed, :163)
+ *   chunk_slot   [P] int32   flat slot b*C + c of each packed chunk (packed_indices :159, as indices)
+ *   q_mask       [B, Q]      float {0,1}
+ *   params       float32[MM_TKL_NPARAMS(K)] device: see matchmaker_amd/tkl.py pack_params()
+ *   saturation   0 = "embedding" (:224-234), 1 = "log" (:245-246)
+ *   win_scores   [B, W] float32 out (W = (max(C*40,30) - 30)/2 + 1), may be NULL if workspace given
+ *   out          [B] float32
+ */
+#define MM_TKL_SAT_EMBEDDING 0
+#define MM_TKL_SAT_LOG 1
+size_t mm_tkl_workspace_bytes(int64_t B, int C, int Q, int K);
+
+int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask,
+               const int32_t* chunk_slot, const float* q_mask, const float* params,
+               float* win_scores, float* out,
+               int64_t B, int64_t P, int C, int Q, int E, int K, int saturation,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_NATIVE_H */

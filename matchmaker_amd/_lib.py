@@ -1,0 +1,59 @@
+"""ctypes binding of libmm_native.so (C ABI declared in include/mm_native.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmm_native.so")
+
+MM_F32, MM_F16, MM_BF16 = 0, 1, 2
+MASK_NONE, MASK_LEN_I32, MASK_U8, MASK_I64, MASK_F32 = 0, 1, 2, 3, 4
+TKL_SAT_EMBEDDING, TKL_SAT_LOG = 0, 1
+
+_c = ctypes
+_vp, _i64, _i, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
+
+# symbol -> (restype, argtypes): must list every function declared in include/mm_native.h
+SIGNATURES = {
+    "mm_abi_version": (_i, []),
+    "mm_last_error": (_c.c_char_p, []),
+    "mm_maxsim_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
+    "mm_maxsim_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_maxsim_inbatch_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
+    "mm_maxsim_inbatch_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_kernel_pool_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                _i, _i, _i, _i, _i, _vp]),
+    "mm_tkl_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "mm_tkl_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared library once; raises if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python -m matchmaker_amd.build` "
+                "(matchmaker_amd has no CPU / eager fallback for the scoring path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().mm_last_error().decode("utf-8", "replace")
+        raise NativeError(f"{what} failed ({code}): {msg}")

@@ -1,0 +1,140 @@
+"""Drop-in ColBERT for matchmaker: same constructor / forward / aggregation surface and state_dict
+keys as matchmaker/models/colbert.py (reference lines cited per method); the interaction scoring
+runs in libmm_native.so (mm_maxsim_fwd / mm_maxsim_inbatch_fwd) instead of bmm + mask + max + sum.
+
+Callers that keep working unchanged: eval.py:108, train.py:347-348 (forward), indexing_heads.py:23,52
+(forward_representation), indexing_heads.py:55 (forward_aggregation), dynamic_teacher.py:245-276
+(forward_inbatch_aggregation), train.py:241-244 (get_param_stats / get_param_secondary).
+"""
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+from transformers import AutoModel, PretrainedConfig, PreTrainedModel
+
+from . import ops
+
+
+class ColBERTConfig(PretrainedConfig):
+    """Fields of matchmaker/models/colbert.py:10-16.  Declared through __init__ so that the class
+    also constructs under transformers >= 5 (the reference's bare annotations do not)."""
+    model_type = "ColBERT"
+
+    def __init__(self, bert_model: str = "", compression_dim: int = 768, dropout: float = 0.0,
+                 return_vecs: bool = False, trainable: bool = True, **kwargs):
+        super().__init__(**kwargs)
+        self.bert_model = bert_model
+        self.compression_dim = compression_dim
+        self.dropout = dropout
+        self.return_vecs = return_vecs
+        self.trainable = trainable
+
+
+class _MaxSimFn(torch.autograd.Function):
+    """Native forward; backward by re-deriving the arg-max routing with torch ops on the device
+    (training path, train.py:503-524).  Inference (eval.py:76 no_grad) never gets here."""
+
+    @staticmethod
+    def forward(ctx, q, d, q_mask, d_mask):
+        ctx.save_for_backward(q, d, q_mask, d_mask)
+        return ops.maxsim(q, d, q_mask, d_mask, pairs_per_query=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, d, q_mask, d_mask = ctx.saved_tensors
+        with torch.enable_grad():
+            q_ = q.detach().float().requires_grad_(True)
+            d_ = d.detach().float().requires_grad_(True)
+            s = torch.bmm(q_, d_.transpose(1, 2))
+            s = s.masked_fill(~(d_mask != 0).unsqueeze(1), -1000.0)
+            m = s.max(-1).values.masked_fill(~(q_mask != 0), 0.0).sum(-1)
+            gq, gd = torch.autograd.grad(m, (q_, d_), g.float())
+        return gq.to(q.dtype), gd.to(d.dtype), None, None
+
+
+class ColBERT(PreTrainedModel):
+    """ColBERT (https://arxiv.org/abs/2004.12832) with MI355X-native late-interaction scoring."""
+
+    config_class = ColBERTConfig
+    base_model_prefix = "bert_model"
+    is_teacher_model = False              # overridden by the dynamic teacher (dynamic_teacher.py:174)
+    # forward_inbatch_aggregation masks score[i, j] with document i's mask in the reference
+    # (colbert.py:158).  True = bit-for-bit the reference's behaviour (incl. its Bq == Bd limit);
+    # set False for the mask-by-document-j semantics.
+    inbatch_bug_compatible = True
+
+    @staticmethod
+    def from_config(config):              # colbert.py:27-35
+        cfg = ColBERTConfig(bert_model=config["bert_pretrained_model"],
+                            compression_dim=config["colbert_compression_dim"],
+                            return_vecs=config.get("in_batch_negatives", False),
+                            trainable=config["bert_trainable"])
+        return ColBERT(cfg)
+
+    def __init__(self, cfg: ColBERTConfig, bert_model: Optional[nn.Module] = None) -> None:
+        super().__init__(cfg)
+        self.return_vecs = cfg.return_vecs
+        # colbert.py:44 loads by name; an already-built encoder can be injected (offline use/tests)
+        self.bert_model = bert_model if bert_model is not None else AutoModel.from_pretrained(cfg.bert_model)
+        for p in self.bert_model.parameters():
+            p.requires_grad = cfg.trainable
+        self._dropout = nn.Dropout(p=cfg.dropout)
+        self.compressor = nn.Linear(self.bert_model.config.hidden_size, cfg.compression_dim)
+
+    # ------------------------------------------------------------------ scoring (the hot path)
+    @staticmethod
+    def _score(query_vecs, document_vecs, query_mask, document_mask):
+        """colbert.py:68-75."""
+        if torch.is_grad_enabled() and (query_vecs.requires_grad or document_vecs.requires_grad):
+            return _MaxSimFn.apply(query_vecs, document_vecs, query_mask, document_mask)
+        return ops.maxsim(query_vecs, document_vecs, query_mask, document_mask, pairs_per_query=1)
+
+    def forward(self, query: Dict[str, torch.LongTensor], document: Dict[str, torch.LongTensor],
+                use_fp16: bool = True, output_secondary_output: bool = False):
+        """colbert.py:54-86 — same arguments and return conventions."""
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+            query_vecs = self.forward_representation(query)
+            document_vecs = self.forward_representation(document)
+            if use_fp16 and query_vecs.dtype == torch.float32:
+                # autocast would run the reference's bmm in fp16 (colbert.py:60,68)
+                q_s, d_s = query_vecs.half(), document_vecs.half()
+            else:
+                q_s, d_s = query_vecs, document_vecs
+            score = self._score(q_s, d_s, query["attention_mask"], document["attention_mask"])
+
+            if self.is_teacher_model:
+                return (score, query_vecs, document_vecs)
+            if self.return_vecs:
+                score = (score, query_vecs, document_vecs)
+            if output_secondary_output:
+                return score, {}
+            return score
+
+    def forward_representation(self, tokens: Dict[str, torch.LongTensor], sequence_type=None) -> torch.Tensor:
+        """colbert.py:88-98 (encoder + compressor stay PyTorch)."""
+        vecs = self.bert_model(**tokens)[0]
+        vecs = self.compressor(vecs)
+        if sequence_type == "doc_encode" or sequence_type == "query_encode":
+            vecs = vecs * tokens["attention_mask"].unsqueeze(-1)
+        return vecs
+
+    def forward_aggregation(self, query_vecs, document_vecs):
+        """colbert.py:100-112 — unmasked MaxSim over pre-encoded vectors."""
+        if query_vecs.dtype != document_vecs.dtype:
+            document_vecs = document_vecs.to(query_vecs.dtype)
+        return ops.maxsim(query_vecs, document_vecs, None, None, pairs_per_query=1)
+
+    def forward_inbatch_aggregation(self, query_vecs, query_mask, document_vecs, document_mask):
+        """colbert.py:114-162 — all-pairs MaxSim [Bq, Bd]."""
+        if self.inbatch_bug_compatible and query_vecs.shape[0] != document_vecs.shape[0]:
+            # the reference's mask expansion (:158) raises for Bq != Bd
+            raise RuntimeError("forward_inbatch_aggregation (reference-compatible masking) needs the same number "
+                               "of queries and documents; set inbatch_bug_compatible = False for the general case")
+        return ops.maxsim_inbatch(query_vecs, query_mask, document_vecs, document_mask,
+                                  bug_compatible=self.inbatch_bug_compatible)
+
+    def get_param_stats(self):            # colbert.py:164-165
+        return "ColBERT: / "
+
+    def get_param_secondary(self):        # colbert.py:166-167
+        return {}

@@ -1,0 +1,94 @@
+// Error reporting + mask packing for libmm_native.so.
+#include "mm_internal.h"
+
+namespace mm {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// One wave per mask row.  Lanes sweep the row 64 positions at a time; __ballot gives the 64
+// validity bits -> two uint32 words.  len = index of the last real token + 1 (so all-padding tails
+// are never loaded by the scoring kernels); holes inside [0, len) stay visible through `bits`.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_mask_kernel(const T* __restrict__ mask, int64_t rows, int L,
+                                                        int words, int32_t* __restrict__ len_out,
+                                                        uint32_t* __restrict__ bits_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* m = mask + row * (int64_t)L;
+  int last = 0;
+  for (int base = 0; base < L; base += 64) {
+    const int j = base + lane;
+    const bool v = (j < L) && (m[j] != T(0));
+    const unsigned long long b = __ballot(v);
+    if (lane == 0) {
+      const int w = base >> 5;
+      bits_out[row * words + w] = (uint32_t)b;
+      if (w + 1 < words) bits_out[row * words + w + 1] = (uint32_t)(b >> 32);
+    }
+    if (b) last = base + 64 - __builtin_clzll(b);
+  }
+  if (lane == 0) len_out[row] = last;
+}
+
+size_t packed_mask_bytes(int kind, int64_t rows, int L) {
+  if (kind == MM_MASK_U8 || kind == MM_MASK_I64 || kind == MM_MASK_F32) {
+    const int words = (L + 31) / 32;
+    size_t b = (size_t)rows * 4 + (size_t)rows * words * 4;
+    return (b + 255) & ~(size_t)255;
+  }
+  return 0;
+}
+
+int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, size_t* ws_left,
+                 hipStream_t stream, PackedMask* out) {
+  out->len = nullptr;
+  out->bits = nullptr;
+  switch (kind) {
+    case MM_MASK_NONE:
+      return MM_OK;
+    case MM_MASK_LEN_I32:
+      if (!mask) return set_error(MM_EINVAL, "mask kind LEN_I32 given with a null pointer");
+      out->len = (const int32_t*)mask;
+      return MM_OK;
+    case MM_MASK_U8:
+    case MM_MASK_I64:
+    case MM_MASK_F32: {
+      if (!mask) return set_error(MM_EINVAL, "dense mask given with a null pointer");
+      const size_t need = packed_mask_bytes(kind, rows, L);
+      if (!*ws || *ws_left < need)
+        return set_error(MM_EWORKSPACE, "workspace too small for mask packing: need %zu more bytes, have %zu",
+                         need, *ws_left);
+      const int words = (L + 31) / 32;
+      int32_t* len = (int32_t*)*ws;
+      uint32_t* bits = (uint32_t*)(*ws + (size_t)rows * 4);
+      *ws += need;
+      *ws_left -= need;
+      const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+      if (kind == MM_MASK_U8)
+        hipLaunchKernelGGL(pack_mask_kernel<uint8_t>, grid, block, 0, stream, (const uint8_t*)mask, rows, L, words, len, bits);
+      else if (kind == MM_MASK_I64)
+        hipLaunchKernelGGL(pack_mask_kernel<int64_t>, grid, block, 0, stream, (const int64_t*)mask, rows, L, words, len, bits);
+      else
+        hipLaunchKernelGGL(pack_mask_kernel<float>, grid, block, 0, stream, (const float*)mask, rows, L, words, len, bits);
+      out->len = len;
+      out->bits = bits;
+      return check_launch("pack_mask_kernel");
+    }
+    default:
+      return set_error(MM_EINVAL, "unknown mask kind %d", kind);
+  }
+}
+
+}  // namespace mm
+
+extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
+extern "C" const char* mm_last_error(void) { return mm::g_err; }

@@ -1,0 +1,531 @@
+// ColBERT late-interaction MaxSim for MI355X (gfx950 / CDNA4).
+//
+//   out[p] = sum_{i<Q, qmask}  max_{j<D} ( dmask[p,j] ? <q_i, d_{p,j}> : -1000 )
+//
+// Reference semantics: matchmaker/models/colbert.py:68-75 (masked, paired), :100-112 (unmasked),
+// :154-162 (all pairs).  Sentinel is -1000 (not -inf); query padding contributes 0.
+//
+// Two kernels:
+//   * maxsim_stream_kernel — the roofline path (16-bit dtypes, E == 128, Q <= 32).  One wavefront
+//     per workgroup streams its documents through a private LDS ring with LDS-DMA
+//     (global_load_lds_dwordx4: 1 KiB of contiguous HBM per instruction, no VGPR round trip),
+//     keeps the whole query tile as MFMA B-fragments in 32 VGPRs, and computes each 32-token
+//     document block with 8 x v_mfma_f32_32x32x16_{bf16,f16}.  Document tokens sit on the MFMA M
+//     axis so the max over document tokens is an element-wise running max of the 16 accumulator
+//     registers; one cross-half exchange + one wave reduction per pair finish the score.
+//   * maxsim_generic_kernel — any E/Q/D and fp32: fragment-shaped direct loads, same MFMA maps.
+//
+// HBM-bound by design: 2*Q*E flop per D-side byte pair = 32 flop/B at bf16, far below the MFMA
+// ridge, so everything here is about keeping >= 16 KiB of D stream in flight per wavefront.
+#include "mm_internal.h"
+
+namespace mm {
+
+struct MaxsimArgs {
+  const void* q;
+  const void* d;
+  PackedMask qm;  // rows = queries
+  PackedMask dm;  // rows = documents
+  float* out;
+  int64_t n_pairs;
+  int64_t ppq;     // pairs per query (paired mode)
+  int64_t inb_bd;  // > 0: all-pairs mode, pair p = (query p / Bd, doc p % Bd)
+  int inb_bug;     // all-pairs: mask with the document row of the *query* index (colbert.py:158)
+  int Q, D, E;
+  int64_t pairs_per_wave;
+};
+
+template <int DT>
+struct Mfma32x16;
+template <>
+struct Mfma32x16<MM_BF16> {
+  static __device__ __forceinline__ f32x16 run(short8 a, short8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mfma32x16<MM_F16> {
+  static __device__ __forceinline__ f32x16 run(short8 a, short8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// C/D layout of the 32x32 MFMA: lane l holds column (l & 31), rows rowof(i) + 4*(l >> 5).
+__device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
+
+// Running max of one 32-row document block into m[16].
+//   ex: bit r set <=> row r of the block is below the document's effective length
+//   va: bit r set <=> row r is a real token (va is a subset of ex)
+//   fill: value of rows outside ex (-1000 if the document has padding at all, else -inf: rows
+//         past D do not exist and must not take part in the max).
+__device__ __forceinline__ void block_max(float (&m)[16], const f32x16& acc, uint32_t ex, uint32_t va, float fill, int h) {
+  if (va == 0xffffffffu) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], acc[i]);
+  } else {
+    const uint32_t exs = ex >> (4 * h), vas = va >> (4 * h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int bit = rowof(i);
+      float v = ((vas >> bit) & 1u) ? acc[i] : (((exs >> bit) & 1u) ? -1000.0f : fill);
+      m[i] = fmaxf(m[i], v);
+    }
+  }
+}
+
+// Wave-uniform 32-bit load through the scalar cache.  The compiler cannot use s_load here on its
+// own (the asm "memory" clobbers of the LDS-DMA pipeline make every global look written), and a
+// vector load would make it wait vmcnt(0) and drain the D stream once per pair.  Lengths / mask
+// words are never written by these kernels, so the (non-coherent) scalar cache is safe.
+__device__ __forceinline__ uint32_t sload_u32(const void* base, int64_t idx) {
+  uint32_t v;
+  const uint32_t* p = (const uint32_t*)base + idx;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+
+// Query-tile B fragments: 8 x 16 B per lane at base + kk*32.  Loaded in asm together with their
+// own vmcnt(0) so the compiler never plants vmcnt(N) waits for them inside the block loop (those
+// would also drain the hidden LDS-DMA queue).  Runs once per query, so the drain is harmless.
+__device__ __forceinline__ void load_q_frags(const char* base, short8 (&qf)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off\n\t"
+      "global_load_dwordx4 %1, %8, off offset:32\n\t"
+      "global_load_dwordx4 %2, %8, off offset:64\n\t"
+      "global_load_dwordx4 %3, %8, off offset:96\n\t"
+      "global_load_dwordx4 %4, %8, off offset:128\n\t"
+      "global_load_dwordx4 %5, %8, off offset:160\n\t"
+      "global_load_dwordx4 %6, %8, off offset:192\n\t"
+      "global_load_dwordx4 %7, %8, off offset:224\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]), "=&v"(qf[4]), "=&v"(qf[5]), "=&v"(qf[6]),
+        "=&v"(qf[7])
+      : "v"(base)
+      : "memory");
+}
+
+__device__ __forceinline__ float finish_pair(const float (&m)[16], bool qvalid, int h) {
+  float mx = m[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, m[i]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // other half holds the other 16 rows of every block
+  return wave_sum((qvalid && h == 0) ? mx : 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Roofline path.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlkBytes = 32 * 256;  // 32 document tokens x 128 dims x 2 B
+
+// 8 LDS-DMA instructions = one 8 KiB document block.  Instruction k moves rows 4k..4k+3:
+// 16 lanes per row, each lane one 16-B chunk.  LDS destination is lane-linear (M0 + lane*16), so
+// the bank swizzle is applied on the SOURCE side: the chunk stored at slot p of row r is chunk
+// p ^ (r & 15).  A later ds_read_b128 of chunk c of row (lane & 31) then reads slot c ^ (r & 15):
+// every 16-lane service group of the read covers 16 distinct slots of the 256-B bank row.
+template <bool NT>
+__device__ __forceinline__ void issue_block(const char* gbase, const uint32_t (&voff)[8], uint32_t lds_dst) {
+  uint32_t keep;
+  if (NT) {
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %9 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %9 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]),
+          "v"(voff[7]), "s"(gbase), "s"(lds_dst)
+        : "memory", "scc");
+  } else {
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %10\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %9\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]),
+          "v"(voff[7]), "s"(gbase), "s"(lds_dst)
+        : "memory", "scc");
+  }
+}
+
+// Wait until at most `younger` blocks (8 LDS-DMA each) issued after the one we need are pending.
+__device__ __forceinline__ void wait_block(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+  }
+}
+
+template <int DT, int NBUF, bool NT>
+__global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // per-lane source offsets of the 8 LDS-DMA instructions of a block (and of the last block of a
+  // document, whose rows past D are redirected to the last real row: never read past the tensor)
+  uint32_t voff[8], voff_tail[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = 4 * k + (lane >> 4);
+    const int c = (lane & 15) ^ (row & 15);
+    const int rowt = row < rows_last ? row : rows_last - 1;
+    voff[k] = (uint32_t)(row * 256 + c * 16);
+    voff_tail[k] = (uint32_t)(rowt * 256 + c * 16);
+  }
+  // per-lane LDS offsets of the 8 A-fragment reads: chunk 2kk+h of row r lives at slot (2kk+h)^(r&15)
+  uint32_t lo[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
+
+  const char* dbase = (const char*)a.d;
+  auto doc_len = [&](int64_t p) -> int {
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
+    return len < 0 ? 0 : (len > D ? D : len);
+  };
+
+  // ---- producer cursor: next (pair, block) to put in flight --------------------------------
+  int64_t pp = p0;
+  int pt = 0, pn = 0;
+  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      const char* g = dbase + (pp * D + (int64_t)pt * 32) * 256;
+      const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes;
+      if (pt == nblk_tot - 1 && rows_last != 32)
+        issue_block<NT>(g, voff_tail, dst);
+      else
+        issue_block<NT>(g, voff, dst);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (++pt == pn) {
+        pt = 0;
+        ++pp;
+        while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+      }
+    }
+  };
+  top_up();
+
+  // ---- query tile as MFMA B fragments ---------------------------------------------------------
+  short8 qf[8];
+  bool qvalid = false;
+  int64_t cur_q = -1;
+  int64_t qi = p0 / a.ppq;
+  int64_t q_left = a.ppq - (p0 - qi * a.ppq);  // pairs left on this query
+
+  for (int64_t pair = p0; pair < p1; ++pair) {
+    if (q_left == 0) {
+      ++qi;
+      q_left = a.ppq;
+    }
+    --q_left;
+    if (qi != cur_q) {
+      cur_q = qi;
+      const int qr = r < Q ? r : Q - 1;
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * 256;
+      load_q_frags(qrow + h * 16, qf);
+      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      qvalid = r < Q && r < qlen;
+      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+    }
+    const int len = doc_len(pair);
+    const int nb = (len + 31) >> 5;
+    const float fill = len < D ? -1000.0f : neg_inf();
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = fill;
+
+    for (int t = 0; t < nb; ++t) {
+      top_up();
+      wait_block(inflight - 1);
+      const char* buf = smem + cbuf * kBlkBytes;
+      f32x16 acc = {0};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const short8 av = *(const short8*)(buf + lo[kk]);
+        acc = Mfma32x16<DT>::run(av, qf[kk], acc);
+      }
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      block_max(m, acc, ex, va, fill, h);
+      cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+      --inflight;
+    }
+    const float s = finish_pair(m, qvalid, h);
+    if (lane == 0) a.out[pair] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic path: any E (16-B aligned rows), any Q, any D; bf16 / f16 / f32.
+// One wavefront per pair; query tiles of 32 tokens looped sequentially (deterministic sum order).
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ f32x16 dot_block(const char* drow, const char* qrow, int E) {
+  f32x16 acc = {0};
+  if constexpr (DT == MM_F32) {
+    // v_mfma_f32_32x32x2_f32: lane (r,h) supplies A[r][k=h].  K is walked in 16-B chunks: chunk
+    // pair (2c, 2c+1) -> h=0 takes chunk 2c, h=1 chunk 2c+1; the 4 floats of a chunk are 4 steps.
+    const int h = threadIdx.x >> 5;
+    const int nch = E >> 2;
+    for (int c = 0; c < nch; c += 2) {
+      const int cc = c + h;
+      f32x4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
+      if (cc < nch) {
+        av = *(const f32x4*)(drow + cc * 16);
+        bv = *(const f32x4*)(qrow + cc * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+    }
+  } else {
+    const int h = threadIdx.x >> 5;
+    const int nch = E >> 3;
+    for (int c = 0; c < nch; c += 2) {
+      const int cc = c + h;
+      short8 av = {0, 0, 0, 0, 0, 0, 0, 0}, bv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (cc < nch) {
+        av = *(const short8*)(drow + cc * 16);
+        bv = *(const short8*)(qrow + cc * 16);
+      }
+      acc = Mfma32x16<DT == MM_F32 ? MM_BF16 : DT>::run(av, bv, acc);
+    }
+  }
+  return acc;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(64) maxsim_generic_kernel(const MaxsimArgs a) {
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t pair = blockIdx.x;
+  if (pair >= a.n_pairs) return;
+  const int D = a.D, Q = a.Q, E = a.E;
+  constexpr int ES = (DT == MM_F32) ? 4 : 2;
+  const int64_t rowb = (int64_t)E * ES;
+  int64_t qi, di, mi;
+  if (a.inb_bd > 0) {
+    qi = pair / a.inb_bd;
+    di = pair - qi * a.inb_bd;
+    mi = a.inb_bug ? qi : di;
+  } else {
+    qi = pair / a.ppq;
+    di = pair;
+    mi = pair;
+  }
+  const int nblk_tot = (D + 31) >> 5;
+  const int qwords = (Q + 31) >> 5;
+  int len = a.dm.len ? a.dm.len[mi] : D;
+  len = len < 0 ? 0 : (len > D ? D : len);
+  const int nb = (len + 31) >> 5;
+  const float fill = len < D ? -1000.0f : neg_inf();
+  const int qlen = a.qm.len ? a.qm.len[qi] : Q;
+  const char* dbase = (const char*)a.d + di * D * rowb;
+  const char* qbase = (const char*)a.q + qi * Q * rowb;
+
+  float total = 0.0f;
+  for (int n = 0; n < qwords; ++n) {
+    const int qtok = 32 * n + r;
+    const int qr = qtok < Q ? qtok : Q - 1;
+    bool qvalid = qtok < Q && qtok < qlen;
+    if (a.qm.bits) qvalid = qvalid && ((a.qm.bits[qi * qwords + n] >> r) & 1u);
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = fill;
+    for (int t = 0; t < nb; ++t) {
+      const int drow = 32 * t + r;
+      const int dr = drow < D ? drow : D - 1;
+      const f32x16 acc = dot_block<DT>(dbase + dr * rowb, qbase + qr * rowb, E);
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (a.dm.bits[mi * nblk_tot + t] & ex) : ex;
+      block_max(m, acc, ex, va, fill, h);
+    }
+    total += finish_pair(m, qvalid, h);
+  }
+  if (lane == 0) a.out[pair] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int validate(const void* q, const void* d, float* out, int64_t n_pairs, int Q, int D, int E, int dtype) {
+  if (!q || !d || !out) return set_error(MM_EINVAL, "maxsim: null tensor pointer");
+  if (n_pairs < 0 || Q <= 0 || D <= 0 || E <= 0) return set_error(MM_EINVAL, "maxsim: non-positive shape");
+  if (dtype != MM_F32 && dtype != MM_F16 && dtype != MM_BF16) return set_error(MM_EINVAL, "maxsim: bad dtype %d", dtype);
+  const int per16 = dtype == MM_F32 ? 4 : 8;
+  if (E % per16) return set_error(MM_EUNSUPPORTED, "maxsim: E=%d rows are not 16-byte multiples (pad E to a multiple of %d)", E, per16);
+  if (((uintptr_t)q | (uintptr_t)d) & 15) return set_error(MM_EINVAL, "maxsim: q/d must be 16-byte aligned");
+  return MM_OK;
+}
+
+static int g_stream_nbuf = 3;  // LDS ring depth of the roofline kernel (env MM_MAXSIM_NBUF)
+static int g_stream_wpc = 0;   // wavefronts per CU to launch (0 = what the ring depth allows)
+static int g_stream_nt = 1;    // non-temporal LDS-DMA (env MM_MAXSIM_NT)
+static int g_force_generic = 0;
+static bool g_env_read = false;
+static void read_env() {
+  if (g_env_read) return;
+  g_env_read = true;
+  if (const char* s = getenv("MM_MAXSIM_NBUF")) g_stream_nbuf = atoi(s);
+  if (const char* s = getenv("MM_MAXSIM_WPC")) g_stream_wpc = atoi(s);
+  if (const char* s = getenv("MM_MAXSIM_NT")) g_stream_nt = atoi(s);
+  if (const char* s = getenv("MM_MAXSIM_GENERIC")) g_force_generic = atoi(s);
+  if (g_stream_nbuf < 2) g_stream_nbuf = 2;
+  if (g_stream_nbuf > 4) g_stream_nbuf = 4;
+}
+
+template <int DT, int NBUF, bool NT>
+static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
+  MaxsimArgs a = a0;
+  const int lds = NBUF * kBlkBytes;
+  int wpc = g_stream_wpc > 0 ? g_stream_wpc : (160 * 1024) / lds;
+  if (wpc > 16) wpc = 16;
+  int64_t waves = (int64_t)kCUs * wpc;
+  if (waves > a.n_pairs) waves = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
+  waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  return check_launch("maxsim_stream_kernel");
+}
+
+template <int DT>
+static int launch_stream_cfg(const MaxsimArgs& a, hipStream_t stream) {
+  const bool nt = g_stream_nt != 0;
+  switch (g_stream_nbuf) {
+    case 2: return nt ? launch_stream<DT, 2, true>(a, stream) : launch_stream<DT, 2, false>(a, stream);
+    case 4: return nt ? launch_stream<DT, 4, true>(a, stream) : launch_stream<DT, 4, false>(a, stream);
+    default: return nt ? launch_stream<DT, 3, true>(a, stream) : launch_stream<DT, 3, false>(a, stream);
+  }
+}
+
+static int launch_generic(const MaxsimArgs& a, int dtype, hipStream_t stream) {
+  if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "maxsim: more than 2^31-1 pairs in one generic launch");
+  const dim3 grid((unsigned)a.n_pairs), block(64);
+  if (dtype == MM_F32)
+    hipLaunchKernelGGL(maxsim_generic_kernel<MM_F32>, grid, block, 0, stream, a);
+  else if (dtype == MM_F16)
+    hipLaunchKernelGGL(maxsim_generic_kernel<MM_F16>, grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL(maxsim_generic_kernel<MM_BF16>, grid, block, 0, stream, a);
+  return check_launch("maxsim_generic_kernel");
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" size_t mm_maxsim_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                                             int q_mask_kind, int d_mask_kind) {
+  if (pairs_per_query <= 0) pairs_per_query = 1;
+  const int64_t nq = (n_pairs + pairs_per_query - 1) / pairs_per_query;
+  return packed_mask_bytes(q_mask_kind, nq, Q) + packed_mask_bytes(d_mask_kind, n_pairs, D);
+}
+
+extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
+                             const void* d_mask, int d_mask_kind, float* out, int64_t n_pairs,
+                             int64_t pairs_per_query, int Q, int D, int E, int dtype, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
+  read_env();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = validate(q, d, out, n_pairs, Q, D, E, dtype)) return e;
+  if (pairs_per_query <= 0) return set_error(MM_EINVAL, "maxsim: pairs_per_query must be >= 1");
+  if (n_pairs == 0) return MM_OK;
+  const int64_t nq = (n_pairs + pairs_per_query - 1) / pairs_per_query;
+  MaxsimArgs a{};
+  a.q = q; a.d = d; a.out = out; a.n_pairs = n_pairs; a.ppq = pairs_per_query; a.inb_bd = 0; a.inb_bug = 0;
+  a.Q = Q; a.D = D; a.E = E;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
+  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  const bool stream_ok = !g_force_generic && dtype != MM_F32 && E == 128 && Q <= 32;
+  if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16>(a, stream) : launch_stream_cfg<MM_F16>(a, stream);
+  return launch_generic(a, dtype, stream);
+}
+
+extern "C" size_t mm_maxsim_inbatch_workspace_bytes(int64_t Bq, int64_t Bd, int Q, int D, int q_mask_kind,
+                                                     int d_mask_kind) {
+  return packed_mask_bytes(q_mask_kind, Bq, Q) + packed_mask_bytes(d_mask_kind, Bd, D);
+}
+
+extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
+                                     const void* d_mask, int d_mask_kind, float* out, int64_t Bq, int64_t Bd,
+                                     int Q, int D, int E, int dtype, int bug_compatible, void* workspace,
+                                     size_t workspace_bytes, void* stream_) {
+  read_env();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (Bq < 0 || Bd < 0) return set_error(MM_EINVAL, "maxsim_inbatch: negative batch");
+  if (int e = validate(q, d, out, Bq * Bd, Q, D, E, dtype)) return e;
+  if (bug_compatible && Bq != Bd)
+    return set_error(MM_EINVAL, "maxsim_inbatch: bug_compatible masking (colbert.py:158) requires Bq == Bd (got %lld, %lld)",
+                     (long long)Bq, (long long)Bd);
+  if (Bq * Bd == 0) return MM_OK;
+  MaxsimArgs a{};
+  a.q = q; a.d = d; a.out = out; a.n_pairs = Bq * Bd; a.ppq = 1; a.inb_bd = Bd; a.inb_bug = bug_compatible ? 1 : 0;
+  a.Q = Q; a.D = D; a.E = E;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  if (int e = resolve_mask(q_mask, q_mask_kind, Bq, Q, &ws, &left, stream, &a.qm)) return e;
+  if (int e = resolve_mask(d_mask, d_mask_kind, Bd, D, &ws, &left, stream, &a.dm)) return e;
+  return launch_generic(a, dtype, stream);
+}

@@ -1,0 +1,52 @@
+// Internal helpers shared by the HIP translation units of libmm_native.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mm_native.h"
+
+namespace mm {
+
+typedef __attribute__((ext_vector_type(8))) short short8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kWave = 64;
+constexpr int kCUs = 256;  // MI355X
+
+int set_error(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(MM_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MM_OK;
+}
+
+// ---- mask handling -------------------------------------------------------------------------
+// The kernels consume, per mask row, an int32 "effective length" (positions >= len are padding
+// and never need to be loaded) and optionally one validity bit per position (for non-prefix
+// masks).  LEN_I32 masks are used as-is; U8/I64/F32 masks are packed by pack_mask_kernel.
+struct PackedMask {
+  const int32_t* len = nullptr;    // [rows] or null (all positions real)
+  const uint32_t* bits = nullptr;  // [rows, ceil(L/32)] or null
+};
+
+size_t packed_mask_bytes(int kind, int64_t rows, int L);
+// Resolves a user mask to a PackedMask, launching the pack kernel into `ws` when needed.
+// Advances *ws / *ws_left.  Returns MM_OK or an error code.
+int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, size_t* ws_left,
+                 hipStream_t stream, PackedMask* out);
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float neg_inf() { return -__builtin_huge_valf(); }
+
+}  // namespace mm

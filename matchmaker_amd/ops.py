@@ -1,0 +1,202 @@
+"""Host side of the scoring operators: torch tensors in, torch tensors out, arithmetic in
+libmm_native.so (hand-written HIP, gfx950).  torch is used only for device memory and streams.
+
+Every function launches on the *current* torch stream of the tensors' device, allocates only its
+output (+ a small mask-packing workspace from torch's caching allocator), never synchronises and
+keeps no state, so it is re-entrant from nn.DataParallel's per-GPU threads
+(matchmaker/train.py:201).  CPU tensors are rejected: there is no CPU fallback.
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import NativeError
+
+_DT = {torch.float32: _lib.MM_F32, torch.float16: _lib.MM_F16, torch.bfloat16: _lib.MM_BF16}
+
+
+def _dev_check(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeError("matchmaker_amd operators need HIP device tensors (got a CPU tensor); "
+                              "there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise NativeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _emb(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype not in _DT:
+        raise NativeError(f"{name}: unsupported dtype {t.dtype}")
+    if t.dim() != 3:
+        raise NativeError(f"{name}: expected [rows, tokens, dim], got {tuple(t.shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _mask(m: Optional[torch.Tensor], rows: int, L: int, name: str):
+    """-> (tensor kept alive, pointer, kind)"""
+    if m is None:
+        return None, None, _lib.MASK_NONE
+    if m.dim() == 1:
+        if m.shape[0] != rows:
+            raise NativeError(f"{name}: expected {rows} lengths, got {tuple(m.shape)}")
+        m = m.to(torch.int32).contiguous()
+        return m, m.data_ptr(), _lib.MASK_LEN_I32
+    if tuple(m.shape) != (rows, L):
+        raise NativeError(f"{name}: expected [{rows}, {L}], got {tuple(m.shape)}")
+    if m.dtype == torch.int64:
+        kind = _lib.MASK_I64
+    elif m.dtype == torch.float32:
+        kind = _lib.MASK_F32
+    elif m.dtype in (torch.uint8, torch.bool):
+        kind = _lib.MASK_U8
+    else:
+        m = (m != 0)
+        kind = _lib.MASK_U8
+    m = m.contiguous()
+    return m, m.data_ptr(), kind
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = None,
+           d_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1) -> torch.Tensor:
+    """ColBERT MaxSim (matchmaker/models/colbert.py:68-75; unmasked: :100-112).
+
+    q [n_queries, Q, E], d [n_pairs, D, E]; pair p scores against query p // pairs_per_query.
+    Masks: None | 1-D lengths | [rows, L] bool/uint8/int64/float (nonzero = real token).
+    Returns float32 [n_pairs]."""
+    dev = _dev_check(q, d, q_mask, d_mask)
+    q, d = _emb(q, "q"), _emb(d, "d")
+    if q.dtype != d.dtype:
+        raise NativeError(f"q/d dtype mismatch: {q.dtype} vs {d.dtype}")
+    nq, Q, E = q.shape
+    B, D, E2 = d.shape
+    if E != E2:
+        raise NativeError(f"embedding dims differ: {E} vs {E2}")
+    if pairs_per_query < 1 or nq != (B + pairs_per_query - 1) // pairs_per_query:
+        raise NativeError(f"q has {nq} rows but {B} pairs / {pairs_per_query} per query")
+    qm, qp, qk = _mask(q_mask, nq, Q, "q_mask")
+    dm, dp, dk = _mask(d_mask, B, D, "d_mask")
+    L = _lib.lib()
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    if B == 0:
+        return out
+    with torch.cuda.device(dev):
+        wsb = L.mm_maxsim_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        rc = L.mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), B, pairs_per_query,
+                             Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+    _lib.check(rc, "mm_maxsim_fwd")
+    return out
+
+
+def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Tensor,
+                   d_mask: Optional[torch.Tensor], bug_compatible: bool = False) -> torch.Tensor:
+    """All-pairs MaxSim [Bq, Bd] (matchmaker/models/colbert.py:154-162).  bug_compatible=True masks
+    score[i, j] with document i's mask as the reference does (and needs Bq == Bd)."""
+    dev = _dev_check(q, d, q_mask, d_mask)
+    q, d = _emb(q, "q"), _emb(d, "d")
+    if q.dtype != d.dtype:
+        raise NativeError(f"q/d dtype mismatch: {q.dtype} vs {d.dtype}")
+    Bq, Q, E = q.shape
+    Bd, D, E2 = d.shape
+    if E != E2:
+        raise NativeError(f"embedding dims differ: {E} vs {E2}")
+    qm, qp, qk = _mask(q_mask, Bq, Q, "q_mask")
+    dm, dp, dk = _mask(d_mask, Bd, D, "d_mask")
+    L = _lib.lib()
+    out = torch.empty((Bq, Bd), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        wsb = L.mm_maxsim_inbatch_workspace_bytes(Bq, Bd, Q, D, qk, dk)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        rc = L.mm_maxsim_inbatch_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), Bq, Bd, Q, D, E,
+                                     _DT[q.dtype], 1 if bug_compatible else 0,
+                                     ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+    _lib.check(rc, "mm_maxsim_inbatch_fwd")
+    return out
+
+
+def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
+                mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor,
+                pairs_per_query: int = 1, return_per_kernel: bool = False):
+    """TK kernel pooling (matchmaker/models/published/ecai20_tk.py:105-124).
+
+    q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings; mu/sigma/alpha/w [K].
+    Returns float32 [n_pairs] (and per_kernel [n_pairs, K] when asked)."""
+    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w)
+    q, d = _emb(q, "q"), _emb(d, "d")
+    if q.dtype != torch.float32 or d.dtype != torch.float32:
+        raise NativeError("kernel_pool: float32 embeddings only (the reference cosine rejects bf16, "
+                          "and tk.yaml sets use_fp16: False)")
+    nq, Q, E = q.shape
+    B, D, E2 = d.shape
+    if E != E2:
+        raise NativeError(f"embedding dims differ: {E} vs {E2}")
+    if pairs_per_query < 1 or nq != (B + pairs_per_query - 1) // pairs_per_query:
+        raise NativeError(f"q has {nq} rows but {B} pairs / {pairs_per_query} per query")
+    K = mu.numel()
+    f = lambda t: t.detach().reshape(-1).to(torch.float32).contiguous()
+    mu, sigma, alpha, w = f(mu), f(sigma), f(alpha), f(w)
+    if not (sigma.numel() == alpha.numel() == w.numel() == K):
+        raise NativeError("kernel_pool: mu/sigma/alpha/w must all have K elements")
+    qm, qp, qk = _mask(q_mask, nq, Q, "q_mask")
+    dm, dp, dk = _mask(d_mask, B, D, "d_mask")
+    if qk in (_lib.MASK_U8, _lib.MASK_I64):
+        qm = qm.to(torch.float32); qp, qk = qm.data_ptr(), _lib.MASK_F32
+    if dk in (_lib.MASK_U8, _lib.MASK_I64):
+        dm = dm.to(torch.float32); dp, dk = dm.data_ptr(), _lib.MASK_F32
+    L = _lib.lib()
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
+    if B:
+        with torch.cuda.device(dev):
+            rc = L.mm_kernel_pool_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, mu.data_ptr(), sigma.data_ptr(),
+                                      alpha.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                      pk.data_ptr() if pk is not None else None, B, pairs_per_query,
+                                      Q, D, E, K, _lib.MM_F32, _stream(dev))
+        _lib.check(rc, "mm_kernel_pool_fwd")
+    return (out, pk) if return_per_kernel else out
+
+
+def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor, chunk_slot: torch.Tensor,
+              q_mask: torch.Tensor, params: torch.Tensor, B: int, C: int, K: int, saturation: str = "embedding",
+              return_windows: bool = False):
+    """TKL windowed kernel pooling + region top-k (sigir20_tkl.py:180-286).  See mm_native.h."""
+    dev = _dev_check(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params)
+    q_ctx, chunks = _emb(q_ctx, "q_ctx"), _emb(chunks, "chunks")
+    if q_ctx.dtype != torch.float32 or chunks.dtype != torch.float32:
+        raise NativeError("tkl_score: float32 only (tkl.yaml use_fp16: False)")
+    Bq, Q, E = q_ctx.shape
+    P = chunks.shape[0]
+    if Bq != B or chunks.shape[1] != 50 or chunks.shape[2] != E:
+        raise NativeError(f"tkl_score: bad shapes q_ctx {tuple(q_ctx.shape)} chunks {tuple(chunks.shape)}")
+    sat = {"embedding": _lib.TKL_SAT_EMBEDDING, "log": _lib.TKL_SAT_LOG}.get(saturation)
+    if sat is None:
+        raise NativeError(f"tkl_score: saturation {saturation!r} is dead code in the reference "
+                          "(reads the undefined `query_idfs`, sigir20_tkl.py:214,236)")
+    chunk_mask = chunk_mask.to(torch.float32).contiguous()
+    chunk_slot = chunk_slot.to(torch.int32).contiguous()
+    q_mask = q_mask.to(torch.float32).contiguous()
+    params = params.to(torch.float32).contiguous()
+    W = (max(C * 40, 30) - 30) // 2 + 1
+    L = _lib.lib()
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    win = torch.empty((B, W), dtype=torch.float32, device=dev)
+    if B:
+        with torch.cuda.device(dev):
+            wsb = L.mm_tkl_workspace_bytes(B, C, Q, K)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+            rc = L.mm_tkl_fwd(q_ctx.data_ptr(), chunks.data_ptr(), chunk_mask.data_ptr(), chunk_slot.data_ptr(),
+                              q_mask.data_ptr(), params.data_ptr(), win.data_ptr(), out.data_ptr(), B, P, C, Q, E,
+                              K, sat, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+        _lib.check(rc, "mm_tkl_fwd")
+    return (out, win) if return_windows else out

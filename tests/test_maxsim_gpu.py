@@ -1,0 +1,171 @@
+"""GPU parity tests for the MaxSim path: HIP kernels (through the C ABI / ctypes) vs the oracle and
+the committed golden vectors of the real reference.  Tolerances from BASELINE.json: 1e-3 (fp32),
+1e-2 (bf16 / fp16), identical rank order (tie policy: SURVEY.md §7)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [(torch.bfloat16, util.TOL_BF16), (torch.float16, util.TOL_BF16), (torch.float32, util.TOL_FP32)]
+
+
+def _to(x, dtype, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype).to(dev)
+
+
+def _rounded(x, dtype):
+    """the values the kernel actually sees, as fp32 numpy (oracle input)"""
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype).float().numpy()
+
+
+@pytest.mark.parametrize("fname", util.golden_files("colbert_"))
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_forward_matches_reference_golden(fname, dtype, tol):
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = util.load(fname)
+    q, d = _to(g["q"], dtype, dev), _to(g["d"], dtype, dev)
+    ref = g["forward"]
+    if dtype == torch.float16:   # inputs are bf16-exact; fp16 may round tiny values: re-derive with the oracle
+        ref = O.maxsim_paired(_rounded(g["q"], dtype), _rounded(g["d"], dtype), g["q_mask"], g["d_mask"])
+    for mk in (torch.int64, torch.uint8, torch.bool, torch.float32, torch.int32):
+        qm = torch.from_numpy(g["q_mask"]).to(mk).to(dev)
+        dm = torch.from_numpy(g["d_mask"]).to(mk).to(dev)
+        out = ops.maxsim(q, d, qm, dm, pairs_per_query=1).cpu().numpy()
+        np.testing.assert_allclose(out, ref, atol=tol, rtol=1e-4, err_msg=f"mask dtype {mk}")
+    # unmasked aggregation (colbert.py:100-112)
+    ref_agg = g["forward_aggregation"]
+    if dtype == torch.float16:
+        ref_agg = O.maxsim_unmasked(_rounded(g["q"], dtype), _rounded(g["d"], dtype))
+    out = ops.maxsim(q, d, None, None).cpu().numpy()
+    np.testing.assert_allclose(out, ref_agg, atol=tol, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fname", util.golden_files("colbert_"))
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, util.TOL_BF16), (torch.float32, util.TOL_FP32)])
+def test_inbatch_matches_reference_golden(fname, dtype, tol):
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = util.load(fname)
+    q, d = _to(g["q"], dtype, dev), _to(g["d"], dtype, dev)
+    qm = torch.from_numpy(g["q_mask"]).to(torch.int64).to(dev)
+    dm = torch.from_numpy(g["d_mask"]).to(torch.int64).to(dev)
+    bug = ops.maxsim_inbatch(q, qm, d, dm, bug_compatible=True).cpu().numpy()
+    np.testing.assert_allclose(bug, g["forward_inbatch_aggregation"], atol=tol, rtol=1e-4)
+    ok = ops.maxsim_inbatch(q, qm, d, dm, bug_compatible=False).cpu().numpy()
+    ref_ok = O.maxsim_inbatch(g["q"], g["q_mask"], g["d"], g["d_mask"], bug_compatible=False)
+    np.testing.assert_allclose(ok, ref_ok, atol=tol, rtol=1e-4)
+    # Bq != Bd: the reference raises; bug-compatible mode refuses, correct mode works
+    with pytest.raises(Exception):
+        ops.maxsim_inbatch(q[:1], qm[:1], d[:3], dm[:3], bug_compatible=True)
+    ok13 = ops.maxsim_inbatch(q[:1], qm[:1], d[:3], dm[:3], bug_compatible=False).cpu().numpy()
+    np.testing.assert_allclose(ok13, ref_ok[:1, :3], atol=tol, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("Q,D,E,ppq,nq", [(32, 180, 128, 37, 5), (17, 64, 128, 8, 3), (32, 33, 128, 1, 40),
+                                           (20, 200, 64, 10, 2), (40, 96, 256, 4, 3), (1, 1, 16, 3, 2)])
+def test_shared_query_layout_random(dtype, tol, Q, D, E, ppq, nq):
+    """1 query x C candidates layout (pairs_per_query > 1), ragged lengths incl. empty docs,
+    last query with fewer candidates."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 1000 + D)
+    B = nq * ppq - (ppq // 2 if nq > 1 else 0)
+    q = (torch.randn(nq, Q, E, generator=g) * 0.25).to(dtype)
+    d = (torch.randn(B, D, E, generator=g) * 0.25).to(dtype)
+    q_len = torch.randint(1, Q + 1, (nq,), generator=g).to(torch.int32)
+    d_len = torch.randint(0, D + 1, (B,), generator=g).to(torch.int32)
+    d_len[0] = D
+    d_len[-1] = 0
+    out = ops.maxsim(q.to(dev), d.to(dev), q_len.to(dev), d_len.to(dev), pairs_per_query=ppq).cpu().numpy()
+    qi = np.arange(B) // ppq
+    qm = (np.arange(Q)[None, :] < q_len.numpy()[:, None])
+    dm = (np.arange(D)[None, :] < d_len.numpy()[:, None])
+    ref = O.maxsim_paired(q.float().numpy()[qi], d.float().numpy(), qm[qi], dm)
+    np.testing.assert_allclose(out, ref, atol=tol, rtol=1e-4)
+
+
+def test_padding_content_is_ignored_and_holes_are_sentinel():
+    """Garbage (inf/nan) in padded document rows must not leak; a hole inside the document counts
+    as -1000 exactly like the reference's masked assignment (colbert.py:69)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(5)
+    B, Q, D, E = 6, 32, 180, 128
+    q = torch.nn.functional.normalize(torch.randn(1, Q, E, generator=g), dim=-1).to(torch.bfloat16)
+    d = torch.nn.functional.normalize(torch.randn(B, D, E, generator=g), dim=-1).to(torch.bfloat16)
+    dm = torch.ones(B, D, dtype=torch.int64)
+    dm[0, 100:] = 0
+    dm[1, 31:] = 0
+    dm[2, 32:] = 0
+    dm[3, ::2] = 0          # every other token masked
+    dm[4, :] = 0
+    d2 = d.clone()
+    d2[0, 100:] = float("inf")
+    d2[1, 31:] = float("nan")
+    d2[2, 32:] = -float("inf")
+    out = ops.maxsim(q.to(dev), d2.to(dev), None, dm.to(dev), pairs_per_query=B).cpu().numpy()
+    ref = O.maxsim_paired(np.repeat(q.float().numpy(), B, 0), d.float().numpy(), np.ones((B, Q)), dm.numpy())
+    assert np.isfinite(out).all()
+    np.testing.assert_allclose(out, ref, atol=util.TOL_BF16)
+    assert out[4] == -1000.0 * Q
+
+
+def test_config2_full_size_properties_and_rank_order():
+    """BASELINE.json config 2 at full size (64 queries x 1000 candidates, Q32/D180/E128 bf16):
+    determinism, permutation equivariance over candidates, exact power-of-two linearity, a sampled
+    comparison with the oracle, and identical top-k rank order under the documented tie policy."""
+    from matchmaker_amd import ops, synth
+    dev = util.require_gpu()
+    nq, C = 64, 1000
+    q, d, q_len, d_len = synth.colbert_batch(nq, C, dtype=torch.bfloat16, device=dev, lengths="msmarco")
+    out = ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)
+    out2 = ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)
+    assert torch.equal(out, out2), "non-deterministic"
+    # permutation of candidates inside each query permutes the scores
+    perm = torch.stack([torch.randperm(C, device=dev) + i * C for i in range(nq)]).reshape(-1)
+    outp = ops.maxsim(q, d[perm].contiguous(), q_len, d_len[perm].contiguous(), pairs_per_query=C)
+    assert torch.equal(outp, out[perm])
+    # linearity: 2*q -> 2*score exactly where no -1000 sentinel takes part (d_len >= 8 > 0, but padded docs
+    # contribute the sentinel only if it wins the max, which it cannot against cosines in [-1, 1])
+    outs = ops.maxsim((q.float() * 2).to(torch.bfloat16), d, q_len, d_len, pairs_per_query=C)
+    assert torch.equal(outs, out * 2)
+    # sampled oracle comparison + per-query rank order on 4 whole queries
+    sel = [0, 17, 40, 63]
+    qn = q.float().cpu().numpy()
+    for i in sel:
+        dn = d[i * C:(i + 1) * C].float().cpu().numpy()
+        dm = synth.len_to_mask(d_len[i * C:(i + 1) * C], 180).cpu().numpy()
+        qm = np.repeat(synth.len_to_mask(q_len[i:i + 1], 32).cpu().numpy(), C, 0)
+        ref32 = O.maxsim_paired(np.repeat(qn[i:i + 1], C, 0), dn, qm, dm)
+        ref64 = O.maxsim_paired(np.repeat(qn[i:i + 1], C, 0), dn, qm, dm, dtype=np.float64)
+        got = out[i * C:(i + 1) * C].cpu().numpy()
+        np.testing.assert_allclose(got, ref32, atol=util.TOL_BF16)
+        # rank order: identical wherever the fp64 gap between neighbours exceeds the fp32 noise bound
+        order_ref = O.rank_order(ref64)
+        order_got = O.rank_order(got)
+        noise = 4 * 32 * 128 * np.finfo(np.float32).eps        # 4 x (Q sums of E-long fp32 dots of unit vectors)
+        gaps = np.abs(np.diff(ref64[order_ref]))
+        decided = np.concatenate([[True], gaps > noise]) & np.concatenate([gaps > noise, [True]])
+        assert (order_ref[decided] == order_got[decided]).all()
+        for k in (10, 20, 100):
+            if gaps[k - 1] > noise:
+                assert set(order_ref[:k]) == set(order_got[:k])
+
+
+def test_errors_are_loud():
+    from matchmaker_amd import ops, NativeError
+    dev = util.require_gpu()
+    q = torch.zeros(1, 4, 12, dtype=torch.bfloat16, device=dev)   # E=12: rows not 16-byte multiples
+    d = torch.zeros(2, 5, 12, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(NativeError):
+        ops.maxsim(q, d, pairs_per_query=2)
+    with pytest.raises(NativeError):
+        ops.maxsim(q.cpu(), d.cpu(), pairs_per_query=2)              # no CPU fallback
+    with pytest.raises(NativeError):
+        ops.maxsim(torch.zeros(3, 4, 16, device=dev), torch.zeros(2, 5, 16, device=dev), pairs_per_query=2)
