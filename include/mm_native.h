@@ -108,14 +108,20 @@ int mm_maxsim_inbatch_fwd(const void* q, const void* d,
  *   q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings
  *   mu, sigma, alpha, w: float32[K] device pointers, K <= 16
  *   per_kernel: optional float32 [n_pairs, K] (the reference's secondary output), may be NULL
+ *   masks: float {0,1} as the reference passes them (MM_MASK_F32) or any other mm mask kind;
+ *          nonzero = real token.  workspace as for mm_maxsim_fwd.
  */
+size_t mm_kernel_pool_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                                      int q_mask_kind, int d_mask_kind);
+
 int mm_kernel_pool_fwd(const void* q, const void* d,
                        const void* q_mask, int q_mask_kind,
                        const void* d_mask, int d_mask_kind,
                        const float* mu, const float* sigma, const float* alpha, const float* w,
                        float* out, float* per_kernel,
                        int64_t n_pairs, int64_t pairs_per_query,
-                       int Q, int D, int E, int K, int dtype, void* stream);
+                       int Q, int D, int E, int K, int dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TKL: match + RBF kernels per document position, sliding-window (30, stride 2) pooling with

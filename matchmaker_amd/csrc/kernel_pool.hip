@@ -1,7 +1,487 @@
-// placeholder until the TK kernel lands (next commit)
+// TK kernel pooling for MI355X (gfx950): cosine match matrix + K RBF kernels + log-sum pooling.
+//
+//   cos[i,j] = <q_i, d_j> / ((|q_i| + 1e-13)(|d_j| + 1e-13))          (allennlp CosineMatrixAttention,
+//                                                                       call site ecai20_tk.py:105)
+//   pkq[i,k] = sum_j dmask[j] * exp(-(cos[i,j] - mu_k)^2 / (2 sigma_k^2))     ecai20_tk.py:112-120
+//   out      = sum_k w_k * sum_i qmask[i] * log(max(pkq[i,k] * alpha_k, 1e-10))   ecai20_tk.py:121-124
+//
+// fp32 throughout (tk.yaml: use_fp16 False; the RBF with sigma = 0.1 amplifies cosine error ~6x,
+// so the dot products use the exact-f32 MFMA v_mfma_f32_32x32x2_f32).
+//
+// kernel_pool_stream_kernel<NS> (E == 100*NS, Q <= 32): one wavefront per workgroup.  The D stream
+// moves HBM -> LDS by LDS-DMA in slices of 32 document tokens x 25 16-B chunks (12.8 KB; row stride
+// 400 B = 100 dwords keeps every ds_read_b128 service group on 16 distinct bank slots, no swizzle
+// needed); the query tile lives in VGPRs as MFMA B operands; document tokens sit on the MFMA M
+// axis, so each lane owns one query token (column) x 16 document rows and the K RBF sums are
+// lane-local accumulators.  Row norms of the document tokens are accumulated by the lanes from the
+// very A operands they feed to the MFMA (free VALU work in the MFMA shadow).
+//
+// kernel_pool_generic_kernel: any E (multiple of 4), Q, D; direct fragment loads.
 #include "mm_internal.h"
-extern "C" int mm_kernel_pool_fwd(const void*, const void*, const void*, int, const void*, int, const float*,
-                                  const float*, const float*, const float*, float*, float*, int64_t, int64_t, int,
-                                  int, int, int, int, void*) {
-  return mm::set_error(MM_EUNSUPPORTED, "mm_kernel_pool_fwd: not built yet");
+
+namespace mm {
+
+constexpr int kMaxK = 16;
+
+struct KpArgs {
+  const float* q;
+  const float* d;
+  PackedMask qm, dm;
+  const float* mu;
+  const float* sigma;
+  const float* alpha;
+  const float* w;
+  float* out;
+  float* per_kernel;  // optional [n_pairs, K]
+  int64_t n_pairs;
+  int64_t ppq;
+  int Q, D, E, K;
+  int64_t pairs_per_wave;
+};
+
+__device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
+
+__device__ __forceinline__ uint32_t sload_u32(const void* base, int64_t idx) {
+  uint32_t v;
+  const uint32_t* p = (const uint32_t*)base + idx;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+
+// RBF constants in exp2 form: exp(-(c-mu)^2/(2 s^2)) = exp2((c-mu)^2 * c2), c2 = -log2(e)/(2 s^2)
+struct Rbf {
+  float mu[kMaxK];
+  float c2[kMaxK];
+  float alpha[kMaxK];
+  float w[kMaxK];
+};
+
+__device__ __forceinline__ float sload_f32(const float* base, int idx) {
+  return __builtin_bit_cast(float, sload_u32(base, idx));
+}
+
+// Kernel parameters are wave-uniform: fetch them through the scalar cache (SGPRs, no vmcnt traffic
+// that would make the compiler drain the LDS-DMA queue inside the block loop).
+template <int K>
+__device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, const float* alpha, const float* w, Rbf& rbf) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float sg = sload_f32(sigma, k);
+    rbf.mu[k] = sload_f32(mu, k);
+    rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
+    rbf.alpha[k] = sload_f32(alpha, k);
+    rbf.w[k] = sload_f32(w, k);
+  }
+}
+
+// Epilogue of one 32-token document block: cosine scaling + K RBF kernels, summed into pk[k].
+// acc[i]: raw dot of document row rowof(i)+4h with this lane's query token; rdr[i]: 1/(|d|+tiny) of
+// that row; vbits (already shifted by 4h): bit rowof(i) set <=> the row is a real token.
+template <int K>
+__device__ __forceinline__ void rbf_block(float (&pk)[kMaxK], const f32x16& acc, const float (&rdr)[16], float rq,
+                                          uint32_t vbits, const Rbf& rbf) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float c = (acc[i] * rq) * rdr[i];
+    const bool valid = (vbits >> rowof(i)) & 1u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float t = c - rbf.mu[k];
+      const float e = __builtin_amdgcn_exp2f(t * t * rbf.c2[k]);
+      pk[k] += valid ? e : 0.0f;
+    }
+  }
+}
+
+// log-sum pooling of one pair: pk[k] (this lane's query token, both halves already combined).
+template <int K>
+__device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
+                                            int lane, const Rbf& rbf) {
+  float total = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], 1e-10f));
+    lg = qvalid ? lg : 0.0f;
+    const float s = wave_sum(lg);
+    if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
+    total += rbf.w[k] * s;
+  }
+  if (lane == 0) a.out[pair] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming kernel
+// ---------------------------------------------------------------------------------------------
+constexpr int kSC = 25;                       // 16-B chunks per row per slice (odd: conflict-free)
+constexpr int kSliceInstr = 13;               // ceil(32*25 / 64) LDS-DMA instructions per slice
+constexpr int kSliceBytes = kSliceInstr * 1024;
+constexpr int kPairSteps = 13;                // chunk pairs per slice (last one half empty)
+
+template <bool NT>
+__device__ __forceinline__ void issue_slice(const char* gbase, const uint32_t (&voff)[kSliceInstr], uint32_t vmax,
+                                            bool clamp, uint32_t lds_dst) {
+  uint32_t v[kSliceInstr];
+#pragma unroll
+  for (int n = 0; n < kSliceInstr; ++n) v[n] = clamp ? (voff[n] < vmax ? voff[n] : vmax) : voff[n];
+  uint32_t keep;
+#define MM_GLDS(N) "s_nop 0\n\tglobal_load_lds_dwordx4 %" #N ", %14" NTS "\n\ts_add_u32 m0, m0, 0x400\n\t"
+#define NTS " nt"
+  if (NT) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %15\n\t" MM_GLDS(1) MM_GLDS(2) MM_GLDS(3)
+                     MM_GLDS(4) MM_GLDS(5) MM_GLDS(6) MM_GLDS(7) MM_GLDS(8) MM_GLDS(9) MM_GLDS(10) MM_GLDS(11)
+                         MM_GLDS(12) MM_GLDS(13) "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "s"(gbase), "s"(lds_dst)
+                 : "memory", "scc");
+  } else {
+#undef NTS
+#define NTS ""
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %15\n\t" MM_GLDS(1) MM_GLDS(2) MM_GLDS(3)
+                     MM_GLDS(4) MM_GLDS(5) MM_GLDS(6) MM_GLDS(7) MM_GLDS(8) MM_GLDS(9) MM_GLDS(10) MM_GLDS(11)
+                         MM_GLDS(12) MM_GLDS(13) "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]),
+                   "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "s"(gbase), "s"(lds_dst)
+                 : "memory", "scc");
+  }
+#undef NTS
+#undef MM_GLDS
+}
+
+__device__ __forceinline__ void wait_slices(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+  }
+}
+
+// 13 x 16 B of this lane's query row chunk pairs of one slice (+ vmcnt(0): runs once per query)
+__device__ __forceinline__ void load_q_slice(const char* base, f32x4 (&qf)[kPairSteps]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %13, off\n\t"
+      "global_load_dwordx4 %1, %13, off offset:32\n\t"
+      "global_load_dwordx4 %2, %13, off offset:64\n\t"
+      "global_load_dwordx4 %3, %13, off offset:96\n\t"
+      "global_load_dwordx4 %4, %13, off offset:128\n\t"
+      "global_load_dwordx4 %5, %13, off offset:160\n\t"
+      "global_load_dwordx4 %6, %13, off offset:192\n\t"
+      "global_load_dwordx4 %7, %13, off offset:224\n\t"
+      "global_load_dwordx4 %8, %13, off offset:256\n\t"
+      "global_load_dwordx4 %9, %13, off offset:288\n\t"
+      "global_load_dwordx4 %10, %13, off offset:320\n\t"
+      "global_load_dwordx4 %11, %13, off offset:352\n\t"
+      "global_load_dwordx4 %12, %14, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]), "=&v"(qf[4]), "=&v"(qf[5]), "=&v"(qf[6]),
+        "=&v"(qf[7]), "=&v"(qf[8]), "=&v"(qf[9]), "=&v"(qf[10]), "=&v"(qf[11]), "=&v"(qf[12])
+      : "v"(base), "v"(base + 384 - (threadIdx.x >> 5) * 16)  // last pair: chunk 24 only (h=1 lanes get a dummy)
+      : "memory");
+}
+
+template <int NS, int K, int NBUF, bool NT>
+__global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  constexpr int E = 100 * NS;
+  constexpr int RB = E * 4;  // row bytes
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* rdbuf = (float*)(smem + NBUF * kSliceBytes);  // 32 floats: 1/(|d|+tiny) of the block's rows
+
+  // LDS-DMA source offsets: slot s = 64n + lane of the slice image [32 rows][25 chunks]
+  uint32_t voff[kSliceInstr];
+#pragma unroll
+  for (int n = 0; n < kSliceInstr; ++n) {
+    int s = 64 * n + lane;
+    if (s > 32 * kSC - 1) s = 32 * kSC - 1;  // the last half instruction re-reads the final chunk
+    const int row = s / kSC, c = s - row * kSC;
+    voff[n] = (uint32_t)(row * RB + c * 16);
+  }
+  const uint32_t vmax_tail = (uint32_t)((rows_last - 1) * RB + (kSC - 1) * 16);
+  const uint32_t a_off = (uint32_t)(r * (kSC * 16) + h * 16);  // this lane's A-fragment base inside a slice
+
+  Rbf rbf;
+  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+
+  const char* dbase = (const char*)a.d;
+  auto doc_len = [&](int64_t p) -> int {
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
+    return len < 0 ? 0 : (len > D ? D : len);
+  };
+
+  // producer cursor over (pair, block, slice)
+  int64_t pp = p0;
+  int pt = 0, ps = 0, pn = 0;
+  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      const char* g = dbase + (pp * D + (int64_t)pt * 32) * RB + ps * (kSC * 16);
+      issue_slice<NT>(g, voff, vmax_tail, pt == nblk_tot - 1 && rows_last != 32, lds0 + (uint32_t)pbuf * kSliceBytes);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (++ps == NS) {
+        ps = 0;
+        if (++pt == pn) {
+          pt = 0;
+          ++pp;
+          while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+        }
+      }
+    }
+  };
+  top_up();
+
+  f32x4 qf[NS][kPairSteps];
+  float rq = 0.0f;
+  bool qvalid = false;
+  int64_t cur_q = -1;
+  int64_t qi = p0 / a.ppq;
+  int64_t q_left = a.ppq - (p0 - qi * a.ppq);
+
+  for (int64_t pair = p0; pair < p1; ++pair) {
+    if (q_left == 0) {
+      ++qi;
+      q_left = a.ppq;
+    }
+    --q_left;
+    if (qi != cur_q) {
+      cur_q = qi;
+      const int qr = r < Q ? r : Q - 1;
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB + h * 16;
+      float ss = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        load_q_slice(qrow + s * (kSC * 16), qf[s]);
+        if (h) qf[s][kPairSteps - 1] = f32x4{0, 0, 0, 0};  // chunk 25 of the slice does not exist
+#pragma unroll
+        for (int p = 0; p < kPairSteps; ++p)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ss += qf[s][p][j] * qf[s][p][j];
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      rq = 1.0f / (sqrtf(ss) + 1e-13f);
+      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      qvalid = r < Q && r < qlen;
+      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+    }
+    const int len = doc_len(pair);
+    const int nb = (len + 31) >> 5;
+    float pk[kMaxK];
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) pk[k] = 0.0f;
+
+    for (int t = 0; t < nb; ++t) {
+      f32x16 acc = {0};
+      float ss = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        top_up();
+        wait_slices(inflight - 1);
+        const char* buf = smem + cbuf * kSliceBytes + a_off;
+#pragma unroll
+        for (int p = 0; p < kPairSteps; ++p) {
+          f32x4 av = *(const f32x4*)(buf + p * 32);
+          if (p == kPairSteps - 1 && h) av = f32x4{0, 0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], qf[s][p][j], acc, 0, 0, 0);
+            ss += av[j] * av[j];
+          }
+        }
+        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+        --inflight;
+      }
+      // document-token norms: lane (r,h) summed the even/odd chunks of row r
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      float rdr[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
+        rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
+      }
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
+    finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic kernel: one wavefront per pair, direct fragment loads, any E % 4 == 0, any Q / D.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a) {
+  __shared__ float rdbuf[32];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t pair = blockIdx.x;
+  if (pair >= a.n_pairs) return;
+  const int D = a.D, Q = a.Q, E = a.E;
+  const int64_t rowb = (int64_t)E * 4;
+  const int64_t qi = pair / a.ppq;
+  const int nblk_tot = (D + 31) >> 5;
+  const int qwords = (Q + 31) >> 5;
+  const int nch = E >> 2;
+  int len = a.dm.len ? a.dm.len[pair] : D;
+  len = len < 0 ? 0 : (len > D ? D : len);
+  const int nb = (len + 31) >> 5;
+  const int qlen = a.qm.len ? a.qm.len[qi] : Q;
+  const char* dbase = (const char*)a.d + pair * D * rowb;
+  const char* qbase = (const char*)a.q + qi * Q * rowb;
+  Rbf rbf;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float sg = a.sigma[k];
+    rbf.mu[k] = a.mu[k];
+    rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
+    rbf.alpha[k] = a.alpha[k];
+    rbf.w[k] = a.w[k];
+  }
+  float tot[kMaxK];
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) tot[k] = 0.0f;
+
+  for (int n = 0; n < qwords; ++n) {
+    const int qtok = 32 * n + r;
+    const int qr = qtok < Q ? qtok : Q - 1;
+    bool qvalid = qtok < Q && qtok < qlen;
+    if (a.qm.bits) qvalid = qvalid && ((a.qm.bits[qi * qwords + n] >> r) & 1u);
+    const char* qrow = qbase + qr * rowb;
+    float qss = 0.0f;
+    for (int c = h; c < nch; c += 2) {
+      const f32x4 v = *(const f32x4*)(qrow + c * 16);
+      qss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    qss += __shfl_xor(qss, 32, 64);
+    const float rq = 1.0f / (sqrtf(qss) + 1e-13f);
+    float pk[kMaxK];
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) pk[k] = 0.0f;
+    for (int t = 0; t < nb; ++t) {
+      const int drow = 32 * t + r;
+      const char* dr = dbase + (drow < D ? drow : D - 1) * rowb;
+      f32x16 acc = {0};
+      float ss = 0.0f;
+      for (int c = 0; c < nch; c += 2) {
+        const int cc = c + h;
+        f32x4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
+        if (cc < nch) {
+          av = *(const f32x4*)(dr + cc * 16);
+          bv = *(const f32x4*)(qrow + cc * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+          ss += av[j] * av[j];
+        }
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      __syncthreads();
+      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      __syncthreads();
+      float rdr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rdr[i] = rdbuf[rowof(i) + 4 * h];
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (a.dm.bits[pair * nblk_tot + t] & ex) : ex;
+      rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float v = pk[k] + __shfl_xor(pk[k], 32, 64);
+      float lg = __logf(fmaxf(v * rbf.alpha[k], 1e-10f));
+      tot[k] += wave_sum(qvalid ? lg : 0.0f);
+    }
+  }
+  float total = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = tot[k];
+    total += rbf.w[k] * tot[k];
+  }
+  if (lane == 0) a.out[pair] = total;
+}
+
+template <int K>
+static int launch_k(const KpArgs& a0, hipStream_t stream) {
+  KpArgs a = a0;
+  static int force_generic = -1, nbuf_env = 0;
+  if (force_generic < 0) {
+    force_generic = getenv("MM_KP_GENERIC") ? atoi(getenv("MM_KP_GENERIC")) : 0;
+    nbuf_env = getenv("MM_KP_NBUF") ? atoi(getenv("MM_KP_NBUF")) : 3;
+  }
+  const bool stream_ok = !force_generic && a.Q <= 32 && (a.E == 100 || a.E == 200 || a.E == 300);
+  if (stream_ok) {
+    constexpr int NBUF = 3;
+    (void)nbuf_env;
+    const int lds = NBUF * kSliceBytes + 128;
+    int64_t waves = (int64_t)kCUs * 4;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
+    if (waves > a.n_pairs) waves = a.n_pairs;
+    a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
+    waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+    const dim3 grid((unsigned)waves), block(64);
+    if (a.E == 100)
+      hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true>), grid, block, lds, stream, a);
+    else if (a.E == 200)
+      hipLaunchKernelGGL((kernel_pool_stream_kernel<2, K, NBUF, true>), grid, block, lds, stream, a);
+    else
+      hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true>), grid, block, lds, stream, a);
+    return check_launch("kernel_pool_stream_kernel");
+  }
+  if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
+  hipLaunchKernelGGL((kernel_pool_generic_kernel<K>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
+  return check_launch("kernel_pool_generic_kernel");
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" size_t mm_kernel_pool_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                                                  int q_mask_kind, int d_mask_kind) {
+  if (pairs_per_query <= 0) pairs_per_query = 1;
+  return packed_mask_bytes(q_mask_kind, (n_pairs + pairs_per_query - 1) / pairs_per_query, Q) +
+         packed_mask_bytes(d_mask_kind, n_pairs, D);
+}
+
+extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
+                                  const void* d_mask, int d_mask_kind, const float* mu, const float* sigma,
+                                  const float* alpha, const float* w, float* out, float* per_kernel,
+                                  int64_t n_pairs, int64_t pairs_per_query, int Q, int D, int E, int K, int dtype,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q || !d || !out || !mu || !sigma || !alpha || !w) return set_error(MM_EINVAL, "kernel_pool: null pointer");
+  if (dtype != MM_F32)
+    return set_error(MM_EUNSUPPORTED, "kernel_pool: float32 only (the reference cosine rejects bf16; tk.yaml use_fp16: False)");
+  if (n_pairs < 0 || Q <= 0 || D <= 0 || E <= 0 || pairs_per_query <= 0) return set_error(MM_EINVAL, "kernel_pool: bad shape");
+  if (K != 11) return set_error(MM_EUNSUPPORTED, "kernel_pool: K=%d kernels (only the reference's 11 are instantiated)", K);
+  if (E % 4) return set_error(MM_EUNSUPPORTED, "kernel_pool: E=%d rows are not 16-byte multiples", E);
+  if (((uintptr_t)q | (uintptr_t)d) & 15) return set_error(MM_EINVAL, "kernel_pool: q/d must be 16-byte aligned");
+  if (n_pairs == 0) return MM_OK;
+  KpArgs a{};
+  a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w;
+  a.out = out; a.per_kernel = per_kernel; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
+  a.Q = Q; a.D = D; a.E = E; a.K = K;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  if (int e = resolve_mask(q_mask, q_mask_kind, (n_pairs + pairs_per_query - 1) / pairs_per_query, Q, &ws, &left, stream, &a.qm))
+    return e;
+  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  return launch_k<11>(a, stream);
 }

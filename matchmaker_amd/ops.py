@@ -150,19 +150,18 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
         raise NativeError("kernel_pool: mu/sigma/alpha/w must all have K elements")
     qm, qp, qk = _mask(q_mask, nq, Q, "q_mask")
     dm, dp, dk = _mask(d_mask, B, D, "d_mask")
-    if qk in (_lib.MASK_U8, _lib.MASK_I64):
-        qm = qm.to(torch.float32); qp, qk = qm.data_ptr(), _lib.MASK_F32
-    if dk in (_lib.MASK_U8, _lib.MASK_I64):
-        dm = dm.to(torch.float32); dp, dk = dm.data_ptr(), _lib.MASK_F32
     L = _lib.lib()
     out = torch.empty(B, dtype=torch.float32, device=dev)
     pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
     if B:
         with torch.cuda.device(dev):
+            wsb = L.mm_kernel_pool_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
             rc = L.mm_kernel_pool_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, mu.data_ptr(), sigma.data_ptr(),
                                       alpha.data_ptr(), w.data_ptr(), out.data_ptr(),
                                       pk.data_ptr() if pk is not None else None, B, pairs_per_query,
-                                      Q, D, E, K, _lib.MM_F32, _stream(dev))
+                                      Q, D, E, K, _lib.MM_F32, ws.data_ptr() if ws is not None else None, wsb,
+                                      _stream(dev))
         _lib.check(rc, "mm_kernel_pool_fwd")
     return (out, pk) if return_per_kernel else out
 

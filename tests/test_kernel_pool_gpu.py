@@ -1,0 +1,103 @@
+"""GPU parity tests for TK kernel pooling (mm_kernel_pool_fwd) vs the oracle and the golden vectors
+of the real ECAI20_TK.forward (ecai20_tk.py:105-124).  fp32 tolerance 1e-3 (BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+SIGMA = [0.1] * 11
+
+
+def _t(x, dev, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype).to(dev)
+
+
+def test_tk_matches_reference_golden():
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = util.load("tk_q20_d200_e300.npz")
+    B = g["d"].shape[0]
+    args = [_t(g[k], dev) for k in ("mu", "sigma", "alpha", "w")]
+    # shared-query layout (1 query x B candidates) -> streaming kernel (E = 300)
+    out, pk = ops.kernel_pool(_t(g["q"], dev), _t(g["d"], dev), _t(g["q_mask"][:1], dev), _t(g["d_mask"], dev),
+                              *args, pairs_per_query=B, return_per_kernel=True)
+    np.testing.assert_allclose(pk.cpu().numpy(), g["per_kernel"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), g["score"], atol=util.TOL_FP32)
+    # reference layout: query replicated per pair, float masks [B, Q]
+    q_rep = _t(np.repeat(g["q"], B, 0), dev)
+    out2 = ops.kernel_pool(q_rep, _t(g["d"], dev), _t(g["q_mask"], dev), _t(g["d_mask"], dev), *args)
+    np.testing.assert_allclose(out2.cpu().numpy(), g["score"], atol=util.TOL_FP32)
+
+
+@pytest.mark.parametrize("Q,D,E,ppq,nq", [(20, 200, 300, 10, 3), (30, 180, 300, 1, 12), (32, 64, 100, 7, 4),
+                                           (11, 33, 200, 5, 2), (20, 50, 64, 4, 3), (40, 70, 128, 3, 2),
+                                           (5, 1, 4, 2, 2)])
+def test_kernel_pool_random(Q, D, E, ppq, nq):
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 131 + D)
+    B = nq * ppq - (ppq // 2 if nq > 1 else 0)
+    q = torch.randn(nq, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    # plant near matches so the high-mu kernels see mass
+    for b in range(B):
+        d[b, b % D] = q[b // ppq, b % Q] * (1.0 + 0.02 * b)
+    d[0, 0] = 0.0
+    q_len = torch.randint(1, Q + 1, (nq,), generator=g)
+    d_len = torch.randint(0, D + 1, (B,), generator=g)
+    d_len[0] = D
+    d_len[-1] = 0
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D)[None] < d_len[:, None]).float()
+    dm[0, D // 2] = 0.0           # a hole (non-prefix mask)
+    alpha = torch.rand(11, generator=g) + 0.5
+    w = (torch.rand(11, generator=g) - 0.5) * 0.03
+    mu, sigma = torch.tensor(MU), torch.tensor(SIGMA)
+    out, pk = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev),
+                              alpha.to(dev), w.to(dev), pairs_per_query=ppq, return_per_kernel=True)
+    qi = np.arange(B) // ppq
+    ref, ref_pk = O.tk_kernel_pool(q.numpy()[qi], d.numpy(), qm.numpy()[qi], dm.numpy(), MU, SIGMA, alpha.numpy(),
+                                   w.numpy(), dtype=np.float64, return_per_kernel=True)
+    np.testing.assert_allclose(pk.cpu().numpy(), ref_pk, atol=5e-3, rtol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=util.TOL_FP32)
+    # lengths instead of dense masks give the same result when the masks are prefixes
+    dm2 = (torch.arange(D)[None] < d_len[:, None]).float()
+    a = ops.kernel_pool(q.to(dev), d.to(dev), q_len.to(dev), d_len.to(dev), mu.to(dev), sigma.to(dev),
+                        alpha.to(dev), w.to(dev), pairs_per_query=ppq)
+    b = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm2.to(dev), mu.to(dev), sigma.to(dev),
+                        alpha.to(dev), w.to(dev), pairs_per_query=ppq)
+    assert torch.equal(a, b)
+
+
+def test_kernel_pool_config1_scale_properties():
+    """Config-1 shapes at batch scale (1000 candidates): determinism, permutation equivariance, and
+    invariance to positive rescaling of any token vector (cosine)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator(device=dev).manual_seed(9)
+    nq, C, Q, D, E = 2, 1000, 20, 200, 300
+    q = torch.randn(nq, Q, E, generator=g, device=dev)
+    d = torch.randn(nq * C, D, E, generator=g, device=dev)
+    d_len = torch.randint(10, D + 1, (nq * C,), generator=g, device=dev).to(torch.int32)
+    q_len = torch.tensor([20, 7], dtype=torch.int32, device=dev)
+    p = [torch.tensor(MU, device=dev), torch.tensor(SIGMA, device=dev), torch.ones(11, device=dev),
+         torch.linspace(-0.014, 0.014, 11, device=dev)]
+    out = ops.kernel_pool(q, d, q_len, d_len, *p, pairs_per_query=C)
+    assert torch.equal(out, ops.kernel_pool(q, d, q_len, d_len, *p, pairs_per_query=C))
+    perm = torch.cat([torch.randperm(C, device=dev) + i * C for i in range(nq)])
+    outp = ops.kernel_pool(q, d[perm].contiguous(), q_len, d_len[perm].contiguous(), *p, pairs_per_query=C)
+    assert torch.equal(outp, out[perm])
+    outs = ops.kernel_pool(q * 4.0, d * 0.5, q_len, d_len, *p, pairs_per_query=C)   # powers of two: exact
+    assert torch.equal(outs, out)
+    # sampled oracle check
+    sel = torch.tensor([0, 1, 499, 999, 1000, 1999])
+    ref = O.tk_kernel_pool(q.cpu().numpy()[sel.numpy() // C], d[sel.to(dev)].cpu().numpy(),
+                           (np.arange(Q)[None] < q_len.cpu().numpy()[sel.numpy() // C][:, None]),
+                           (np.arange(D)[None] < d_len[sel.to(dev)].cpu().numpy()[:, None]),
+                           MU, SIGMA, p[2].cpu().numpy(), p[3].cpu().numpy(), dtype=np.float64)
+    np.testing.assert_allclose(out[sel.to(dev)].cpu().numpy(), ref, atol=util.TOL_FP32)
