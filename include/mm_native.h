@@ -136,14 +136,18 @@ int mm_kernel_pool_fwd(const void* q, const void* d,
  *   chunk_mask   [P, 50]     float {0,1} (padding_packed, :163)
  *   chunk_slot   [P] int32   flat slot b*C + c of each packed chunk (packed_indices :159, as indices)
  *   q_mask       [B, Q]      float {0,1}
- *   params       float32[MM_TKL_NPARAMS(K)] device: see matchmaker_amd/tkl.py pack_params()
+ *   params       float32[MM_TKL_NPARAMS(K, E)] device, packed as (matchmaker_amd/tkl.py pack_params()):
+ *                  mu[K] sigma[K] dense.weight[K] kernel_mult[0][K]
+ *                  saturation_linear{w[2], b}  saturation_linear2{w[2], b}  saturation_linear3{w[2], b}
+ *                  sat_normer{weight[2], bias[2]}  chunk_scoring[15]  sat_emb_reduce1.weight[E]
  *   saturation   0 = "embedding" (:224-234), 1 = "log" (:245-246)
  *   win_scores   [B, W] float32 out (W = (max(C*40,30) - 30)/2 + 1), may be NULL if workspace given
  *   out          [B] float32
  */
+#define MM_TKL_NPARAMS(K, E) (4 * (K) + 13 + 15 + (E))
 #define MM_TKL_SAT_EMBEDDING 0
 #define MM_TKL_SAT_LOG 1
-size_t mm_tkl_workspace_bytes(int64_t B, int C, int Q, int K);
+size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int K);
 
 int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask,
                const int32_t* chunk_slot, const float* q_mask, const float* params,

@@ -26,7 +26,7 @@ SIGNATURES = {
     "mm_kernel_pool_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
     "mm_kernel_pool_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                 _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "mm_tkl_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "mm_tkl_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i]),
     "mm_tkl_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

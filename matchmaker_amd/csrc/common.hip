@@ -18,12 +18,13 @@ int set_error(int code, const char* fmt, ...) {
 // are never loaded by the scoring kernels); holes inside [0, len) stay visible through `bits`.
 template <typename T>
 __global__ void __launch_bounds__(256) pack_mask_kernel(const T* __restrict__ mask, int64_t rows, int L,
-                                                        int words, int32_t* __restrict__ len_out,
+                                                        int64_t row_stride, int col0, int words,
+                                                        int32_t* __restrict__ len_out,
                                                         uint32_t* __restrict__ bits_out) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const T* m = mask + row * (int64_t)L;
+  const T* m = mask + row * row_stride + col0;
   int last = 0;
   for (int base = 0; base < L; base += 64) {
     const int j = base + lane;
@@ -49,7 +50,8 @@ size_t packed_mask_bytes(int kind, int64_t rows, int L) {
 }
 
 int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, size_t* ws_left,
-                 hipStream_t stream, PackedMask* out) {
+                 hipStream_t stream, PackedMask* out, int64_t row_stride, int col0) {
+  if (row_stride <= 0) row_stride = L;
   out->len = nullptr;
   out->bits = nullptr;
   switch (kind) {
@@ -74,11 +76,11 @@ int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, siz
       *ws_left -= need;
       const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
       if (kind == MM_MASK_U8)
-        hipLaunchKernelGGL(pack_mask_kernel<uint8_t>, grid, block, 0, stream, (const uint8_t*)mask, rows, L, words, len, bits);
+        hipLaunchKernelGGL(pack_mask_kernel<uint8_t>, grid, block, 0, stream, (const uint8_t*)mask, rows, L, row_stride, col0, words, len, bits);
       else if (kind == MM_MASK_I64)
-        hipLaunchKernelGGL(pack_mask_kernel<int64_t>, grid, block, 0, stream, (const int64_t*)mask, rows, L, words, len, bits);
+        hipLaunchKernelGGL(pack_mask_kernel<int64_t>, grid, block, 0, stream, (const int64_t*)mask, rows, L, row_stride, col0, words, len, bits);
       else
-        hipLaunchKernelGGL(pack_mask_kernel<float>, grid, block, 0, stream, (const float*)mask, rows, L, words, len, bits);
+        hipLaunchKernelGGL(pack_mask_kernel<float>, grid, block, 0, stream, (const float*)mask, rows, L, row_stride, col0, words, len, bits);
       out->len = len;
       out->bits = bits;
       return check_launch("pack_mask_kernel");

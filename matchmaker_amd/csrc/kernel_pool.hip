@@ -37,6 +37,16 @@ struct KpArgs {
   int64_t ppq;
   int Q, D, E, K;
   int64_t pairs_per_wave;
+  // document addressing: document p starts at row p*d_doc_rows + d_row0 (TK: D, 0; TKL chunks: 50, 5)
+  int64_t d_doc_rows;
+  int d_row0;
+  // TKL mode (sigir20_tkl.py:180-199): "documents" are packed chunks, the query of chunk p is
+  // chunk_slot[p] / C, and instead of pooling over the document the kernel emits, per position pair
+  // u (positions 2u, 2u+1 of the chunk's 40 centre tokens), the K summed activations + the number of
+  // positions whose activation is non-zero: ps_out[p][20][Q][K+1].
+  const int32_t* chunk_slot;
+  int C;
+  float* ps_out;
 };
 
 __device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
@@ -69,8 +79,8 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
     const float sg = sload_f32(sigma, k);
     rbf.mu[k] = sload_f32(mu, k);
     rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
-    rbf.alpha[k] = sload_f32(alpha, k);
-    rbf.w[k] = sload_f32(w, k);
+    rbf.alpha[k] = alpha ? sload_f32(alpha, k) : 1.0f;
+    rbf.w[k] = w ? sload_f32(w, k) : 0.0f;
   }
 }
 
@@ -93,6 +103,48 @@ __device__ __forceinline__ void rbf_block(float (&pk)[kMaxK], const f32x16& acc,
   }
 }
 
+// TKL epilogue of one block of a chunk's centre tokens (block t = rows 32t..32t+31 of the 40):
+// per position pair u the K summed activations (ecai-style RBF, masked: sigir20_tkl.py:192-194) and
+// the count of positions with a non-zero activation (feeds `lengths`, :210).
+template <int K>
+__device__ __forceinline__ void tkl_block(float* ps_chunk, int Q, int t, int r, int h, const f32x16& acc,
+                                          const float (&rdr)[16], float rq, uint32_t vbits, const Rbf& rbf) {
+  constexpr int KC = K + 1;
+  static_assert(KC % 4 == 0, "channel count must be a multiple of 4 floats");
+  const int npairs = t == 0 ? 8 : 2;  // block 1 only holds positions 32..39 (rows 0..3 + 4h)
+#pragma unroll
+  for (int ip = 0; ip < 8; ++ip) {
+    if (ip < npairs) {  // wave-uniform guard; keeps every register index static
+    float o[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) o[k] = 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int i = 2 * ip + half;
+      const float c = (acc[i] * rq) * rdr[i];
+      const bool valid = (vbits >> rowof(i)) & 1u;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float tt = c - rbf.mu[k];
+        float e = __builtin_amdgcn_exp2f(tt * tt * rbf.c2[k]);
+        e = valid ? e : 0.0f;
+        o[k] += e;
+        any = any || (e != 0.0f);
+      }
+      o[K] += any ? 1.0f : 0.0f;
+    }
+    const int row0 = rowof(2 * ip) + 4 * h;
+    const int u = (32 * t + row0) >> 1;
+    if (r < Q && u < 20) {
+      f32x4* dst = (f32x4*)(ps_chunk + ((int64_t)u * Q + r) * KC);
+#pragma unroll
+      for (int v = 0; v < KC / 4; ++v) dst[v] = f32x4{o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
+    }
+    }
+  }
+}
+
 // log-sum pooling of one pair: pk[k] (this lane's query token, both halves already combined).
 template <int K>
 __device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
@@ -101,7 +153,7 @@ __device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], 1e-10f));
-    lg = qvalid ? lg : 0.0f;
+    lg = (qvalid && lane < 32) ? lg : 0.0f;  // both halves hold the combined sums: count one
     const float s = wave_sum(lg);
     if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
     total += rbf.w[k] * s;
@@ -181,7 +233,7 @@ __device__ __forceinline__ void load_q_slice(const char* base, f32x4 (&qf)[kPair
       : "memory");
 }
 
-template <int NS, int K, int NBUF, bool NT>
+template <int NS, int K, int NBUF, bool NT, bool TKL>
 __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -225,7 +277,7 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
   int pbuf = 0, cbuf = 0, inflight = 0;
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
-      const char* g = dbase + (pp * D + (int64_t)pt * 32) * RB + ps * (kSC * 16);
+      const char* g = dbase + (pp * a.d_doc_rows + a.d_row0 + (int64_t)pt * 32) * RB + ps * (kSC * 16);
       issue_slice<NT>(g, voff, vmax_tail, pt == nblk_tot - 1 && rows_last != 32, lds0 + (uint32_t)pbuf * kSliceBytes);
       pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
       ++inflight;
@@ -245,15 +297,19 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
   float rq = 0.0f;
   bool qvalid = false;
   int64_t cur_q = -1;
-  int64_t qi = p0 / a.ppq;
-  int64_t q_left = a.ppq - (p0 - qi * a.ppq);
+  int64_t qi = TKL ? 0 : p0 / a.ppq;
+  int64_t q_left = TKL ? 0 : a.ppq - (p0 - qi * a.ppq);
 
   for (int64_t pair = p0; pair < p1; ++pair) {
-    if (q_left == 0) {
-      ++qi;
-      q_left = a.ppq;
+    if (TKL) {
+      qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
+    } else {
+      if (q_left == 0) {
+        ++qi;
+        q_left = a.ppq;
+      }
+      --q_left;
     }
-    --q_left;
     if (qi != cur_q) {
       cur_q = qi;
       const int qr = r < Q ? r : Q - 1;
@@ -313,18 +369,23 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
-      rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
+      if (TKL)
+        tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+      else
+        rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
     }
+    if (!TKL) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
-    finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+      for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
+      finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // generic kernel: one wavefront per pair, direct fragment loads, any E % 4 == 0, any Q / D.
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool TKL>
 __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a) {
   __shared__ float rdbuf[32];
   const int lane = threadIdx.x;
@@ -333,7 +394,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
   if (pair >= a.n_pairs) return;
   const int D = a.D, Q = a.Q, E = a.E;
   const int64_t rowb = (int64_t)E * 4;
-  const int64_t qi = pair / a.ppq;
+  const int64_t qi = TKL ? (int64_t)(a.chunk_slot[pair] / a.C) : pair / a.ppq;
   const int nblk_tot = (D + 31) >> 5;
   const int qwords = (Q + 31) >> 5;
   const int nch = E >> 2;
@@ -341,7 +402,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
   len = len < 0 ? 0 : (len > D ? D : len);
   const int nb = (len + 31) >> 5;
   const int qlen = a.qm.len ? a.qm.len[qi] : Q;
-  const char* dbase = (const char*)a.d + pair * D * rowb;
+  const char* dbase = (const char*)a.d + (pair * a.d_doc_rows + a.d_row0) * rowb;
   const char* qbase = (const char*)a.q + qi * Q * rowb;
   Rbf rbf;
 #pragma unroll
@@ -349,8 +410,8 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
     const float sg = a.sigma[k];
     rbf.mu[k] = a.mu[k];
     rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
-    rbf.alpha[k] = a.alpha[k];
-    rbf.w[k] = a.w[k];
+    rbf.alpha[k] = a.alpha ? a.alpha[k] : 1.0f;
+    rbf.w[k] = a.w ? a.w[k] : 0.0f;
   }
   float tot[kMaxK];
 #pragma unroll
@@ -400,15 +461,20 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (a.dm.bits[pair * nblk_tot + t] & ex) : ex;
-      rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
+      if (TKL)
+        tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, qtok, h, acc, rdr, rq, va >> (4 * h), rbf);
+      else
+        rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
     }
+    if (TKL) continue;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float v = pk[k] + __shfl_xor(pk[k], 32, 64);
       float lg = __logf(fmaxf(v * rbf.alpha[k], 1e-10f));
-      tot[k] += wave_sum(qvalid ? lg : 0.0f);
+      tot[k] += wave_sum((qvalid && h == 0) ? lg : 0.0f);
     }
   }
+  if (TKL) return;
   float total = 0.0f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -416,6 +482,42 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
     total += rbf.w[k] * tot[k];
   }
   if (lane == 0) a.out[pair] = total;
+}
+
+template <int K, bool TKL>
+static int launch_stream(const KpArgs& a0, hipStream_t stream) {
+  KpArgs a = a0;
+  constexpr int NBUF = 3;
+  const int lds = NBUF * kSliceBytes + 128;
+  int64_t waves = (int64_t)kCUs * 4;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
+  if (waves > a.n_pairs) waves = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
+  waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  const dim3 grid((unsigned)waves), block(64);
+  if (a.E == 100)
+    hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+  else if (a.E == 200)
+    hipLaunchKernelGGL((kernel_pool_stream_kernel<2, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+  else
+    hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+  return check_launch("kernel_pool_stream_kernel");
+}
+
+bool kp_stream_supported(int Q, int E) { return Q <= 32 && (E == 100 || E == 200 || E == 300); }
+
+// TKL stage 1 entry (called from tkl.hip): chunks [P,50,E] -> ps_out [P,20,Q,12]
+int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
+                      const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream) {
+  KpArgs a{};
+  a.q = q_ctx; a.d = chunks; a.dm = dm; a.mu = mu; a.sigma = sigma; a.alpha = nullptr; a.w = nullptr;
+  a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;
+  a.d_doc_rows = 50; a.d_row0 = 5; a.chunk_slot = chunk_slot; a.C = C; a.ps_out = ps_out;
+  static int force_generic = -1;
+  if (force_generic < 0) force_generic = getenv("MM_KP_GENERIC") ? atoi(getenv("MM_KP_GENERIC")) : 0;
+  if (!force_generic && kp_stream_supported(Q, E)) return launch_stream<11, true>(a, stream);
+  if (P > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "tkl: too many chunks for one launch");
+  hipLaunchKernelGGL((kernel_pool_generic_kernel<11, true>), dim3((unsigned)P), dim3(64), 0, stream, a);
+  return check_launch("kernel_pool_generic_kernel<TKL>");
 }
 
 template <int K>
@@ -427,25 +529,10 @@ static int launch_k(const KpArgs& a0, hipStream_t stream) {
     nbuf_env = getenv("MM_KP_NBUF") ? atoi(getenv("MM_KP_NBUF")) : 3;
   }
   const bool stream_ok = !force_generic && a.Q <= 32 && (a.E == 100 || a.E == 200 || a.E == 300);
-  if (stream_ok) {
-    constexpr int NBUF = 3;
-    (void)nbuf_env;
-    const int lds = NBUF * kSliceBytes + 128;
-    int64_t waves = (int64_t)kCUs * 4;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
-    if (waves > a.n_pairs) waves = a.n_pairs;
-    a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
-    waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-    const dim3 grid((unsigned)waves), block(64);
-    if (a.E == 100)
-      hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true>), grid, block, lds, stream, a);
-    else if (a.E == 200)
-      hipLaunchKernelGGL((kernel_pool_stream_kernel<2, K, NBUF, true>), grid, block, lds, stream, a);
-    else
-      hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true>), grid, block, lds, stream, a);
-    return check_launch("kernel_pool_stream_kernel");
-  }
+  (void)nbuf_env;
+  if (stream_ok) return launch_stream<K, false>(a, stream);
   if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
-  hipLaunchKernelGGL((kernel_pool_generic_kernel<K>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
   return check_launch("kernel_pool_generic_kernel");
 }
 
@@ -478,6 +565,7 @@ extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_ma
   a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w;
   a.out = out; a.per_kernel = per_kernel; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
   a.Q = Q; a.D = D; a.E = E; a.K = K;
+  a.d_doc_rows = D; a.d_row0 = 0;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, (n_pairs + pairs_per_query - 1) / pairs_per_query, Q, &ws, &left, stream, &a.qm))

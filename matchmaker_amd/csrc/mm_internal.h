@@ -38,8 +38,14 @@ struct PackedMask {
 size_t packed_mask_bytes(int kind, int64_t rows, int L);
 // Resolves a user mask to a PackedMask, launching the pack kernel into `ws` when needed.
 // Advances *ws / *ws_left.  Returns MM_OK or an error code.
+// Dense masks may be strided: row i starts at mask + i*row_stride + col0 (row_stride 0 = L).
 int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, size_t* ws_left,
-                 hipStream_t stream, PackedMask* out);
+                 hipStream_t stream, PackedMask* out, int64_t row_stride = 0, int col0 = 0);
+
+// kernel_pool.hip exports used by tkl.hip
+bool kp_stream_supported(int Q, int E);
+int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
+                      const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream);
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

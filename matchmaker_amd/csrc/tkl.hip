@@ -1,7 +1,264 @@
-// placeholder until the TKL kernels land
+// TKL (long-document TK) scoring for MI355X (gfx950): everything of TKL_sigir20.forward after the
+// chunk contextualiser — matchmaker/models/published/sigir20_tkl.py:180-286.
+//
+// Stage 1 (kernel_pool.hip, TKL mode): per packed chunk, cosine match of the query against the 40
+//   centre tokens, K RBF kernels, document mask (:184-194); emitted as pair sums
+//   ps[p][u][q][0..K-1] = act[2u] + act[2u+1] and ps[..][K] = number of those two positions whose
+//   activation is non-zero.  This replaces the reference's [P,Q,40,K] tensor, its zero-fill +
+//   boolean scatter (:196-197) and the transposing reshape (:199): dropped chunks are simply absent
+//   and read as zeros through the slot -> packed-index map.
+// Stage 2 (tkl_window_kernel): sliding windows of 30 positions, stride 2 (:209) = 15 consecutive
+//   pair sums; window lengths (:210), kernel sums (:211), saturation ("embedding" :224-234 or
+//   "log" :245-246), query mask and empty-window factor (:248), sum over query tokens (:249),
+//   dense layer (:251-252)  ->  win_scores [B, W].
+// Stage 3 (tkl_region_kernel): 0 -> -9900 (:257), three arg-max rounds with +-15 suppression
+//   (:268-273), the peaks' +-1 / +-2 neighbours (:276-282), chunk_scoring dot (:286)  ->  out [B].
 #include "mm_internal.h"
-extern "C" size_t mm_tkl_workspace_bytes(int64_t, int, int, int) { return 0; }
-extern "C" int mm_tkl_fwd(const void*, const void*, const float*, const int32_t*, const float*, const float*, float*,
-                          float*, int64_t, int64_t, int, int, int, int, int, void*, size_t, void*) {
-  return mm::set_error(MM_EUNSUPPORTED, "mm_tkl_fwd: not built yet");
+
+namespace mm {
+
+constexpr int kK = 11;
+constexpr int kKC = 12;       // K + count channel
+constexpr int kU = 20;        // position pairs per chunk
+constexpr int kWinPairs = 15; // 30 positions, stride 2
+constexpr int kWT = 32;       // windows per workgroup in stage 2
+
+struct TklParams {            // offsets into the packed float parameter vector (see mm_native.h)
+  __host__ __device__ static int mu() { return 0; }
+  __host__ __device__ static int sigma() { return kK; }
+  __host__ __device__ static int dense() { return 2 * kK; }
+  __host__ __device__ static int kmult() { return 3 * kK; }
+  __host__ __device__ static int sat() { return 4 * kK; }       // w1[2] b1 w2[2] b2 w3[2] b3 lnw[2] lnb[2]
+  __host__ __device__ static int chunk_scoring() { return 4 * kK + 13; }
+  __host__ __device__ static int emb() { return 4 * kK + 13 + 15; }
+};
+
+__global__ void __launch_bounds__(256) tkl_slot_map_kernel(const int32_t* __restrict__ chunk_slot, int64_t P,
+                                                           int64_t BC, int32_t* __restrict__ slot2p) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < P) {
+    const int32_t s = chunk_slot[p];
+    if (s >= 0 && s < BC) slot2p[s] = (int32_t)p;
+  }
+}
+
+// One workgroup = kWT consecutive windows of one document.
+template <int SAT>
+__global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
+                                                         const float* __restrict__ q_ctx,
+                                                         const float* __restrict__ q_mask,
+                                                         const float* __restrict__ prm, float* __restrict__ win,
+                                                         int C, int Q, int E, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y;
+  const int w0 = blockIdx.x * kWT;
+  const int tid = threadIdx.x;
+  const int nu = kWT + kWinPairs - 1;                 // pair rows needed by this tile
+  const int rowf = Q * kKC;                           // floats per pair row
+  float* tile = (float*)smem;                         // [nu][Q][12]
+  float* emb = tile + (size_t)nu * rowf;              // [Q]   sat_emb_reduce1(q_ctx)  (:224)
+  float* red = emb + ((Q + 3) & ~3);                  // [kWT][Q] per-(window, query token) dense-weighted value
+
+  // ---- stage the pair-sum rows (zeros for dropped chunks) --------------------------------------
+  const int row4 = rowf / 4;
+  for (int idx = tid; idx < nu * row4; idx += 256) {
+    const int j = idx / row4, v = idx - j * row4;
+    const int ug = w0 + j;
+    const int c = ug / kU, uu = ug - c * kU;
+    f32x4 val = {0, 0, 0, 0};
+    if (c < C) {
+      const int p = slot2p[(int64_t)b * C + c];
+      if (p >= 0) val = *(const f32x4*)(ps + ((int64_t)p * kU + uu) * rowf + v * 4);
+    }
+    *(f32x4*)(tile + (size_t)j * rowf + v * 4) = val;
+  }
+  if (SAT == MM_TKL_SAT_EMBEDDING) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < Q; i += 4) {
+      const float* qr = q_ctx + ((int64_t)b * Q + i) * E;
+      float s = 0.0f;
+      for (int e = lane; e < E; e += 64) s += qr[e] * prm[TklParams::emb() + e];
+      s = wave_sum(s);
+      if (lane == 0) emb[i] = s;
+    }
+  }
+  __syncthreads();
+
+  const float* sp = prm + TklParams::sat();
+  for (int item = tid; item < kWT * Q; item += 256) {
+    const int wl = item / Q, i = item - wl * Q;
+    float val = 0.0f;
+    if (w0 + wl < W) {
+      float pk[kKC];
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) pk[k] = 0.0f;
+      for (int j = 0; j < kWinPairs; ++j) {
+        const f32x4* src = (const f32x4*)(tile + (size_t)(wl + j) * rowf + i * kKC);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          const f32x4 x = src[v];
+          pk[4 * v] += x[0]; pk[4 * v + 1] += x[1]; pk[4 * v + 2] += x[2]; pk[4 * v + 3] += x[3];
+        }
+      }
+      const float len = pk[kK];                                        // :210 (exact small integer)
+      const float factor = q_mask[(int64_t)b * Q + i] * (len > 0.0f ? 1.0f : 0.0f);   // :248
+      if (SAT == MM_TKL_SAT_EMBEDDING) {
+        const float x0 = emb[i], x1 = len;                             // :224-225
+        const float mean = (x0 + x1) * 0.5f;                           // LayerNorm(2) :228
+        const float d0 = x0 - mean, d1 = x1 - mean;
+        const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
+        const float n0 = d0 * rstd * sp[9] + sp[11], n1 = d1 * rstd * sp[10] + sp[12];
+        const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];              // :230
+        const float s2 = 1.0f / (n0 * sp[3] + n1 * sp[4] + sp[5]);      // :231
+        const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];              // :232
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          const float sat = s1 * powf(fmaxf(pk[k], 1e-10f), s2) - s3;  // :234
+          val += prm[TklParams::dense() + k] * (sat * factor);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          const float sat = logf(fmaxf(pk[k] * prm[TklParams::kmult() + k], 1e-10f));   // :246
+          val += prm[TklParams::dense() + k] * (sat * factor);
+        }
+      }
+    }
+    red[wl * Q + i] = val;
+  }
+  __syncthreads();
+  if (tid < kWT && w0 + tid < W) {                                     // :249 sum over query tokens, :251 dense
+    float s = 0.0f;
+    for (int i = 0; i < Q; ++i) s += red[tid * Q + i];
+    win[(int64_t)b * W + w0 + tid] = s;
+  }
+}
+
+// One wavefront per document: region top-k over the window scores (:254-286).
+__global__ void __launch_bounds__(64) tkl_region_kernel(const float* __restrict__ win, const float* __restrict__ prm,
+                                                        float* __restrict__ out, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int Wp = W < 3 ? 3 : W;                                        // :254-255
+  float* orig = (float*)smem;                                          // [Wp]
+  float* work = orig + Wp;                                             // [Wp]
+  for (int w = lane; w < Wp; w += 64) {
+    float s = w < W ? win[(int64_t)b * W + w] : 0.0f;
+    if (s == 0.0f) s = -9900.0f;                                       // :257
+    orig[w] = s;
+    work[w] = s;
+  }
+  __syncthreads();
+  int top[3];
+  for (int c = 0; c < 3; ++c) {                                        // :268-273
+    float bv = -__builtin_huge_valf();
+    int bi = 0x7fffffff;
+    for (int w = lane; w < Wp; w += 64) {
+      const float v = work[w];
+      if (v > bv) { bv = v; bi = w; }                                  // first maximal index within the lane
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }      // ties -> lowest index (torch.argmax)
+    }
+    top[c] = bi;
+    __syncthreads();
+    for (int w = lane; w < Wp; w += 64) {
+      const int dlt = w > bi ? w - bi : bi - w;
+      if (dlt < 15) work[w] = -10001.0f - (float)c;                    // |r - best| < 30/2
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    const int offs[5] = {0, -1, 1, -2, 2};                             // :276 peaks, -1, +1, -2, +2
+    float s = 0.0f;
+    for (int g = 0; g < 5; ++g)
+      for (int c = 0; c < 3; ++c) {
+        int idx = top[c] + offs[g];
+        idx = idx < 0 ? 0 : (idx >= Wp ? Wp - 1 : idx);                // :277-278
+        float v = orig[idx];
+        if (v <= -9900.0f) v = 0.0f;                                   // :282
+        s += v * prm[TklParams::chunk_scoring() + g * 3 + c];          // :286
+      }
+    out[b] = s;
+  }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace mm
+
+using namespace mm;
+
+extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int K) {
+  if (B <= 0 || P < 0 || C <= 0 || Q <= 0 || K != kK) return 0;
+  const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
+  return align256((size_t)B * C * 4) + align256((size_t)P * kU * Q * kKC * 4) +
+         packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4);
+}
+
+extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
+                          const float* q_mask, const float* params, float* win_scores, float* out, int64_t B,
+                          int64_t P, int C, int Q, int E, int K, int saturation, void* workspace,
+                          size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q_ctx || !q_mask || !params || !out) return set_error(MM_EINVAL, "tkl: null pointer");
+  if (P > 0 && (!chunks || !chunk_mask || !chunk_slot)) return set_error(MM_EINVAL, "tkl: null chunk pointer");
+  if (B <= 0 || P < 0 || C <= 0 || Q <= 0 || E <= 0) return set_error(MM_EINVAL, "tkl: bad shape");
+  if (K != kK) return set_error(MM_EUNSUPPORTED, "tkl: K=%d kernels (only the reference's 11 are instantiated)", K);
+  if (E % 4) return set_error(MM_EUNSUPPORTED, "tkl: E=%d rows are not 16-byte multiples", E);
+  if (saturation != MM_TKL_SAT_EMBEDDING && saturation != MM_TKL_SAT_LOG)
+    return set_error(MM_EUNSUPPORTED, "tkl: saturation %d (idf/linear read an undefined variable in the reference)", saturation);
+  if (P > B * (int64_t)C) return set_error(MM_EINVAL, "tkl: more packed chunks than slots");
+  const size_t need = mm_tkl_workspace_bytes(B, P, C, Q, K);
+  if (!workspace || workspace_bytes < need) return set_error(MM_EWORKSPACE, "tkl: workspace needs %zu bytes", need);
+  const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
+  if ((size_t)(W < 3 ? 3 : W) * 8 > 64 * 1024) return set_error(MM_EUNSUPPORTED, "tkl: %d windows per document exceed the region kernel's LDS", W);
+
+  char* ws = (char*)workspace;
+  int32_t* slot2p = (int32_t*)ws;
+  ws += align256((size_t)B * C * 4);
+  float* ps = (float*)ws;
+  const size_t ps_bytes = align256((size_t)P * kU * Q * kKC * 4);
+  ws += ps_bytes;
+  size_t left = workspace_bytes - (size_t)(ws - (char*)workspace);
+  float* win = win_scores;
+  hipError_t e1 = hipMemsetAsync(slot2p, 0xFF, (size_t)B * C * 4, stream);
+  hipError_t e2 = ps_bytes ? hipMemsetAsync(ps, 0, ps_bytes, stream) : hipSuccess;
+  if (e1 != hipSuccess || e2 != hipSuccess) return set_error(MM_ELAUNCH, "tkl: memset failed");
+  if (P > 0) {
+    hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, P,
+                       B * (int64_t)C, slot2p);
+    if (int e = check_launch("tkl_slot_map_kernel")) return e;
+    PackedMask dm;
+    if (int e = resolve_mask(chunk_mask, MM_MASK_F32, P, 40, &ws, &left, stream, &dm, 50, 5)) return e;
+    if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, chunk_slot, C,
+                                  params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
+      return e;
+  }
+  if (!win) {
+    ws = (char*)workspace + align256((size_t)B * C * 4) + ps_bytes + packed_mask_bytes(MM_MASK_F32, P, 40);
+    win = (float*)ws;
+  }
+  const int nu = kWT + kWinPairs - 1;
+  const size_t lds2 = ((size_t)nu * Q * kKC + ((Q + 3) & ~3) + (size_t)kWT * Q) * 4;
+  if (lds2 > 160 * 1024) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
+  const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
+  if (saturation == MM_TKL_SAT_EMBEDDING) {
+    if (lds2 > 64 * 1024)
+      hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(256), lds2, stream, ps, slot2p,
+                       (const float*)q_ctx, q_mask, params, win, C, Q, E, W);
+  } else {
+    if (lds2 > 64 * 1024)
+      hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(256), lds2, stream, ps, slot2p,
+                       (const float*)q_ctx, q_mask, params, win, C, Q, E, W);
+  }
+  if (int e = check_launch("tkl_window_kernel")) return e;
+  const int Wp = W < 3 ? 3 : W;
+  hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(64), (size_t)Wp * 8, stream, win, params, out, W);
+  return check_launch("tkl_region_kernel");
 }

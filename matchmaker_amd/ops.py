@@ -192,7 +192,7 @@ def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tenso
     win = torch.empty((B, W), dtype=torch.float32, device=dev)
     if B:
         with torch.cuda.device(dev):
-            wsb = L.mm_tkl_workspace_bytes(B, C, Q, K)
+            wsb = L.mm_tkl_workspace_bytes(B, P, C, Q, K)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
             rc = L.mm_tkl_fwd(q_ctx.data_ptr(), chunks.data_ptr(), chunk_mask.data_ptr(), chunk_slot.data_ptr(),
                               q_mask.data_ptr(), params.data_ptr(), win.data_ptr(), out.data_ptr(), B, P, C, Q, E,

@@ -1,0 +1,95 @@
+"""GPU: the ColBERT drop-in (tiny random BERT encoder in PyTorch + native MaxSim) scores exactly what
+the oracle computes from the module's own token vectors; fp16 autocast path, teacher / return_vecs
+conventions, aggregation entry points (colbert.py:54-162), training backward."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev, dim=128):
+    from transformers import BertConfig, BertModel
+    from matchmaker_amd.colbert import ColBERT, ColBERTConfig
+    torch.manual_seed(0)
+    enc = BertModel(BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                               vocab_size=500, max_position_embeddings=256))
+    return ColBERT(ColBERTConfig(bert_model="(injected)", compression_dim=dim), bert_model=enc).to(dev).eval()
+
+
+def _batch(dev, B=9, Q=32, D=180):
+    g = torch.Generator().manual_seed(1)
+    ql = torch.randint(3, Q + 1, (B,), generator=g)
+    dl = torch.randint(8, D + 1, (B,), generator=g)
+    mk = lambda L, n: {"input_ids": torch.randint(1, 500, (B, n), generator=g).to(dev),
+                       "attention_mask": (torch.arange(n)[None] < L[:, None]).long().to(dev)}
+    return mk(ql, Q), mk(dl, D)
+
+
+@pytest.mark.parametrize("use_fp16", [False, True])
+def test_forward_equals_oracle_on_module_vectors(use_fp16):
+    dev = util.require_gpu()
+    m = _model(dev)
+    query, doc = _batch(dev)
+    with torch.no_grad():
+        score = m.forward(query, doc, use_fp16=use_fp16)
+        m.is_teacher_model = True
+        s2, qv, dv = m.forward(query, doc, use_fp16=use_fp16)
+        m.is_teacher_model = False
+    assert score.dtype == torch.float32 and torch.equal(score, s2)
+    ref = O.maxsim_paired(qv.float().cpu().numpy(), dv.float().cpu().numpy(), query["attention_mask"].cpu().numpy(),
+                          doc["attention_mask"].cpu().numpy())
+    np.testing.assert_allclose(score.cpu().numpy(), ref, atol=util.TOL_BF16 if use_fp16 else util.TOL_FP32)
+    if use_fp16:
+        assert qv.dtype == torch.float16
+    with torch.no_grad():
+        s, sec = m.forward(query, doc, use_fp16=use_fp16, output_secondary_output=True)
+        assert sec == {} and torch.equal(s, score)
+        m.return_vecs = True
+        out = m.forward(query, doc, use_fp16=use_fp16)
+        assert isinstance(out, tuple) and len(out) == 3
+        m.return_vecs = False
+
+
+def test_aggregation_entry_points():
+    dev = util.require_gpu()
+    m = _model(dev)
+    query, doc = _batch(dev, B=6)
+    with torch.no_grad():
+        qv = m.forward_representation(query, "query_encode")      # zeroes padded rows (colbert.py:95-96)
+        dv = m.forward_representation(doc, "doc_encode")
+        agg = m.forward_aggregation(qv, dv)
+        inb = m.forward_inbatch_aggregation(qv, query["attention_mask"], dv, doc["attention_mask"])
+        m.inbatch_bug_compatible = False
+        inb_ok = m.forward_inbatch_aggregation(qv, query["attention_mask"], dv, doc["attention_mask"])
+        rect = m.forward_inbatch_aggregation(qv[:2], query["attention_mask"][:2], dv, doc["attention_mask"])
+        m.inbatch_bug_compatible = True
+        with pytest.raises(RuntimeError):
+            m.forward_inbatch_aggregation(qv[:2], query["attention_mask"][:2], dv, doc["attention_mask"])
+    qn, dn = qv.cpu().numpy(), dv.cpu().numpy()
+    qm, dm = query["attention_mask"].cpu().numpy(), doc["attention_mask"].cpu().numpy()
+    np.testing.assert_allclose(agg.cpu().numpy(), O.maxsim_unmasked(qn, dn), atol=util.TOL_FP32)
+    np.testing.assert_allclose(inb.cpu().numpy(), O.maxsim_inbatch(qn, qm, dn, dm, True), atol=util.TOL_FP32)
+    np.testing.assert_allclose(inb_ok.cpu().numpy(), O.maxsim_inbatch(qn, qm, dn, dm, False), atol=util.TOL_FP32)
+    assert rect.shape == (2, 6)
+
+
+def test_training_backward_flows_through_native_forward():
+    dev = util.require_gpu()
+    m = _model(dev).train()
+    query, doc = _batch(dev, B=4)
+    score = m.forward(query, doc, use_fp16=False)
+    score.sum().backward()
+    g = m.compressor.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # same gradient as the eager formula of colbert.py:68-75
+    m.zero_grad()
+    qv, dv = m.forward_representation(query), m.forward_representation(doc)
+    s = torch.bmm(qv, dv.transpose(2, 1))
+    s = s.masked_fill(~doc["attention_mask"].bool().unsqueeze(1), -1000)
+    ref = s.max(-1).values.masked_fill(~query["attention_mask"].bool(), 0).sum(-1)
+    ref.sum().backward()
+    torch.testing.assert_close(m.compressor.weight.grad, g, rtol=1e-3, atol=1e-4)

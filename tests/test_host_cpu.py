@@ -1,0 +1,140 @@
+"""CPU tests of the host-side logic (no GPU, no compute through the HIP library): chunking,
+positional features, drop-in constructors / state_dict keys vs the real reference classes, the C-ABI
+library loading with every declared symbol, and loud failure on CPU tensors."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from oracle import ref_harness as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+SIGMA = [0.1] * 11
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from matchmaker_amd import build, _lib
+    build.build()
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "mm_native.h")).read()
+    declared = set(re.findall(r"\b(mm_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mm_abi_version() == 1
+    # size queries are pure host arithmetic: callable without a GPU
+    assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_NONE, _lib.MASK_LEN_I32) == 0
+    assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_I64, _lib.MASK_I64) > 0
+
+
+def test_ops_reject_cpu_tensors_loudly():
+    from matchmaker_amd import ops, NativeError
+    q = torch.zeros(1, 4, 16)
+    d = torch.zeros(2, 5, 16)
+    with pytest.raises(NativeError):
+        ops.maxsim(q, d, pairs_per_query=2)
+    with pytest.raises(NativeError):
+        ops.kernel_pool(q, d, None, None, torch.tensor(MU), torch.tensor(SIGMA), torch.ones(11), torch.ones(11), 2)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "matchmaker_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+\.*oracle|import_module\(.*oracle|oracle[/.]np_oracle|libmm_oracle",
+                                     src, re.M), f"{f} uses the oracle"
+                assert "/root/reference" not in src, f
+
+
+@pytest.mark.parametrize("D", [4, 5, 6, 20, 45, 46, 85, 333, 2048])
+def test_chunk_documents_matches_oracle_chunking(D):
+    from matchmaker_amd.tkl import chunk_documents
+    g = torch.Generator().manual_seed(D)
+    B, E = 3, 8
+    d = torch.randn(B, D, E, generator=g)
+    lens = torch.randint(1, D + 1, (B,), generator=g)
+    lens[0] = D
+    m = (torch.arange(D)[None] < lens[:, None]).float()
+    chunks, cmask, slot, C = chunk_documents(d, m)
+    rc, rm, rp, rC = O.tkl_chunk(d.numpy(), m.numpy())
+    assert C == rC
+    np.testing.assert_array_equal(slot.numpy(), np.nonzero(rp)[0])
+    np.testing.assert_array_equal(chunks.numpy(), rc[rp])
+    np.testing.assert_array_equal(cmask.numpy(), rm[rp])
+
+
+def test_tkl_param_packing_layout():
+    from matchmaker_amd.tkl import TKL_sigir20
+    torch.manual_seed(0)
+    m = TKL_sigir20(64, MU, SIGMA, 8, 1, 32, 2000, True, True, "embedding")
+    with torch.no_grad():
+        m.chunk_scoring.copy_(torch.arange(15.0).view(1, 15))
+    v = m.pack_params()
+    assert v.numel() == 4 * 11 + 13 + 15 + 64
+    p = O.tkl_params_from_state(m.state_dict())
+    np.testing.assert_array_equal(v[:11].numpy(), p["mu"])
+    np.testing.assert_array_equal(v[22:33].numpy(), p["dense_w"])
+    np.testing.assert_array_equal(v[44:46].numpy(), p["sat_w1"])
+    assert float(v[46]) == p["sat_b1"] == 100.0
+    np.testing.assert_array_equal(v[53:55].numpy(), p["ln_w"])
+    np.testing.assert_array_equal(v[57:72].numpy(), np.arange(15.0))
+    np.testing.assert_array_equal(v[72:].numpy(), p["emb_reduce_w"])
+    v2 = m.pack_params()
+    assert v2 is v                                   # cached
+    with torch.no_grad():
+        m.dense.weight.add_(1.0)
+    assert m.pack_params() is not v                  # invalidated by an in-place update
+
+
+@pytest.mark.skipif(not R.available(), reason="/root/reference not mounted (GPU box)")
+def test_dropins_mirror_reference_state_dict_and_positions():
+    from matchmaker_amd.tk import ECAI20_TK, sinusoid_positions
+    from matchmaker_amd.tkl import TKL_sigir20
+    ref_tk = R.make_tk(60, bypass_contextualizer=False, att_heads=6, att_ff_dim=32, max_length=50)
+    mine = ECAI20_TK(60, MU, SIGMA, 6, 2, 32, 50, True, True)
+    assert {k: tuple(v.shape) for k, v in ref_tk.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+    torch.testing.assert_close(mine.positional_features_q, ref_tk.positional_features_q, rtol=0, atol=0)
+    torch.testing.assert_close(mine.positional_features_d, ref_tk.positional_features_d, rtol=0, atol=0)
+    mine.load_state_dict(ref_tk.state_dict())        # strict load works
+    # odd dimension: zero column appended
+    assert sinusoid_positions(7, 3).shape == (1, 3, 7) and float(sinusoid_positions(7, 3)[0, :, -1].abs().sum()) == 0
+
+    ref_tkl = R.make_tkl(64, bypass_contextualizer=False, att_heads=8, att_ff_dim=32)
+    mine_l = TKL_sigir20(64, MU, SIGMA, 8, 2, 32, 2000, True, True, "embedding")
+    assert {k: tuple(v.shape) for k, v in ref_tkl.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in mine_l.state_dict().items()}
+    mine_l.load_state_dict(ref_tkl.state_dict())
+    # the contextualiser half (stays PyTorch) is the same function as the reference's
+    x = torch.randn(2, 9, 64)
+    mk = torch.ones(2, 9)
+    mk[1, 5:] = 0
+    ref_tkl.eval(); mine_l.eval()
+    with torch.no_grad():
+        a, _ = ref_tkl.forward_representation(x, mk, ref_tkl.positional_features_q[:, :9, :])
+        b, _ = mine_l.forward_representation(x, mk, mine_l.positional_features_q[:, :9, :])
+    torch.testing.assert_close(a, b)
+
+
+def test_colbert_dropin_constructs_offline_with_reference_keys():
+    from transformers import BertConfig, BertModel
+    from matchmaker_amd.colbert import ColBERT, ColBERTConfig
+    enc = BertModel(BertConfig(hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                               vocab_size=100))
+    m = ColBERT(ColBERTConfig(bert_model="(injected)", compression_dim=16), bert_model=enc)
+    keys = set(m.state_dict())
+    assert "compressor.weight" in keys and "compressor.bias" in keys
+    assert any(k.startswith("bert_model.") for k in keys)
+    assert all(k.startswith(("bert_model.", "compressor.")) for k in keys)
+    assert m.get_param_stats() == "ColBERT: / " and m.get_param_secondary() == {}
+    toks = {"input_ids": torch.randint(1, 100, (2, 7)), "attention_mask": torch.ones(2, 7, dtype=torch.long)}
+    with torch.no_grad():
+        v = m.forward_representation(toks, sequence_type="doc_encode")
+    assert v.shape == (2, 7, 16)

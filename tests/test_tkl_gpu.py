@@ -1,0 +1,147 @@
+"""GPU parity tests for the TKL path (mm_tkl_fwd through the TKL_sigir20 drop-in) vs the golden
+vectors of the real TKL_sigir20.forward (sigir20_tkl.py:128-294, contextualiser bypassed the same
+way on both sides) and vs the oracle.  fp32 tolerance 1e-3 on scores (BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+SIGMA = [0.1] * 11
+
+
+def make_model(E, sat, dev, heads=None, state=None, bypass=True):
+    from matchmaker_amd.tkl import TKL_sigir20
+
+    class Bypass(TKL_sigir20):   # mirrors oracle/ref_harness.TKLBypass: keeps the mask multiply of :306
+        def forward_representation(self, emb, mask, positional_features=None):
+            return emb * mask.unsqueeze(-1), emb
+
+    heads = heads or (10 if E % 10 == 0 else 8)
+    cls = Bypass if bypass else TKL_sigir20
+    m = cls(E, MU, SIGMA, heads, 1 if bypass else 2, 32 if bypass else 300, 2000, True, True, sat)
+    if state is not None:
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()},
+                                                strict=False)
+        assert not unexpected, unexpected
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("fname", util.golden_files("tkl_"))
+def test_tkl_matches_reference_golden(fname):
+    dev = util.require_gpu()
+    g = util.load(fname)
+    sat = str(g["saturation"])
+    state = {k[len("param."):]: v for k, v in g.items() if k.startswith("param.")}
+    E = g["q"].shape[-1]
+    m = make_model(E, sat, dev, state=state)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).float().to(dev)
+    with torch.no_grad():
+        score, sec = m.forward(t(g["q"]), t(g["d"]), t(g["q_mask"]), t(g["d_mask"]), output_secondary_output=True)
+    np.testing.assert_allclose(score.cpu().numpy(), g["score"], atol=util.TOL_FP32, rtol=1e-5)
+    if "orig_score" in g:
+        win = sec["orig_score"].cpu().numpy()
+        ref = g["orig_score"]
+        np.testing.assert_allclose(win, ref[:, :win.shape[1]], atol=util.TOL_FP32, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,Q,D,E,sat", [(3, 20, 500, 300, "embedding"), (2, 30, 2048, 300, "log"),
+                                          (4, 12, 130, 100, "embedding"), (2, 20, 90, 200, "embedding"),
+                                          (3, 7, 41, 64, "log"), (2, 40, 300, 32, "embedding")])
+def test_tkl_random_vs_oracle(B, Q, D, E, sat):
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(B * 1000 + D)
+    m = make_model(E, sat, dev)
+    with torch.no_grad():
+        for p in (m.chunk_scoring, m.kernel_mult, m.sat_normer.weight):
+            p.copy_(torch.rand(p.shape, generator=gen) + 0.5)
+        m.sat_normer.bias.copy_(torch.rand(2, generator=gen) - 0.5)
+    q = torch.randn(B, Q, E, generator=gen)
+    d = torch.randn(B, D, E, generator=gen)
+    for b in range(B):                                   # plant exact / near matches
+        d[b, (7 * b) % D] = q[b, b % Q]
+        d[b, (11 * b + 3) % D] = q[b, (b + 1) % Q] + 0.1 * torch.randn(E, generator=gen)
+    q_len = torch.randint(1, Q + 1, (B,), generator=gen)
+    d_len = torch.randint(1, D + 1, (B,), generator=gen)
+    d_len[0] = D
+    if B > 1:
+        d_len[1] = min(D, 50)                            # most chunks of this document are dropped
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D)[None] < d_len[:, None]).float()
+    with torch.no_grad():
+        score, sec = m.forward(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), output_secondary_output=True)
+    params = O.tkl_params_from_state({k: v.cpu() for k, v in m.state_dict().items()})
+    ref, ref_win = O.tkl_forward_bypass(q.numpy(), d.numpy(), qm.numpy(), dm.numpy(), params, sat, dtype=np.float64,
+                                        return_windows=True)
+    np.testing.assert_allclose(sec["orig_score"].cpu().numpy(), ref_win, atol=util.TOL_FP32, rtol=1e-5)
+    np.testing.assert_allclose(score.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+def test_tkl_config3_scale_properties():
+    """BASELINE.json config 3 (D=2048, E=300): determinism, permutation equivariance over documents,
+    sampled oracle comparison."""
+    dev = util.require_gpu()
+    B, Q, D, E = 48, 20, 2048, 300
+    gen = torch.Generator(device=dev).manual_seed(3003)
+    m = make_model(E, "embedding", dev)
+    q = torch.randn(B, Q, E, generator=gen, device=dev)
+    d = torch.randn(B, D, E, generator=gen, device=dev)
+    q_len = torch.randint(3, Q + 1, (B,), generator=gen, device=dev)
+    d_len = torch.randint(50, D + 1, (B,), generator=gen, device=dev)
+    qm = (torch.arange(Q, device=dev)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < d_len[:, None]).float()
+    with torch.no_grad():
+        s1 = m.forward(q, d, qm, dm)
+        s2 = m.forward(q, d, qm, dm)
+        assert torch.equal(s1, s2)
+        perm = torch.randperm(B, device=dev)
+        sp = m.forward(q[perm], d[perm], qm[perm], dm[perm])
+    torch.testing.assert_close(sp, s1[perm], rtol=0, atol=1e-5)
+    sel = [0, 13, 47]
+    params = O.tkl_params_from_state({k: v.cpu() for k, v in m.state_dict().items()})
+    ref = O.tkl_forward_bypass(q[sel].cpu().numpy(), d[sel].cpu().numpy(), qm[sel].cpu().numpy(),
+                               dm[sel].cpu().numpy(), params, "embedding", dtype=np.float64)
+    np.testing.assert_allclose(s1[sel].cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+def test_tk_and_tkl_full_models_wire_native_pooling_correctly():
+    """Full drop-in models (real Transformer contextualiser in PyTorch on the GPU): the native block
+    must equal the oracle applied to the very embeddings the module's contextualiser produced."""
+    from matchmaker_amd.tk import ECAI20_TK
+    dev = util.require_gpu()
+    torch.manual_seed(4)
+    B, Q, D, E = 6, 20, 200, 300
+    tk = ECAI20_TK(E, MU, SIGMA, 10, 2, 300, 200, True, True).to(dev).eval()
+    q, d = torch.randn(B, Q, E, device=dev), torch.randn(B, D, E, device=dev)
+    qm = (torch.arange(Q, device=dev)[None] < torch.tensor([20, 3, 11, 20, 7, 15], device=dev)[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < torch.tensor([200, 10, 77, 133, 64, 199], device=dev)[:, None]).float()
+    with torch.no_grad():
+        score, sec = tk.forward(q, d, qm, dm, output_secondary_output=True)
+        qc = tk.forward_representation(q, qm, tk.positional_features_q[:, :Q, :])
+        dc = tk.forward_representation(d, dm, tk.positional_features_d[:, :D, :])
+    ref, ref_pk = O.tk_kernel_pool(qc.cpu().numpy(), dc.cpu().numpy(), qm.cpu().numpy(), dm.cpu().numpy(), MU, SIGMA,
+                                   tk.kernel_alpha_scaler.detach().cpu().numpy().reshape(-1),
+                                   tk.kernel_bin_weights.weight.detach().cpu().numpy().reshape(-1),
+                                   dtype=np.float64, return_per_kernel=True)
+    np.testing.assert_allclose(score.cpu().numpy(), ref, atol=util.TOL_FP32)
+    np.testing.assert_allclose(sec["per_kernel"].cpu().numpy(), ref_pk, atol=5e-3, rtol=1e-4)
+    assert sec["cosine_matrix"].shape == (B, Q, D)
+
+    # training path: autograd through the native forward (backward = torch re-derivation)
+    tk.train()
+    q.requires_grad_(True)
+    s = tk.forward(q, d, qm, dm)
+    s.sum().backward()
+    assert q.grad is not None and torch.isfinite(q.grad).all()
+    assert tk.kernel_bin_weights.weight.grad is not None
+
+    tkl = make_model(E, "embedding", dev, bypass=False)
+    dl = torch.randn(2, 700, E, device=dev)
+    dml = (torch.arange(700, device=dev)[None] < torch.tensor([700, 130], device=dev)[:, None]).float()
+    with torch.no_grad():
+        s_tkl = tkl.forward(q[:2].detach(), dl, qm[:2], dml)
+    assert s_tkl.shape == (2,) and torch.isfinite(s_tkl).all()
