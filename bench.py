@@ -54,13 +54,33 @@ def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
         O.maxsim_paired(np.repeat(qn[i:i + 1], cands, 0), dn, qm, dm)
         return time.perf_counter() - t0
     run(0)
-    while t_total < budget_s and i < nq:
-        t_total += run(i)
+    while t_total < budget_s:
+        t_total += run(i % nq)
         pairs += cands
         i += 1
     return {"value": pairs / t_total, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{i} queries x {cands} candidates (fp32 numpy restatement of colbert.py:68-75, "
-                      f"{t_total:.1f} s of CPU work, BLAS threads = cores)"}
+            "sample": f"{i} passes over whole queries ({nq} distinct) x {cands} candidates = {pairs} pairs of the "
+                      f"bench workload, fp32 numpy restatement of colbert.py:68-75 (oracle/np_oracle.py), "
+                      f"{t_total:.1f} s of CPU work, BLAS threads = cores"}
+
+
+def measured_traffic(nq, cands, lengths):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/*_maxsim_pmc.json, written by tools/profile_maxsim.sh + tools/summarize_rocprof.py:
+    separate --pmc passes, FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*maxsim*pmc*.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        wl = j.get("workload", {})
+        if wl.get("queries") == nq and wl.get("cands") == cands and wl.get("lengths") == lengths:
+            for k, c in j.get("pmc", {}).items():
+                if "maxsim_stream_kernel" in k and "_hbm_traffic_bytes_per_dispatch" in c:
+                    best = (c["_hbm_traffic_bytes_per_dispatch"]["total"], os.path.basename(f))
+    return best
 
 
 def main():
@@ -148,6 +168,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "maxsim_stream_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": ab},
         }
+        tr = measured_traffic(nq, CANDS, args.lengths)
+        if tr is not None:
+            out["roofline"]["traffic"] = tr[0]
+            out["roofline"]["traffic_source"] = f"profiles/{tr[1]} (rocprofv3 PMC passes of this workload)"
         if not args.no_cpu_baseline:
             nsamp = min(nq, 24)
             out["cpu_baseline"] = cpu_baseline(q[:nsamp].cpu(), d[:nsamp * CANDS].cpu(), q_len[:nsamp].cpu(),
