@@ -206,8 +206,11 @@ __device__ __forceinline__ void wait_block(int younger) {
   }
 }
 
-template <int DT, int NBUF, bool NT>
+// NSL = E / 128: a 32-token block is streamed as NSL slices of 32 rows x 256 B (one ring slot each);
+// the accumulator runs across the slices, the query tile is NSL x 32 VGPRs of B fragments.
+template <int DT, int NBUF, bool NT, int NSL>
 __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
+  constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
@@ -227,8 +230,8 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     const int row = 4 * k + (lane >> 4);
     const int c = (lane & 15) ^ (row & 15);
     const int rowt = row < rows_last ? row : rows_last - 1;
-    voff[k] = (uint32_t)(row * 256 + c * 16);
-    voff_tail[k] = (uint32_t)(rowt * 256 + c * 16);
+    voff[k] = (uint32_t)(row * RB + c * 16);
+    voff_tail[k] = (uint32_t)(rowt * RB + c * 16);
   }
   // per-lane LDS offsets of the 8 A-fragment reads: chunk 2kk+h of row r lives at slot (2kk+h)^(r&15)
   uint32_t lo[8];
@@ -241,15 +244,15 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     return len < 0 ? 0 : (len > D ? D : len);
   };
 
-  // ---- producer cursor: next (pair, block) to put in flight --------------------------------
+  // ---- producer cursor: next (pair, block, slice) to put in flight ---------------------------
   int64_t pp = p0;
-  int pt = 0, pn = 0;
+  int pt = 0, pn = 0, psl = 0;
   while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
   int pbuf = 0, cbuf = 0, inflight = 0;
 
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
-      const char* g = dbase + (pp * D + (int64_t)pt * 32) * 256;
+      const char* g = dbase + (pp * D + (int64_t)pt * 32) * RB + psl * 256;
       const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes;
       if (pt == nblk_tot - 1 && rows_last != 32)
         issue_block<NT>(g, voff_tail, dst);
@@ -257,6 +260,8 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
         issue_block<NT>(g, voff, dst);
       pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
       ++inflight;
+      if (NSL > 1 && ++psl < NSL) continue;
+      psl = 0;
       if (++pt == pn) {
         pt = 0;
         ++pp;
@@ -267,7 +272,7 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   top_up();
 
   // ---- query tile as MFMA B fragments ---------------------------------------------------------
-  short8 qf[8];
+  short8 qf[NSL][8];
   bool qvalid = false;
   int64_t cur_q = -1;
   int64_t qi = p0 / a.ppq;
@@ -282,8 +287,9 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     if (qi != cur_q) {
       cur_q = qi;
       const int qr = r < Q ? r : Q - 1;
-      const char* qrow = (const char*)a.q + (qi * Q + qr) * 256;
-      load_q_frags(qrow + h * 16, qf);
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[sl]);
       const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
       qvalid = r < Q && r < qlen;
       if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
@@ -296,21 +302,24 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     for (int i = 0; i < 16; ++i) m[i] = fill;
 
     for (int t = 0; t < nb; ++t) {
-      top_up();
-      wait_block(inflight - 1);
-      const char* buf = smem + cbuf * kBlkBytes;
       f32x16 acc = {0};
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const short8 av = *(const short8*)(buf + lo[kk]);
-        acc = Mfma32x16<DT>::run(av, qf[kk], acc);
+      for (int sl = 0; sl < NSL; ++sl) {
+        top_up();
+        wait_block(inflight - 1);
+        const char* buf = smem + cbuf * kBlkBytes;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const short8 av = *(const short8*)(buf + lo[kk]);
+          acc = Mfma32x16<DT>::run(av, qf[sl][kk], acc);
+        }
+        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+        --inflight;
       }
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
       block_max(m, acc, ex, va, fill, h);
-      cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
-      --inflight;
     }
     const float s = finish_pair(m, qvalid, h);
     if (lane == 0) a.out[pair] = s;
@@ -418,8 +427,10 @@ static int validate(const void* q, const void* d, float* out, int64_t n_pairs, i
   return MM_OK;
 }
 
-static int g_stream_nbuf = 3;  // LDS ring depth of the roofline kernel (env MM_MAXSIM_NBUF)
-static int g_stream_wpc = 0;   // wavefronts per CU to launch (0 = what the ring depth allows)
+// Measured on MI355X (profiles/r01_sweep_nbuf_wpc.log): one wavefront per SIMD (4 / CU) with a
+// 2-slot ring is the fastest point (6.9 TB/s); more wavefronts or deeper rings only add contention.
+static int g_stream_nbuf = 2;  // LDS ring depth of the roofline kernel (env MM_MAXSIM_NBUF)
+static int g_stream_wpc = 4;   // wavefronts per CU to launch (env MM_MAXSIM_WPC; 0 = what LDS allows)
 static int g_stream_nt = 1;    // non-temporal LDS-DMA (env MM_MAXSIM_NT)
 static int g_force_generic = 0;
 static bool g_env_read = false;
@@ -434,7 +445,7 @@ static void read_env() {
   if (g_stream_nbuf > 4) g_stream_nbuf = 4;
 }
 
-template <int DT, int NBUF, bool NT>
+template <int DT, int NBUF, bool NT, int NSL>
 static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   MaxsimArgs a = a0;
   const int lds = NBUF * kBlkBytes;
@@ -444,17 +455,31 @@ static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL>), dim3((unsigned)waves), dim3(64), lds, stream, a);
   return check_launch("maxsim_stream_kernel");
+}
+
+template <int DT, int NSL>
+static int launch_stream_nsl(const MaxsimArgs& a, hipStream_t stream) {
+  const bool nt = g_stream_nt != 0;
+  if (NSL == 1) {  // the tuning knobs are only instantiated for the headline shape
+    switch (g_stream_nbuf) {
+      case 3: return nt ? launch_stream<DT, 3, true, NSL>(a, stream) : launch_stream<DT, 3, false, NSL>(a, stream);
+      case 4: return nt ? launch_stream<DT, 4, true, NSL>(a, stream) : launch_stream<DT, 4, false, NSL>(a, stream);
+      default: return nt ? launch_stream<DT, 2, true, NSL>(a, stream) : launch_stream<DT, 2, false, NSL>(a, stream);
+    }
+  }
+  return launch_stream<DT, 2, true, NSL>(a, stream);
 }
 
 template <int DT>
 static int launch_stream_cfg(const MaxsimArgs& a, hipStream_t stream) {
-  const bool nt = g_stream_nt != 0;
-  switch (g_stream_nbuf) {
-    case 2: return nt ? launch_stream<DT, 2, true>(a, stream) : launch_stream<DT, 2, false>(a, stream);
-    case 4: return nt ? launch_stream<DT, 4, true>(a, stream) : launch_stream<DT, 4, false>(a, stream);
-    default: return nt ? launch_stream<DT, 3, true>(a, stream) : launch_stream<DT, 3, false>(a, stream);
+  switch (a.E / 128) {
+    case 1: return launch_stream_nsl<DT, 1>(a, stream);
+    case 2: return launch_stream_nsl<DT, 2>(a, stream);
+    case 3: return launch_stream_nsl<DT, 3>(a, stream);
+    case 4: return launch_stream_nsl<DT, 4>(a, stream);
+    default: return launch_stream_nsl<DT, 6>(a, stream);
   }
 }
 
@@ -498,7 +523,8 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-  const bool stream_ok = !g_force_generic && dtype != MM_F32 && E == 128 && Q <= 32;
+  const bool stream_ok = !g_force_generic && dtype != MM_F32 && Q <= 32 &&
+                         (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16>(a, stream) : launch_stream_cfg<MM_F16>(a, stream);
   return launch_generic(a, dtype, stream);
 }

@@ -248,12 +248,12 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
   if (saturation == MM_TKL_SAT_EMBEDDING) {
     if (lds2 > 64 * 1024)
-      hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(256), lds2, stream, ps, slot2p,
                        (const float*)q_ctx, q_mask, params, win, C, Q, E, W);
   } else {
     if (lds2 > 64 * 1024)
-      hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(256), lds2, stream, ps, slot2p,
                        (const float*)q_ctx, q_mask, params, win, C, Q, E, W);
   }

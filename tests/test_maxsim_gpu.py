@@ -68,7 +68,9 @@ def test_inbatch_matches_reference_golden(fname, dtype, tol):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("Q,D,E,ppq,nq", [(32, 180, 128, 37, 5), (17, 64, 128, 8, 3), (32, 33, 128, 1, 40),
-                                           (20, 200, 64, 10, 2), (40, 96, 256, 4, 3), (1, 1, 16, 3, 2)])
+                                           (20, 200, 64, 10, 2), (40, 96, 256, 4, 3), (1, 1, 16, 3, 2),
+                                           (32, 180, 768, 6, 3), (30, 200, 768, 1, 5), (20, 70, 256, 3, 3),
+                                           (32, 65, 384, 4, 2), (7, 31, 512, 2, 3)])
 def test_shared_query_layout_random(dtype, tol, Q, D, E, ppq, nq):
     """1 query x C candidates layout (pairs_per_query > 1), ragged lengths incl. empty docs,
     last query with fewer candidates."""

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""MaxSim micro-benchmarks beyond the headline line: ragged MSMARCO-like lengths, the reference's
+pair-per-row layout (query replicated per pair), HF int64 masks (packed on device), fp16, fp32 / E=768
+(generic kernel), all-pairs.  Prints one JSON object per variant."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from matchmaker_amd import ops, synth
+
+dev = torch.device("cuda:0")
+Q, D, E, C = 32, 180, 128, 1000
+
+
+def timeit(fn, steps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+
+
+def report(name, ms, pairs, bytes_):
+    print(json.dumps({"variant": name, "ms": round(ms, 4), "Mpairs_per_s": round(pairs / ms / 1e3, 2),
+                      "GBps": round(bytes_ / ms / 1e6, 1)}), flush=True)
+
+
+nq = int(os.environ.get("NQ", 64))
+which = sys.argv[1:] or ["full", "msmarco", "paired", "i64mask", "fp16", "fp32", "e768", "inbatch"]
+q, d, q_len, d_len = synth.colbert_batch(nq, C, Q, D, E, torch.bfloat16, dev, lengths="full")
+B = nq * C
+if "full" in which:
+    report("bf16 shared-Q full lengths", timeit(lambda: ops.maxsim(q, d, q_len, d_len, C)), B, B * D * E * 2)
+if "msmarco" in which:
+    g = torch.Generator(device=dev).manual_seed(7)
+    dl = synth.msmarco_doc_lengths(B, D, g, dev)
+    rd = int((((dl + 31) // 32) * 32).clamp(max=D).sum().item()) * E * 2
+    report("bf16 shared-Q msmarco lengths (bytes = 32-token blocks actually read)",
+           timeit(lambda: ops.maxsim(q, d, q_len, dl, C)), B, rd)
+if "paired" in which:
+    qp = q.repeat_interleave(C, 0)[: B // 4].contiguous()
+    report("bf16 pair-per-row layout (reference batch layout, Q replicated)",
+           timeit(lambda: ops.maxsim(qp, d[: B // 4], None, d_len[: B // 4], 1)), B // 4, (B // 4) * (D + Q) * E * 2)
+if "i64mask" in which:
+    dm = synth.len_to_mask(d_len, D, torch.int64)
+    qm = synth.len_to_mask(q_len, Q, torch.int64)
+    report("bf16 shared-Q, HF int64 masks packed on device (bytes incl. masks)",
+           timeit(lambda: ops.maxsim(q, d, qm, dm, C)), B, B * D * (E * 2 + 8))
+if "fp16" in which:
+    qh, dh = q.half(), d.half()
+    report("fp16 shared-Q full lengths", timeit(lambda: ops.maxsim(qh, dh, q_len, d_len, C)), B, B * D * E * 2)
+    del qh, dh
+if "fp32" in which:
+    n = B // 4
+    qf, df = q[: nq // 4].float(), d[:n].float()
+    report("fp32 shared-Q (generic kernel)", timeit(lambda: ops.maxsim(qf, df, q_len[: nq // 4], d_len[:n], C)), n, n * D * E * 4)
+    del qf, df
+if "e768" in which:
+    n = 8000
+    q7 = torch.randn(8, Q, 768, device=dev).to(torch.bfloat16)
+    d7 = torch.randn(n, D, 768, device=dev).to(torch.bfloat16)
+    report("bf16 E=768 (reference default dim; generic kernel)", timeit(lambda: ops.maxsim(q7, d7, None, None, 1000)), n, n * D * 768 * 2)
+    del q7, d7
+if "inbatch" in which:
+    qb, db = q[:32].contiguous(), d[:32].contiguous()
+    qm = torch.ones(32, Q, dtype=torch.int64, device=dev); dm = torch.ones(32, D, dtype=torch.int64, device=dev)
+    report("all-pairs 32x32 (dynamic teacher shape)", timeit(lambda: ops.maxsim_inbatch(qb, qm, db, dm, True)), 1024, 32 * D * E * 2)
