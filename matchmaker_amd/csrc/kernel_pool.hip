@@ -59,12 +59,34 @@ __device__ __forceinline__ uint32_t sload_u32(const void* base, int64_t idx) {
 }
 
 // RBF constants in exp2 form: exp(-(c-mu)^2/(2 s^2)) = exp2((c-mu)^2 * c2), c2 = -log2(e)/(2 s^2)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
 struct Rbf {
   float mu[kMaxK];
   float c2[kMaxK];
   float alpha[kMaxK];
   float w[kMaxK];
+  // packed form for v_pk_* math: exp(-(c-mu)^2/(2 s^2)) = exp2(-(c*sq - mu*sq)^2), sq = sqrt(log2(e)/(2 s^2));
+  // kernels are processed two at a time, an odd K gets a dummy partner (sq = 0) whose sum is ignored
+  f32x2 sq2[kMaxK / 2];
+  f32x2 msq2[kMaxK / 2];
 };
+
+template <int K>
+__device__ __forceinline__ void pack_rbf(Rbf& rbf) {
+#pragma unroll
+  for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+    float sq[2], msq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = 2 * kp + u;
+      sq[u] = k < K ? sqrtf(-rbf.c2[k]) : 0.0f;
+      msq[u] = k < K ? rbf.mu[k] * sq[u] : 0.0f;
+    }
+    rbf.sq2[kp] = f32x2{sq[0], sq[1]};
+    rbf.msq2[kp] = f32x2{msq[0], msq[1]};
+  }
+}
 
 __device__ __forceinline__ float sload_f32(const float* base, int idx) {
   return __builtin_bit_cast(float, sload_u32(base, idx));
@@ -82,23 +104,31 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
     rbf.alpha[k] = alpha ? sload_f32(alpha, k) : 1.0f;
     rbf.w[k] = w ? sload_f32(w, k) : 0.0f;
   }
+  pack_rbf<K>(rbf);
 }
 
 // Epilogue of one 32-token document block: cosine scaling + K RBF kernels, summed into pk[k].
 // acc[i]: raw dot of document row rowof(i)+4h with this lane's query token; rdr[i]: 1/(|d|+tiny) of
 // that row; vbits (already shifted by 4h): bit rowof(i) set <=> the row is a real token.
+// Packed: per row one select (a masked row gets cosine 1e5, which underflows every kernel to exactly
+// 0, the same contribution as the reference's multiply by the 0 mask) and per kernel PAIR
+// v_pk_fma + v_pk_mul + 2 v_exp + v_pk_add.  The fp32 MFMA shares the SIMD's FMA lanes with the
+// VALU (measured: zero overlap, profiles/r01_kernel_pool_pmc.json), so every VALU op removed here
+// is wall time.
 template <int K>
-__device__ __forceinline__ void rbf_block(float (&pk)[kMaxK], const f32x16& acc, const float (&rdr)[16], float rq,
+__device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
                                           uint32_t vbits, const Rbf& rbf) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const float c = (acc[i] * rq) * rdr[i];
-    const bool valid = (vbits >> rowof(i)) & 1u;
+    float c = (acc[i] * rq) * rdr[i];
+    c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+    const f32x2 cc = {c, c};
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const float t = c - rbf.mu[k];
-      const float e = __builtin_amdgcn_exp2f(t * t * rbf.c2[k]);
-      pk[k] += valid ? e : 0.0f;
+    for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+      const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+      const f32x2 av = -(sv * sv);
+      const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+      pk2[kp] += e;
     }
   }
 }
@@ -332,13 +362,13 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
-    float pk[kMaxK];
+    f32x2 pk2[kMaxK / 2];
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) pk[k] = 0.0f;
+    for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
 
     for (int t = 0; t < nb; ++t) {
       f32x16 acc = {0};
-      float ss = 0.0f;
+      f32x2 ss2 = {0.0f, 0.0f};
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         top_up();
@@ -349,15 +379,16 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
           f32x4 av = *(const f32x4*)(buf + p * 32);
           if (p == kPairSteps - 1 && h) av = f32x4{0, 0, 0, 0};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], qf[s][p][j], acc, 0, 0, 0);
-            ss += av[j] * av[j];
-          }
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], qf[s][p][j], acc, 0, 0, 0);
+          const f32x2 lo = {av[0], av[1]}, hi = {av[2], av[3]};
+          ss2 += lo * lo;
+          ss2 += hi * hi;
         }
         cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
         --inflight;
       }
       // document-token norms: lane (r,h) summed the even/odd chunks of row r
+      float ss = ss2[0] + ss2[1];
       ss += __shfl_xor(ss, 32, 64);
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
       float rdr[16];
@@ -372,11 +403,15 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
       if (TKL)
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
       else
-        rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
+        rbf_block<K>(pk2, acc, rdr, rq, va >> (4 * h), rbf);
     }
     if (!TKL) {
+      float pk[kMaxK];
 #pragma unroll
-      for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
+      for (int k = 0; k < K; ++k) {
+        pk[k] = pk2[k >> 1][k & 1];
+        pk[k] += __shfl_xor(pk[k], 32, 64);
+      }
       finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
     }
   }
@@ -413,6 +448,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
     rbf.alpha[k] = a.alpha ? a.alpha[k] : 1.0f;
     rbf.w[k] = a.w ? a.w[k] : 0.0f;
   }
+  pack_rbf<K>(rbf);
   float tot[kMaxK];
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) tot[k] = 0.0f;
@@ -430,9 +466,9 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
     }
     qss += __shfl_xor(qss, 32, 64);
     const float rq = 1.0f / (sqrtf(qss) + 1e-13f);
-    float pk[kMaxK];
+    f32x2 pk2[kMaxK / 2];
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) pk[k] = 0.0f;
+    for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
     for (int t = 0; t < nb; ++t) {
       const int drow = 32 * t + r;
       const char* dr = dbase + (drow < D ? drow : D - 1) * rowb;
@@ -464,12 +500,13 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
       if (TKL)
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, qtok, h, acc, rdr, rq, va >> (4 * h), rbf);
       else
-        rbf_block<K>(pk, acc, rdr, rq, va >> (4 * h), rbf);
+        rbf_block<K>(pk2, acc, rdr, rq, va >> (4 * h), rbf);
     }
     if (TKL) continue;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const float v = pk[k] + __shfl_xor(pk[k], 32, 64);
+      const float pkk = pk2[k >> 1][k & 1];
+      const float v = pkk + __shfl_xor(pkk, 32, 64);
       float lg = __logf(fmaxf(v * rbf.alpha[k], 1e-10f));
       tot[k] += wave_sum((qvalid && h == 0) ? lg : 0.0f);
     }
