@@ -21,7 +21,7 @@ constexpr int kK = 11;
 constexpr int kKC = 12;       // K + count channel
 constexpr int kU = 20;        // position pairs per chunk
 constexpr int kWinPairs = 15; // 30 positions, stride 2
-constexpr int kWT = 32;       // windows per workgroup in stage 2
+constexpr int kWT = 64;       // windows per workgroup in stage 2
 
 struct TklParams {            // offsets into the packed float parameter vector (see mm_native.h)
   __host__ __device__ static int mu() { return 0; }
@@ -113,7 +113,10 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
         const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];              // :232
 #pragma unroll
         for (int k = 0; k < kK; ++k) {
-          const float sat = s1 * powf(fmaxf(pk[k], 1e-10f), s2) - s3;  // :234
+          // x^s2 = exp2(s2 * log2 x) on the hardware transcendentals (x >= 1e-10 > 0): 3 instructions
+          // instead of ~80 for powf; |s2 * log2 x| <= ~33 |s2| keeps the error ~1e-6 relative
+          const float xp = __builtin_amdgcn_exp2f(s2 * __builtin_amdgcn_logf(fmaxf(pk[k], 1e-10f)));
+          const float sat = s1 * xp - s3;  // :234
           val += prm[TklParams::dense() + k] * (sat * factor);
         }
       } else {
