@@ -19,7 +19,7 @@ def main():
     root, out = sys.argv[1], sys.argv[2]
     pat = sys.argv[3] if len(sys.argv) > 3 else "mm::"
     res = {"source_dir": os.path.basename(os.path.normpath(root)), "kernel_filter": pat, "kernel_trace": [], "pmc": {},
-           "workload": {"queries": int(os.environ.get("MM_PROF_QUERIES", 64)), "cands": 1000,
+           "workload": {"queries": int(os.environ.get("MM_PROF_QUERIES", 256)), "cands": 1000,
                         "lengths": os.environ.get("MM_PROF_LENGTHS", "full"),
                         "command": "python bench.py --no-cpu-baseline (see tools/profile_maxsim.sh)"}}
     for db in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
