@@ -81,7 +81,7 @@ __device__ __forceinline__ void pack_rbf(Rbf& rbf) {
     for (int u = 0; u < 2; ++u) {
       const int k = 2 * kp + u;
       sq[u] = k < K ? sqrtf(-rbf.c2[k]) : 0.0f;
-      msq[u] = k < K ? rbf.mu[k] * sq[u] : 0.0f;
+      msq[u] = k < K ? rbf.mu[k] * sq[u] : 1.0e3f;  // dummy partner: exp2(-(0*c - 1e3)^2) = 0 for every c
     }
     rbf.sq2[kp] = f32x2{sq[0], sq[1]};
     rbf.msq2[kp] = f32x2{msq[0], msq[1]};
@@ -117,18 +117,30 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
 // is wall time.
 template <int K>
 __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
-                                          uint32_t vbits, const Rbf& rbf) {
+                                          uint32_t va, int h, const Rbf& rbf) {
+  // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
+  // 4g..4g+3 hold rows 8g..8g+7 (both lane halves), so a group with no real row is skipped as a
+  // whole (the last block of a document: D = 200 -> 8 of 32 rows) and a group of 8 real rows needs
+  // no per-row select.
+  const uint32_t vbits = va >> (4 * h);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    float c = (acc[i] * rq) * rdr[i];
-    c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
-    const f32x2 cc = {c, c};
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t gm = (va >> (8 * g)) & 0xffu;
+    if (gm == 0) continue;
+    const bool full = gm == 0xffu;
 #pragma unroll
-    for (int kp = 0; kp < (K + 1) / 2; ++kp) {
-      const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
-      const f32x2 av = -(sv * sv);
-      const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
-      pk2[kp] += e;
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = 4 * g + ii;
+      float c = (acc[i] * rq) * rdr[i];
+      if (!full) c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+      const f32x2 cc = {c, c};
+#pragma unroll
+      for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+        const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+        const f32x2 av = -(sv * sv);
+        const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+        pk2[kp] += e;
+      }
     }
   }
 }
@@ -140,37 +152,43 @@ template <int K>
 __device__ __forceinline__ void tkl_block(float* ps_chunk, int Q, int t, int r, int h, const f32x16& acc,
                                           const float (&rdr)[16], float rq, uint32_t vbits, const Rbf& rbf) {
   constexpr int KC = K + 1;
-  static_assert(KC % 4 == 0, "channel count must be a multiple of 4 floats");
+  constexpr int KP = (K + 1) / 2;
+  static_assert(KC % 4 == 0 && K % 2 == 1, "K kernels + the count channel must fill whole float4s");
   const int npairs = t == 0 ? 8 : 2;  // block 1 only holds positions 32..39 (rows 0..3 + 4h)
 #pragma unroll
   for (int ip = 0; ip < 8; ++ip) {
     if (ip < npairs) {  // wave-uniform guard; keeps every register index static
-    float o[KC];
+      f32x2 o2[KP];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) o[k] = 0.0f;
+      for (int k = 0; k < KP; ++k) o2[k] = f32x2{0.0f, 0.0f};
+      float cnt = 0.0f;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int i = 2 * ip + half;
-      const float c = (acc[i] * rq) * rdr[i];
-      const bool valid = (vbits >> rowof(i)) & 1u;
-      bool any = false;
+      for (int half = 0; half < 2; ++half) {
+        const int i = 2 * ip + half;
+        float c = (acc[i] * rq) * rdr[i];
+        // masked position: cosine 1e5 underflows every kernel to exactly 0 (= the reference's
+        // multiply by the 0 mask, :194); the dummy 12th kernel is built to be 0 everywhere
+        c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+        const f32x2 cc = {c, c};
+        f32x2 any2 = {0.0f, 0.0f};
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float tt = c - rbf.mu[k];
-        float e = __builtin_amdgcn_exp2f(tt * tt * rbf.c2[k]);
-        e = valid ? e : 0.0f;
-        o[k] += e;
-        any = any || (e != 0.0f);
+        for (int kp = 0; kp < KP; ++kp) {
+          const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+          const f32x2 av = -(sv * sv);
+          const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+          o2[kp] += e;
+          any2 += e;
+        }
+        cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;  // activations are >= 0: sum != 0 <=> any != 0 (:210)
       }
-      o[K] += any ? 1.0f : 0.0f;
-    }
-    const int row0 = rowof(2 * ip) + 4 * h;
-    const int u = (32 * t + row0) >> 1;
-    if (r < Q && u < 20) {
-      f32x4* dst = (f32x4*)(ps_chunk + ((int64_t)u * Q + r) * KC);
+      const int row0 = rowof(2 * ip) + 4 * h;
+      const int u = (32 * t + row0) >> 1;
+      if (r < Q && u < 20) {
+        f32x4* dst = (f32x4*)(ps_chunk + ((int64_t)u * Q + r) * KC);
 #pragma unroll
-      for (int v = 0; v < KC / 4; ++v) dst[v] = f32x4{o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};
-    }
+        for (int v = 0; v < KC / 4 - 1; ++v) dst[v] = f32x4{o2[2 * v][0], o2[2 * v][1], o2[2 * v + 1][0], o2[2 * v + 1][1]};
+        dst[KC / 4 - 1] = f32x4{o2[KP - 2][0], o2[KP - 2][1], o2[KP - 1][0], cnt};
+      }
     }
   }
 }
@@ -403,7 +421,285 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
       if (TKL)
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
       else
-        rbf_block<K>(pk2, acc, rdr, rq, va >> (4 * h), rbf);
+        rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
+    }
+    if (!TKL) {
+      float pk[kMaxK];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        pk[k] = pk2[k >> 1][k & 1];
+        pk[k] += __shfl_xor(pk[k], 32, 64);
+      }
+      finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-bf16 streaming kernel (the default for E == 100*NS, Q <= 32)
+//
+// The exact-f32 MFMA runs at the fp32 VECTOR rate (64 cycles per 32x32x2 on a SIMD) and shares the
+// SIMD's FMA lanes with the VALU epilogue: at E = 300 it alone is 9,600 cycles per 32-token block
+// (profiles/r01_tk_pmc.json: MFMA busy 51 %, no overlap with the RBF math).  This kernel feeds the
+// 16x faster bf16 matrix pipe instead: every fp32 operand x is split as x = hi + lo + eps with
+// hi = bf16_rne(x), lo = bf16_rne(x - hi) (|eps| <= 2^-18 |x|), and the dot product is the sum of the
+// FOUR bf16 MFMAs hi.hi + lo.hi + hi.lo + lo.lo accumulated in fp32.  Keeping the lo.lo term
+// matters: for near-identical vectors (the cosine ~ 1 matches that feed the mu = 1.0 / 0.9
+// kernels) the lo_i^2 terms are all positive and would bias the cosine by ~3e-6.  With it the
+// cosine error is ~1e-7 on ordinary inputs (= an fp32 accumulation in a different order) and at most
+// ~1.5e-6 on planted near-duplicates (bounded against the fp64 oracle on the CPU by
+// tests/test_host_cpu.py::test_split_bf16_numerics, and on the GPU by the parity tests).
+// Cost per 16 K-values: 4 x 32 MFMA cycles (was 8 x 64) + 20 VALU ops for the split of the 8 values
+// a lane feeds.  The bf16 pipe is independent of the VALU, so the split and the RBF epilogue can
+// overlap it.
+//
+// K order inside a slice of 25 chunks: step p (0..5) takes chunks 4p..4p+3 (lane half h: chunks
+// 4p+2h, 4p+2h+1 = 8 consecutive floats); chunk 24 of each slice is parked and the NS parked chunks
+// form one extra step (slice s -> lane half s>>1, position s&1) = 6*NS + 1 steps per block.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+  u32x4 hw, lw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4];
+    const float b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+    const uint32_t w = cvt_pk_bf16(a, b);
+    const float ha = __uint_as_float(w << 16), hb = __uint_as_float(w & 0xffff0000u);
+    hw[j] = w;
+    lw[j] = cvt_pk_bf16(a - ha, b - hb);
+  }
+  hi = __builtin_bit_cast(bf16x8, hw);
+  lo = __builtin_bit_cast(bf16x8, lw);
+}
+
+__device__ __forceinline__ float sumsq4(const f32x4& v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+
+constexpr int kSplitSteps = 6;  // full 16-wide K steps per 100-float slice
+
+// this lane's 12 chunks of one query-row slice (base = row + slice*400 + h*32) + the parked chunk 24
+// (left = row + slice*400 + 384); own vmcnt(0): runs once per query
+__device__ __forceinline__ void load_q_slice_split(const char* base, const char* left, f32x4 (&qr)[13]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %13, off\n\t"
+      "global_load_dwordx4 %1, %13, off offset:16\n\t"
+      "global_load_dwordx4 %2, %13, off offset:64\n\t"
+      "global_load_dwordx4 %3, %13, off offset:80\n\t"
+      "global_load_dwordx4 %4, %13, off offset:128\n\t"
+      "global_load_dwordx4 %5, %13, off offset:144\n\t"
+      "global_load_dwordx4 %6, %13, off offset:192\n\t"
+      "global_load_dwordx4 %7, %13, off offset:208\n\t"
+      "global_load_dwordx4 %8, %13, off offset:256\n\t"
+      "global_load_dwordx4 %9, %13, off offset:272\n\t"
+      "global_load_dwordx4 %10, %13, off offset:320\n\t"
+      "global_load_dwordx4 %11, %13, off offset:336\n\t"
+      "global_load_dwordx4 %12, %14, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(qr[0]), "=&v"(qr[1]), "=&v"(qr[2]), "=&v"(qr[3]), "=&v"(qr[4]), "=&v"(qr[5]), "=&v"(qr[6]),
+        "=&v"(qr[7]), "=&v"(qr[8]), "=&v"(qr[9]), "=&v"(qr[10]), "=&v"(qr[11]), "=&v"(qr[12])
+      : "v"(base), "v"(left)
+      : "memory");
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NS, int K, int NBUF, bool NT, bool TKL>
+__global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
+  static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  constexpr int E = 100 * NS;
+  constexpr int RB = E * 4;  // row bytes
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* rdbuf = (float*)(smem + NBUF * kSliceBytes);  // 32 floats: 1/(|d|+tiny) of the block's rows
+
+  uint32_t voff[kSliceInstr];
+#pragma unroll
+  for (int n = 0; n < kSliceInstr; ++n) {
+    int s = 64 * n + lane;
+    if (s > 32 * kSC - 1) s = 32 * kSC - 1;
+    const int row = s / kSC, c = s - row * kSC;
+    voff[n] = (uint32_t)(row * RB + c * 16);
+  }
+  const uint32_t vmax_tail = (uint32_t)((rows_last - 1) * RB + (kSC - 1) * 16);
+  const uint32_t a_off = (uint32_t)(r * (kSC * 16) + h * 32);  // this lane's 32-B A window of step 0
+  const uint32_t l_off = (uint32_t)(r * (kSC * 16) + 24 * 16); // the parked chunk of this lane's row
+
+  Rbf rbf;
+  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+
+  const char* dbase = (const char*)a.d;
+  auto doc_len = [&](int64_t p) -> int {
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
+    return len < 0 ? 0 : (len > D ? D : len);
+  };
+
+  int64_t pp = p0;
+  int pt = 0, ps = 0, pn = 0;
+  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      const char* g = dbase + (pp * a.d_doc_rows + a.d_row0 + (int64_t)pt * 32) * RB + ps * (kSC * 16);
+      issue_slice<NT>(g, voff, vmax_tail, pt == nblk_tot - 1 && rows_last != 32, lds0 + (uint32_t)pbuf * kSliceBytes);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (++ps == NS) {
+        ps = 0;
+        if (++pt == pn) {
+          pt = 0;
+          ++pp;
+          while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+        }
+      }
+    }
+  };
+  top_up();
+
+  // query tile as bf16 hi / lo B fragments: (6*NS + 1) steps x 4 VGPRs x 2
+  bf16x8 qhi[NS][kSplitSteps], qlo[NS][kSplitSteps], qhiL, qloL;
+  float rq = 0.0f;
+  bool qvalid = false;
+  int64_t cur_q = -1;
+  int64_t qi = TKL ? 0 : p0 / a.ppq;
+  int64_t q_left = TKL ? 0 : a.ppq - (p0 - qi * a.ppq);
+
+  for (int64_t pair = p0; pair < p1; ++pair) {
+    if (TKL) {
+      qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
+    } else {
+      if (q_left == 0) {
+        ++qi;
+        q_left = a.ppq;
+      }
+      --q_left;
+    }
+    if (qi != cur_q) {
+      cur_q = qi;
+      const int qr = r < Q ? r : Q - 1;
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
+      float ss = 0.0f;
+      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        f32x4 raw[13];
+        load_q_slice_split(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw);
+#pragma unroll
+        for (int p = 0; p < kSplitSteps; ++p) {
+          split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
+          ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
+        }
+        if (h == 0) ss += sumsq4(raw[12]);  // both halves loaded the parked chunk: count it once
+        if (h == (s >> 1)) park[s & 1] = raw[12];
+      }
+      split8(park[0], park[1], qhiL, qloL);
+      ss += __shfl_xor(ss, 32, 64);
+      rq = 1.0f / (sqrtf(ss) + 1e-13f);
+      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      qvalid = r < Q && r < qlen;
+      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+    }
+    const int len = doc_len(pair);
+    const int nb = (len + 31) >> 5;
+    f32x2 pk2[kMaxK / 2];
+#pragma unroll
+    for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
+
+    for (int t = 0; t < nb; ++t) {
+      f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+      f32x2 ss2 = {0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        top_up();
+        wait_slices(inflight - 1);
+        const char* buf = smem + cbuf * kSliceBytes;
+        // all 13 LDS reads of the slice go out first; the split of step p+1 and the norm update are
+        // scheduled between the four MFMAs of step p (the bf16 matrix pipe runs beside the VALU)
+        f32x4 x[13];
+#pragma unroll
+        for (int p = 0; p < kSplitSteps; ++p) {
+          x[2 * p] = *(const f32x4*)(buf + a_off + p * 64);
+          x[2 * p + 1] = *(const f32x4*)(buf + a_off + p * 64 + 16);
+        }
+        x[12] = *(const f32x4*)(buf + l_off);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ah, al;
+        split8(x[0], x[1], ah, al);
+#pragma unroll
+        for (int p = 0; p < kSplitSteps; ++p) {
+          bf16x8 nh = ah, nl = al;
+          if (p + 1 < kSplitSteps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
+          acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
+          acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
+          acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
+          acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
+          {
+            const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
+            const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
+            ss2 += a0 * a0;
+            ss2 += a1 * a1;
+            ss2 += b0 * b0;
+            ss2 += b1 * b1;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 VALU in its shadow
+          }
+          ah = nh;
+          al = nl;
+        }
+        const f32x4 xl = x[12];
+        if (h == 0) ss2 += f32x2{xl[0] * xl[0] + xl[1] * xl[1], xl[2] * xl[2] + xl[3] * xl[3]};
+        if (h == (s >> 1)) park[s & 1] = xl;
+        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+        --inflight;
+      }
+      {
+        bf16x8 ah, al;
+        split8(park[0], park[1], ah, al);
+        acc_hh = mfma_bf16(ah, qhiL, acc_hh);
+        acc_lh = mfma_bf16(al, qhiL, acc_lh);
+        acc_xl = mfma_bf16(ah, qloL, acc_xl);
+        acc_xl = mfma_bf16(al, qloL, acc_xl);
+      }
+      float ss = ss2[0] + ss2[1];
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+      // document-token norms: lane (r,h) summed its K-halves of row r (from the fp32 values)
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      float rdr[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
+        rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
+      }
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      if (TKL)
+        tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+      else
+        rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
     }
     if (!TKL) {
       float pk[kMaxK];
@@ -500,7 +796,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
       if (TKL)
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, qtok, h, acc, rdr, rq, va >> (4 * h), rbf);
       else
-        rbf_block<K>(pk2, acc, rdr, rq, va >> (4 * h), rbf);
+        rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
     }
     if (TKL) continue;
 #pragma unroll
@@ -531,13 +827,26 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
   const dim3 grid((unsigned)waves), block(64);
+  // MM_KP_F32MFMA=1 selects the exact-f32 MFMA kernel (A/B runs, tools/bench_kernel_pool.py);
+  // the default is the split-bf16 kernel (same numerics class, 4x less matrix-pipe time)
+  static int f32mfma = -1;
+  if (f32mfma < 0) f32mfma = getenv("MM_KP_F32MFMA") ? atoi(getenv("MM_KP_F32MFMA")) : 0;
+  if (f32mfma) {
+    if (a.E == 100)
+      hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+    else if (a.E == 200)
+      hipLaunchKernelGGL((kernel_pool_stream_kernel<2, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+    else
+      hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+    return check_launch("kernel_pool_stream_kernel");
+  }
   if (a.E == 100)
-    hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+    hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
   else if (a.E == 200)
-    hipLaunchKernelGGL((kernel_pool_stream_kernel<2, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+    hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, true, TKL>), grid, block, lds, stream, a);
   else
-    hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
-  return check_launch("kernel_pool_stream_kernel");
+    hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
+  return check_launch("kernel_pool_split_kernel");
 }
 
 bool kp_stream_supported(int Q, int E) { return Q <= 32 && (E == 100 || E == 200 || E == 300); }

@@ -138,3 +138,30 @@ def test_colbert_dropin_constructs_offline_with_reference_keys():
     with torch.no_grad():
         v = m.forward_representation(toks, sequence_type="doc_encode")
     assert v.shape == (2, 7, 16)
+
+
+def test_split_bf16_numerics():
+    """The TK / TKL kernels feed the bf16 matrix pipe with fp32 operands split as hi + lo (four
+    MFMAs per K step).  Bound that scheme's cosine error against the fp64 oracle on the reference's
+    golden TK inputs and on an adversarial batch of planted near-duplicates (cosine ~ 1, where a
+    dropped lo.lo term would bias the result): it must stay within ~10x of
+    fp32-accumulation noise (<= 2.5e-6 on the cosine; the scores' 1e-3 tolerance is 2-3 orders above)."""
+    from tests import util
+    g = util.load("tk_q20_d200_e300.npz")
+    B = g["d"].shape[0]
+    q = np.repeat(g["q"], B, 0) if g["q"].shape[0] == 1 else g["q"]
+    c64 = O.cosine_matrix(q, g["d"], np.float64)
+    c32 = O.cosine_matrix(q, g["d"], np.float32)
+    cs = O.cosine_matrix_split_bf16(q, g["d"])
+    e32, es = np.abs(c32 - c64).max(), np.abs(cs - c64).max()
+    assert es < 5e-7 and es < 4 * max(e32, 1e-7), (es, e32)
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((4, 20, 300)).astype(np.float32) * 3.0
+    d = rng.standard_normal((4, 200, 300)).astype(np.float32)
+    for b in range(4):
+        for j in range(0, 200, 5):
+            d[b, j] = q[b, j % 20] * (1 + 0.01 * j) + 0.02 * rng.standard_normal(300).astype(np.float32)
+    es = np.abs(O.cosine_matrix_split_bf16(q, d) - O.cosine_matrix(q, d, np.float64)).max()
+    assert es < 2.5e-6, es       # 2^-18 residual per operand; worst case = coherent near-duplicates
+    # exact power-of-two scale invariance (what tests/test_kernel_pool_gpu.py asserts on the device)
+    assert np.array_equal(O.cosine_matrix_split_bf16(q * 4, d * 0.5), O.cosine_matrix_split_bf16(q, d))
