@@ -95,6 +95,37 @@ int mm_maxsim_inbatch_fwd(const void* q, const void* d,
                           int bug_compatible,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ragged (CSR) MaxSim over a resident token store: document p = rows [doc_begin[p], doc_end[p]) of
+ * `tokens` [T, E]; no padding, no document mask (every stored row is a real token: zero rows were
+ * stripped when the store was written, dense_retrieval.py:244).  One launch replaces the
+ * per-candidate Python loop of the ColBERT retrieval aggregate
+ *   matchmaker/dense_retrieval.py:398-412   (doc_infos[seq_id] = (file, start, end) -> storage[file][start:end])
+ *   ColBERT.forward_aggregation             matchmaker/models/colbert.py:100-112
+ * q [n_queries, Q, E] in the store's dtype, pair p uses query p / pairs_per_query; q_mask as for
+ * mm_maxsim_fwd (MM_MASK_NONE reproduces forward_aggregation exactly).  An empty range scores like
+ * a fully padded document (-1000 per query token).  out [n_pairs] float32. */
+size_t mm_maxsim_ragged_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int q_mask_kind);
+
+int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int64_t* doc_begin, const int64_t* doc_end,
+                         const void* q_mask, int q_mask_kind, float* out,
+                         int64_t n_pairs, int64_t pairs_per_query, int Q, int E, int dtype,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the paired MaxSim (pair-per-row layout, the one train.py uses: train.py:347-348,
+ * loss.backward() :503-524).  Recomputes the similarities and routes grad_out[p] to the FIRST
+ * arg-max document position of every real query token (torch.max's rule); nothing flows through
+ * the -1000 sentinel (colbert.py:69) or padded query tokens (:73).
+ *   grad_out [n_pairs] float32; grad_q [n_pairs, Q, E], grad_d [n_pairs, D, E] float32, fully
+ *   written by the call (grad_d is zero-filled first).  q/d/masks exactly as given to the forward. */
+size_t mm_maxsim_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind);
+
+int mm_maxsim_bwd(const void* q, const void* d,
+                  const void* q_mask, int q_mask_kind,
+                  const void* d_mask, int d_mask_kind,
+                  const float* grad_out, float* grad_q, float* grad_d,
+                  int64_t n_pairs, int Q, int D, int E, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * TK kernel pooling (cosine match matrix + K RBF kernels + log-sum pooling + bin weights).
  *

@@ -31,8 +31,8 @@ class ColBERTConfig(PretrainedConfig):
 
 
 class _MaxSimFn(torch.autograd.Function):
-    """Native forward; backward by re-deriving the arg-max routing with torch ops on the device
-    (training path, train.py:503-524).  Inference (eval.py:76 no_grad) never gets here."""
+    """Native forward (mm_maxsim_fwd) and native backward (mm_maxsim_bwd: arg-max routing recomputed
+    on the device, no [B,Q,D] tensor) for the training path, train.py:347-348 / :503-524."""
 
     @staticmethod
     def forward(ctx, q, d, q_mask, d_mask):
@@ -42,13 +42,7 @@ class _MaxSimFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, d, q_mask, d_mask = ctx.saved_tensors
-        with torch.enable_grad():
-            q_ = q.detach().float().requires_grad_(True)
-            d_ = d.detach().float().requires_grad_(True)
-            s = torch.bmm(q_, d_.transpose(1, 2))
-            s = s.masked_fill(~(d_mask != 0).unsqueeze(1), -1000.0)
-            m = s.max(-1).values.masked_fill(~(q_mask != 0), 0.0).sum(-1)
-            gq, gd = torch.autograd.grad(m, (q_, d_), g.float())
+        gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g)
         return gq.to(q.dtype), gd.to(d.dtype), None, None
 
 

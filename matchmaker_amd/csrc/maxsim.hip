@@ -33,6 +33,10 @@ struct MaxsimArgs {
   int inb_bug;     // all-pairs: mask with the document row of the *query* index (colbert.py:158)
   int Q, D, E;
   int64_t pairs_per_wave;
+  // ragged (CSR) documents: document p = rows [rag_begin[p], rag_end[p]) of the token matrix `d`
+  // (the reference's on-disk store: token_reps_N.npy + doc_infos, dense_retrieval.py:201-280)
+  const int64_t* rag_begin;
+  const int64_t* rag_end;
 };
 
 template <int DT>
@@ -81,6 +85,13 @@ __device__ __forceinline__ uint32_t sload_u32(const void* base, int64_t idx) {
   uint32_t v;
   const uint32_t* p = (const uint32_t*)base + idx;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+
+__device__ __forceinline__ int64_t sload_i64(const int64_t* base, int64_t idx) {
+  int64_t v;
+  const int64_t* p = base + idx;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
   return v;
 }
 
@@ -208,7 +219,7 @@ __device__ __forceinline__ void wait_block(int younger) {
 
 // NSL = E / 128: a 32-token block is streamed as NSL slices of 32 rows x 256 B (one ring slot each);
 // the accumulator runs across the slices, the query tile is NSL x 32 VGPRs of B fragments.
-template <int DT, int NBUF, bool NT, int NSL>
+template <int DT, int NBUF, bool NT, int NSL, bool RAG>
 __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,21 +251,41 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
 
   const char* dbase = (const char*)a.d;
   auto doc_len = [&](int64_t p) -> int {
+    if (RAG) {
+      const int64_t l = sload_i64(a.rag_end, p) - sload_i64(a.rag_begin, p);
+      return l < 0 ? 0 : (l > 0x7fffffe0LL ? 0x7fffffe0 : (int)l);
+    }
     int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
     return len < 0 ? 0 : (len > D ? D : len);
   };
 
   // ---- producer cursor: next (pair, block, slice) to put in flight ---------------------------
   int64_t pp = p0;
-  int pt = 0, pn = 0, psl = 0;
-  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pt = 0, pn = 0, psl = 0, plen = 0;
+  while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) == 0) ++pp;
   int pbuf = 0, cbuf = 0, inflight = 0;
 
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
-      const char* g = dbase + (pp * D + (int64_t)pt * 32) * RB + psl * 256;
+      const int64_t row0 = RAG ? sload_i64(a.rag_begin, pp) : pp * D;
+      const char* g = dbase + (row0 + (int64_t)pt * 32) * RB + psl * 256;
       const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes;
-      if (pt == nblk_tot - 1 && rows_last != 32)
+      if (RAG) {
+        // documents have no common padded length: rows past this document's end are redirected to
+        // its last row (the last document must not read past the token matrix)
+        const int rl = plen - 32 * pt;  // rows of this block that exist (>= 1)
+        if (rl < 32) {
+          uint32_t vt[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int over = 4 * k + (lane >> 4) - (rl - 1);
+            vt[k] = voff[k] - (uint32_t)((over > 0 ? over : 0) * RB);
+          }
+          issue_block<NT>(g, vt, dst);
+        } else {
+          issue_block<NT>(g, voff, dst);
+        }
+      } else if (pt == nblk_tot - 1 && rows_last != 32)
         issue_block<NT>(g, voff_tail, dst);
       else
         issue_block<NT>(g, voff, dst);
@@ -265,7 +296,7 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
       if (++pt == pn) {
         pt = 0;
         ++pp;
-        while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+        while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) == 0) ++pp;
       }
     }
   };
@@ -296,7 +327,8 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
-    const float fill = len < D ? -1000.0f : neg_inf();
+    // ragged documents have no padded positions; an empty one scores like a fully padded one
+    const float fill = (RAG ? len == 0 : len < D) ? -1000.0f : neg_inf();
     float m[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) m[i] = fill;
@@ -318,7 +350,7 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
       }
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
       block_max(m, acc, ex, va, fill, h);
     }
     const float s = finish_pair(m, qvalid, h);
@@ -370,7 +402,7 @@ __global__ void __launch_bounds__(64) maxsim_generic_kernel(const MaxsimArgs a) 
   const int r = lane & 31, h = lane >> 5;
   const int64_t pair = blockIdx.x;
   if (pair >= a.n_pairs) return;
-  const int D = a.D, Q = a.Q, E = a.E;
+  const int Q = a.Q, E = a.E;
   constexpr int ES = (DT == MM_F32) ? 4 : 2;
   const int64_t rowb = (int64_t)E * ES;
   int64_t qi, di, mi;
@@ -383,14 +415,22 @@ __global__ void __launch_bounds__(64) maxsim_generic_kernel(const MaxsimArgs a) 
     di = pair;
     mi = pair;
   }
+  const bool rag = a.rag_begin != nullptr;
+  int D = a.D;
+  int64_t drow0 = di * D;
+  if (rag) {  // document = rows [begin, end) of the token matrix; every row is a real token
+    drow0 = a.rag_begin[pair];
+    const int64_t l = a.rag_end[pair] - drow0;
+    D = l < 0 ? 0 : (l > 0x7fffffe0LL ? 0x7fffffe0 : (int)l);
+  }
   const int nblk_tot = (D + 31) >> 5;
   const int qwords = (Q + 31) >> 5;
-  int len = a.dm.len ? a.dm.len[mi] : D;
+  int len = (!rag && a.dm.len) ? a.dm.len[mi] : D;
   len = len < 0 ? 0 : (len > D ? D : len);
   const int nb = (len + 31) >> 5;
-  const float fill = len < D ? -1000.0f : neg_inf();
+  const float fill = (rag ? len == 0 : len < D) ? -1000.0f : neg_inf();
   const int qlen = a.qm.len ? a.qm.len[qi] : Q;
-  const char* dbase = (const char*)a.d + di * D * rowb;
+  const char* dbase = (const char*)a.d + drow0 * rowb;
   const char* qbase = (const char*)a.q + qi * Q * rowb;
 
   float total = 0.0f;
@@ -408,12 +448,121 @@ __global__ void __launch_bounds__(64) maxsim_generic_kernel(const MaxsimArgs a) 
       const f32x16 acc = dot_block<DT>(dbase + dr * rowb, qbase + qr * rowb, E);
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-      const uint32_t va = a.dm.bits ? (a.dm.bits[mi * nblk_tot + t] & ex) : ex;
+      const uint32_t va = (!rag && a.dm.bits) ? (a.dm.bits[mi * nblk_tot + t] & ex) : ex;
       block_max(m, acc, ex, va, fill, h);
     }
     total += finish_pair(m, qvalid, h);
   }
   if (lane == 0) a.out[pair] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the paired MaxSim (training path, train.py:503-524): one wavefront per pair.
+//   d out / d s[i, j] = g  for j = j*(i) = the FIRST arg-max over the document positions of query
+//   token i (torch.max's tie rule), 0 elsewhere; nothing flows when the maximum is the -1000
+//   sentinel of a padded position (colbert.py:69 assigns a constant there) or the query token is
+//   padding (:73).  Hence
+//     grad_q[p, i, :]   = g[p] * d[p, j*(i), :]
+//     grad_d[p, j, :]   = g[p] * sum_{i : j*(i) = j} q[p, i, :]
+// The similarities are recomputed with the same MFMA maps as the forward generic kernel (the
+// forward keeps no [B,Q,D] tensor to save); gradients are written as float32.
+// ---------------------------------------------------------------------------------------------
+struct MaxsimBwdArgs {
+  const void* q;
+  const void* d;
+  PackedMask qm, dm;
+  const float* go;
+  float* gq;
+  float* gd;
+  int64_t n_pairs;
+  int Q, D, E;
+};
+
+template <int DT>
+__device__ __forceinline__ float load_elem(const char* row, int e) {
+  if constexpr (DT == MM_F32) return ((const float*)row)[e];
+  else if constexpr (DT == MM_F16) return (float)((const _Float16*)row)[e];
+  else return __uint_as_float((uint32_t)((const uint16_t*)row)[e] << 16);
+}
+
+template <int DT>
+__global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
+  __shared__ int jstar[32];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t pair = blockIdx.x;
+  if (pair >= a.n_pairs) return;
+  const int D = a.D, Q = a.Q, E = a.E;
+  constexpr int ES = (DT == MM_F32) ? 4 : 2;
+  const int64_t rowb = (int64_t)E * ES;
+  const int nblk_tot = (D + 31) >> 5;
+  const int qwords = (Q + 31) >> 5;
+  int len = a.dm.len ? a.dm.len[pair] : D;
+  len = len < 0 ? 0 : (len > D ? D : len);
+  const int nb = (len + 31) >> 5;
+  const float fill = len < D ? -1000.0f : neg_inf();
+  const int qlen = a.qm.len ? a.qm.len[pair] : Q;
+  const char* dbase = (const char*)a.d + pair * D * rowb;
+  const char* qbase = (const char*)a.q + pair * Q * rowb;
+  const float g = a.go[pair];
+  float* gq = a.gq + pair * Q * (int64_t)E;
+  float* gd = a.gd + pair * D * (int64_t)E;
+
+  for (int n = 0; n < qwords; ++n) {
+    const int qtok = 32 * n + r;
+    const int qr = qtok < Q ? qtok : Q - 1;
+    bool qvalid = qtok < Q && qtok < qlen;
+    if (a.qm.bits) qvalid = qvalid && ((a.qm.bits[pair * qwords + n] >> r) & 1u);
+    float m[16];
+    int bt[16];  // block of the running maximum; -1 = a padded position / nothing yet
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { m[i] = fill; bt[i] = -1; }
+    for (int t = 0; t < nb; ++t) {
+      const int drow = 32 * t + r;
+      const int dr = drow < D ? drow : D - 1;
+      const f32x16 acc = dot_block<DT>(dbase + dr * rowb, qbase + qr * rowb, E);
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (a.dm.bits[pair * nblk_tot + t] & ex) : ex;
+      const uint32_t exs = ex >> (4 * h), vas = va >> (4 * h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int bit = rowof(i);
+        const bool real = (vas >> bit) & 1u;
+        const float v = real ? acc[i] : (((exs >> bit) & 1u) ? -1000.0f : fill);
+        if (v > m[i]) { m[i] = v; bt[i] = real ? t : -1; }  // strict: the first block wins ties
+      }
+    }
+    // first arg-max over this lane's 16 row classes, then over the two lane halves
+    float best = m[0];
+    int brow = bt[0] < 0 ? 0x7fffffff : 32 * bt[0] + rowof(0) + 4 * h;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+      const int row = bt[i] < 0 ? 0x7fffffff : 32 * bt[i] + rowof(i) + 4 * h;
+      if (m[i] > best || (m[i] == best && row < brow)) { best = m[i]; brow = row; }
+    }
+    const float ob = __shfl_xor(best, 32, 64);
+    const int orow = __shfl_xor(brow, 32, 64);
+    if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+    __syncthreads();
+    if (h == 0) jstar[r] = (qvalid && brow != 0x7fffffff) ? brow : -1;
+    __syncthreads();
+    const int nq_tile = Q - 32 * n < 32 ? Q - 32 * n : 32;
+    for (int qq = 0; qq < nq_tile; ++qq) {
+      const int j = jstar[qq];
+      const int qt = 32 * n + qq;
+      const char* qrow = qbase + qt * rowb;
+      if (j >= 0) {
+        const char* drow = dbase + j * rowb;
+        for (int e = lane; e < E; e += 64) {
+          gq[(int64_t)qt * E + e] = g * load_elem<DT>(drow, e);
+          gd[(int64_t)j * E + e] += g * load_elem<DT>(qrow, e);  // same lane owns element e for every qq
+        }
+      } else {
+        for (int e = lane; e < E; e += 64) gq[(int64_t)qt * E + e] = 0.0f;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,7 +594,7 @@ static void read_env() {
   if (g_stream_nbuf > 4) g_stream_nbuf = 4;
 }
 
-template <int DT, int NBUF, bool NT, int NSL>
+template <int DT, int NBUF, bool NT, int NSL, bool RAG>
 static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   MaxsimArgs a = a0;
   const int lds = NBUF * kBlkBytes;
@@ -455,31 +604,31 @@ static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL, RAG>), dim3((unsigned)waves), dim3(64), lds, stream, a);
   return check_launch("maxsim_stream_kernel");
 }
 
-template <int DT, int NSL>
+template <int DT, int NSL, bool RAG>
 static int launch_stream_nsl(const MaxsimArgs& a, hipStream_t stream) {
   const bool nt = g_stream_nt != 0;
-  if (NSL == 1) {  // the tuning knobs are only instantiated for the headline shape
+  if (NSL == 1 && !RAG) {  // the tuning knobs are only instantiated for the headline shape
     switch (g_stream_nbuf) {
-      case 3: return nt ? launch_stream<DT, 3, true, NSL>(a, stream) : launch_stream<DT, 3, false, NSL>(a, stream);
-      case 4: return nt ? launch_stream<DT, 4, true, NSL>(a, stream) : launch_stream<DT, 4, false, NSL>(a, stream);
-      default: return nt ? launch_stream<DT, 2, true, NSL>(a, stream) : launch_stream<DT, 2, false, NSL>(a, stream);
+      case 3: return nt ? launch_stream<DT, 3, true, NSL, false>(a, stream) : launch_stream<DT, 3, false, NSL, false>(a, stream);
+      case 4: return nt ? launch_stream<DT, 4, true, NSL, false>(a, stream) : launch_stream<DT, 4, false, NSL, false>(a, stream);
+      default: return nt ? launch_stream<DT, 2, true, NSL, false>(a, stream) : launch_stream<DT, 2, false, NSL, false>(a, stream);
     }
   }
-  return launch_stream<DT, 2, true, NSL>(a, stream);
+  return launch_stream<DT, 2, true, NSL, RAG>(a, stream);
 }
 
-template <int DT>
+template <int DT, bool RAG>
 static int launch_stream_cfg(const MaxsimArgs& a, hipStream_t stream) {
   switch (a.E / 128) {
-    case 1: return launch_stream_nsl<DT, 1>(a, stream);
-    case 2: return launch_stream_nsl<DT, 2>(a, stream);
-    case 3: return launch_stream_nsl<DT, 3>(a, stream);
-    case 4: return launch_stream_nsl<DT, 4>(a, stream);
-    default: return launch_stream_nsl<DT, 6>(a, stream);
+    case 1: return launch_stream_nsl<DT, 1, RAG>(a, stream);
+    case 2: return launch_stream_nsl<DT, 2, RAG>(a, stream);
+    case 3: return launch_stream_nsl<DT, 3, RAG>(a, stream);
+    case 4: return launch_stream_nsl<DT, 4, RAG>(a, stream);
+    default: return launch_stream_nsl<DT, 6, RAG>(a, stream);
   }
 }
 
@@ -525,7 +674,7 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
   const bool stream_ok = !g_force_generic && dtype != MM_F32 && Q <= 32 &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
-  if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16>(a, stream) : launch_stream_cfg<MM_F16>(a, stream);
+  if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
   return launch_generic(a, dtype, stream);
 }
 
@@ -554,4 +703,62 @@ extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q
   if (int e = resolve_mask(q_mask, q_mask_kind, Bq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, Bd, D, &ws, &left, stream, &a.dm)) return e;
   return launch_generic(a, dtype, stream);
+}
+
+extern "C" size_t mm_maxsim_ragged_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int q_mask_kind) {
+  if (pairs_per_query <= 0) pairs_per_query = 1;
+  return packed_mask_bytes(q_mask_kind, (n_pairs + pairs_per_query - 1) / pairs_per_query, Q);
+}
+
+extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int64_t* doc_begin, const int64_t* doc_end,
+                                    const void* q_mask, int q_mask_kind, float* out, int64_t n_pairs,
+                                    int64_t pairs_per_query, int Q, int E, int dtype, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
+  read_env();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (int e = validate(q, tokens, out, n_pairs, Q, 1, E, dtype)) return e;
+  if (!doc_begin || !doc_end) return set_error(MM_EINVAL, "maxsim_ragged: null document range pointer");
+  if (pairs_per_query <= 0) return set_error(MM_EINVAL, "maxsim_ragged: pairs_per_query must be >= 1");
+  if (n_pairs == 0) return MM_OK;
+  const int64_t nq = (n_pairs + pairs_per_query - 1) / pairs_per_query;
+  MaxsimArgs a{};
+  a.q = q; a.d = tokens; a.out = out; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
+  a.Q = Q; a.D = 32; a.E = E; a.rag_begin = doc_begin; a.rag_end = doc_end;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
+  const bool stream_ok = !g_force_generic && dtype != MM_F32 && Q <= 32 &&
+                         (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
+  if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, true>(a, stream) : launch_stream_cfg<MM_F16, true>(a, stream);
+  return launch_generic(a, dtype, stream);
+}
+
+extern "C" size_t mm_maxsim_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind) {
+  return packed_mask_bytes(q_mask_kind, n_pairs, Q) + packed_mask_bytes(d_mask_kind, n_pairs, D);
+}
+
+extern "C" int mm_maxsim_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
+                             int d_mask_kind, const float* grad_out, float* grad_q, float* grad_d, int64_t n_pairs,
+                             int Q, int D, int E, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!grad_out || !grad_q || !grad_d) return set_error(MM_EINVAL, "maxsim_bwd: null gradient pointer");
+  if (int e = validate(q, d, grad_q, n_pairs, Q, D, E, dtype)) return e;
+  if (n_pairs == 0) return MM_OK;
+  if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "maxsim_bwd: more than 2^31-1 pairs in one launch");
+  MaxsimBwdArgs a{};
+  a.q = q; a.d = d; a.go = grad_out; a.gq = grad_q; a.gd = grad_d; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
+  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (hipMemsetAsync(grad_d, 0, (size_t)n_pairs * D * E * sizeof(float), stream) != hipSuccess)
+    return set_error(MM_ELAUNCH, "maxsim_bwd: memset failed");
+  const dim3 grid((unsigned)n_pairs), block(64);
+  if (dtype == MM_F32)
+    hipLaunchKernelGGL(maxsim_bwd_kernel<MM_F32>, grid, block, 0, stream, a);
+  else if (dtype == MM_F16)
+    hipLaunchKernelGGL(maxsim_bwd_kernel<MM_F16>, grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL(maxsim_bwd_kernel<MM_BF16>, grid, block, 0, stream, a);
+  return check_launch("maxsim_bwd_kernel");
 }

@@ -99,6 +99,77 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
     return out
 
 
+def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor, doc_end: torch.Tensor,
+                  q_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1) -> torch.Tensor:
+    """Unpadded MaxSim over a resident token store (the ColBERT retrieval aggregate,
+    matchmaker/dense_retrieval.py:398-412 + colbert.py:100-112, in ONE launch).
+
+    q [n_queries, Q, E]; tokens [T, E] (the store: token_reps_N.npy rows); document p of the batch is
+    tokens[doc_begin[p]:doc_end[p]] (doc_infos ranges); pair p scores against query
+    p // pairs_per_query.  Returns float32 [n_pairs]."""
+    dev = _dev_check(q, tokens, doc_begin, doc_end, q_mask)
+    q = _emb(q, "q")
+    if tokens.dim() != 2 or tokens.dtype not in _DT:
+        raise NativeError(f"tokens: expected [T, E] float tensor, got {tuple(tokens.shape)} {tokens.dtype}")
+    if q.dtype != tokens.dtype:
+        raise NativeError(f"q/tokens dtype mismatch: {q.dtype} vs {tokens.dtype} (convert the query to the store's dtype)")
+    tokens = tokens if tokens.is_contiguous() else tokens.contiguous()
+    nq, Q, E = q.shape
+    if tokens.shape[1] != E:
+        raise NativeError(f"embedding dims differ: {E} vs {tokens.shape[1]}")
+    B = doc_begin.numel()
+    if doc_end.numel() != B:
+        raise NativeError("doc_begin / doc_end must have one entry per pair")
+    if pairs_per_query < 1 or nq != (B + pairs_per_query - 1) // pairs_per_query:
+        raise NativeError(f"q has {nq} rows but {B} pairs / {pairs_per_query} per query")
+    doc_begin = doc_begin.to(torch.int64).contiguous()
+    doc_end = doc_end.to(torch.int64).contiguous()
+    qm, qp, qk = _mask(q_mask, nq, Q, "q_mask")
+    L = _lib.lib()
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    if B == 0:
+        return out
+    with torch.cuda.device(dev):
+        wsb = L.mm_maxsim_ragged_workspace_bytes(B, pairs_per_query, Q, qk)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        rc = L.mm_maxsim_ragged_fwd(q.data_ptr(), tokens.data_ptr(), doc_begin.data_ptr(), doc_end.data_ptr(), qp, qk,
+                                    out.data_ptr(), B, pairs_per_query, Q, E, _DT[q.dtype],
+                                    ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+    _lib.check(rc, "mm_maxsim_ragged_fwd")
+    return out
+
+
+def maxsim_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
+               grad_out: torch.Tensor):
+    """Backward of the paired MaxSim (pair-per-row layout).  Returns float32 (grad_q [B,Q,E],
+    grad_d [B,D,E]); see mm_maxsim_bwd in include/mm_native.h."""
+    dev = _dev_check(q, d, q_mask, d_mask, grad_out)
+    q, d = _emb(q, "q"), _emb(d, "d")
+    if q.dtype != d.dtype:
+        raise NativeError(f"q/d dtype mismatch: {q.dtype} vs {d.dtype}")
+    B, Q, E = q.shape
+    B2, D, E2 = d.shape
+    if B != B2 or E != E2:
+        raise NativeError(f"maxsim_bwd needs the pair-per-row layout: q {tuple(q.shape)} vs d {tuple(d.shape)}")
+    go = grad_out.detach().reshape(-1).to(torch.float32).contiguous()
+    if go.numel() != B:
+        raise NativeError(f"grad_out has {go.numel()} elements for {B} pairs")
+    qm, qp, qk = _mask(q_mask, B, Q, "q_mask")
+    dm, dp, dk = _mask(d_mask, B, D, "d_mask")
+    L = _lib.lib()
+    gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
+    gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
+    if B:
+        with torch.cuda.device(dev):
+            wsb = L.mm_maxsim_bwd_workspace_bytes(B, Q, D, qk, dk)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+            rc = L.mm_maxsim_bwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, go.data_ptr(), gq.data_ptr(),
+                                 gd.data_ptr(), B, Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None,
+                                 wsb, _stream(dev))
+        _lib.check(rc, "mm_maxsim_bwd")
+    return gq, gd
+
+
 def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Tensor,
                    d_mask: Optional[torch.Tensor], bug_compatible: bool = False) -> torch.Tensor:
     """All-pairs MaxSim [Bq, Bd] (matchmaker/models/colbert.py:154-162).  bug_compatible=True masks

@@ -104,11 +104,12 @@ def _make_colbert():
     return m
 
 
-def colbert_forward(q, d, q_mask, d_mask):
+def colbert_forward(q, d, q_mask, d_mask, grad=False):
     """Real ColBERT.forward (colbert.py:54-86) with identity encoder/compressor.
-    q [B,Q,E], d [B,D,E] float32; masks int64 {0,1}.  Returns [B] float32."""
+    q [B,Q,E], d [B,D,E] float32; masks int64 {0,1}.  Returns [B] float32.
+    grad=True keeps the autograd graph (gradients of the real scoring block w.r.t. q / d)."""
     m = _make_colbert()
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         return m.forward({"vecs": q, "attention_mask": q_mask},
                          {"vecs": d, "attention_mask": d_mask}, use_fp16=False)
 

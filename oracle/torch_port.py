@@ -1,0 +1,58 @@
+"""TEST INFRASTRUCTURE — torch (CPU) port of the reference's scoring blocks, op by op.
+
+The reference IS a sequence of torch ops; this file repeats exactly those ops (same order, same
+in-place masked assignments) on CPU tensors so that
+  * tests can differentiate through them with autograd (the training path's gradients), and
+  * bench.py's `cpu_baseline` leg times what the reference's CPU path would execute on the host
+    cores (kind "port": /root/reference does not exist on the GPU box, so the real classes cannot be
+    imported there; tests/test_oracle_golden.py pins these functions on the real reference's outputs).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
+"""
+import torch
+
+
+def maxsim_forward(query_vecs, document_vecs, query_mask, document_mask):
+    """ColBERT.forward scoring block — matchmaker/models/colbert.py:68-75."""
+    score_per_term = torch.bmm(query_vecs, document_vecs.transpose(2, 1))                       # :68
+    score_per_term[~(document_mask.bool()).unsqueeze(1).expand(-1, score_per_term.shape[1], -1)] = -1000  # :69
+    score = score_per_term.max(-1).values                                                       # :71
+    score[~(query_mask.bool())] = 0                                                             # :73
+    return score.sum(-1)                                                                        # :75
+
+
+def maxsim_aggregation(query_vecs, document_vecs):
+    """ColBERT.forward_aggregation — matchmaker/models/colbert.py:100-112."""
+    score = torch.bmm(query_vecs, document_vecs.transpose(2, 1))                                # :101
+    score = score.max(-1).values                                                                # :104
+    return score.sum(-1)                                                                        # :108
+
+
+def maxsim_forward_backward(q, d, query_mask, document_mask, grad_out):
+    """Autograd through maxsim_forward: what loss.backward() (train.py:503-524) sends into the
+    encoder outputs.  Returns (score, grad_q, grad_d) as float32 CPU tensors."""
+    q = q.detach().float().clone().requires_grad_(True)
+    d = d.detach().float().clone().requires_grad_(True)
+    out = maxsim_forward(q, d, query_mask, document_mask)
+    out.backward(grad_out.float())
+    return out.detach(), q.grad, d.grad
+
+
+def cosine_matrix(a, b):
+    """allennlp 2.5.1 CosineMatrixAttention.forward (published source; call sites ecai20_tk.py:105,
+    sigir20_tkl.py:184): x / (x.norm(p=2, dim=-1, keepdim=True) + tiny), then bmm.  tiny = 1e-13 (fp32)."""
+    a_norm = a / (a.norm(p=2, dim=-1, keepdim=True) + 1e-13)
+    b_norm = b / (b.norm(p=2, dim=-1, keepdim=True) + 1e-13)
+    return torch.bmm(a_norm, b_norm.transpose(-1, -2))
+
+
+def tk_kernel_pool(query_embeddings, document_embeddings, query_mask, document_mask, mu, sigma, alpha, weight):
+    """ECAI20_TK.forward kernel-pooling block — matchmaker/models/published/ecai20_tk.py:105-124.
+    mu, sigma [1,1,1,K]; alpha = kernel_alpha_scaler [1,1,K]; weight = kernel_bin_weights.weight [1,K]."""
+    cosine_matrix_ = cosine_matrix(query_embeddings, document_embeddings).unsqueeze(-1)         # :105-110
+    raw_kernel_results = torch.exp(- torch.pow(cosine_matrix_ - mu, 2) / (2 * torch.pow(sigma, 2)))   # :112
+    kernel_results_masked = raw_kernel_results * document_mask.unsqueeze(1).unsqueeze(-1)       # :114
+    per_kernel_query = torch.sum(kernel_results_masked, 2)                                      # :120
+    log_per_kernel_query = torch.log(torch.clamp(per_kernel_query * alpha, min=1e-10))          # :121
+    log_per_kernel_query_masked = log_per_kernel_query * query_mask.unsqueeze(-1)               # :122
+    per_kernel = torch.sum(log_per_kernel_query_masked, 1)                                      # :123
+    return torch.nn.functional.linear(per_kernel, weight).squeeze(1)                            # :124

@@ -165,3 +165,33 @@ def test_split_bf16_numerics():
     assert es < 2.5e-6, es       # 2^-18 residual per operand; worst case = coherent near-duplicates
     # exact power-of-two scale invariance (what tests/test_kernel_pool_gpu.py asserts on the device)
     assert np.array_equal(O.cosine_matrix_split_bf16(q * 4, d * 0.5), O.cosine_matrix_split_bf16(q, d))
+
+
+def test_token_store_reads_the_reference_layout(tmp_path):
+    """TokenStore.load follows dense_retrieval.py:292-303: raw memmap blocks + doc_infos.npz; global row
+    ranges must address exactly the rows the reference's `storage[file][start:end]` (:404) returns."""
+    from matchmaker_amd.token_store import TokenStore, write_reference_store
+    rng = np.random.default_rng(5)
+    E, blk = 16, 64
+    docs, ids = [], []
+    for i in range(23):
+        n = int(rng.integers(1, 20))
+        x = rng.standard_normal((n + 2, E)).astype(np.float16)
+        x[-2:] = 0                                   # padding rows, stripped by the writer (:244)
+        docs.append(x)
+        ids.append(f"doc{i}")
+    write_reference_store(str(tmp_path), docs, ids, blk, "float16")
+    st = TokenStore.load(str(tmp_path), E, "float16", blk, "cpu")
+    # the reference's loader
+    dfs = np.load(os.path.join(str(tmp_path), "doc_infos.npz"), allow_pickle=True)
+    doc_infos = dfs.get("doc_infos")[()]
+    filled = dfs.get("storage_filled_to_index")[()]
+    storage = [np.memmap(os.path.join(str(tmp_path), f"token_reps_{f}.npy"), dtype=np.float16, mode="r",
+                         shape=(blk, E))[: filled[f]] for f in range(len(filled))]
+    assert len(storage) > 1                         # the synthetic store spans several files
+    b, e = st.ranges(ids)
+    for i, sid in enumerate(ids):
+        f, a, z = doc_infos[sid]
+        ref = np.asarray(storage[f][a:z])
+        got = st.tokens[int(b[i]): int(e[i])].numpy()
+        assert np.array_equal(ref, got) and np.array_equal(ref, docs[i][:-2])
