@@ -12,8 +12,8 @@ scaling, no data-path collective); with N > 1 one RCCL all-gather of the fp32 sc
 part of the timed region (the ranking merge of SURVEY.md §8e).
 
 Prints ONE JSON line (rank 0).  `roofline`: algorithmic bytes per launch / average
-kernel time measured with HIP events on the launch stream; `cpu_baseline`: the numpy oracle port
-timed on this host's cores on a bounded sample of the same workload.
+kernel time measured with HIP events on the launch stream; `cpu_baseline`: the torch CPU port of the
+reference's ops (oracle/torch_port.py) timed on this host's cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -36,32 +36,49 @@ def algorithmic_bytes(n_queries: int, cands: int) -> int:
 
 
 def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
-    """numpy oracle port (oracle/np_oracle.maxsim_paired, restating colbert.py:68-75) on a bounded
-    sample: whole queries (1000 pairs each) until ~budget_s seconds of CPU work."""
-    import numpy as np
-    from oracle import np_oracle as O
+    """The reference's CPU path for this block = the torch ops of colbert.py:68-75, repeated op by op
+    in oracle/torch_port.py (pinned on the real reference's golden outputs); /root/reference itself
+    does not exist on the GPU box, hence kind "port".  Reference layout: fp32, query replicated per
+    pair, int64 HF masks, one candidate list (1000 pairs) per forward call.  Bounded sample: whole
+    queries until ~budget_s seconds; a short single-thread leg is reported too because the
+    reference's scripts export OMP_NUM_THREADS=1 (train.py:12)."""
+    import torch
+    from oracle import torch_port as TP
     from matchmaker_amd import synth
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    qn = q_cpu.float().numpy()
-    t_total, pairs, i = 0.0, 0, 0
+    qn = q_cpu.float()
     nq = qn.shape[0]
-    # one warm-up query
+
     def run(i):
-        dn = d_cpu[i * cands:(i + 1) * cands].float().numpy()
-        dm = synth.len_to_mask(d_len[i * cands:(i + 1) * cands], D).numpy()
-        qm = np.repeat(synth.len_to_mask(q_len[i:i + 1], Q).numpy(), cands, 0)
+        dn = d_cpu[i * cands:(i + 1) * cands].float()
+        dm = synth.len_to_mask(d_len[i * cands:(i + 1) * cands], D)
+        qr = qn[i:i + 1].expand(cands, -1, -1).contiguous()
+        qm = synth.len_to_mask(q_len[i:i + 1], Q).expand(cands, -1).contiguous()
         t0 = time.perf_counter()
-        O.maxsim_paired(np.repeat(qn[i:i + 1], cands, 0), dn, qm, dm)
+        with torch.no_grad():
+            TP.maxsim_forward(qr, dn, qm, dm)
         return time.perf_counter() - t0
-    run(0)
-    while t_total < budget_s:
-        t_total += run(i % nq)
-        pairs += cands
-        i += 1
-    return {"value": pairs / t_total, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{i} passes over whole queries ({nq} distinct) x {cands} candidates = {pairs} pairs of the "
-                      f"bench workload, fp32 numpy restatement of colbert.py:68-75 (oracle/np_oracle.py), "
-                      f"{t_total:.1f} s of CPU work, BLAS threads = cores"}
+
+    def leg(budget):
+        run(0)
+        t_total, pairs, i = 0.0, 0, 0
+        while t_total < budget:
+            t_total += run(i % nq)
+            pairs += cands
+            i += 1
+        return pairs / t_total, i, pairs, t_total
+
+    threads = torch.get_num_threads()
+    rate, n, pairs, t_total = leg(budget_s)
+    torch.set_num_threads(1)
+    rate1, n1, pairs1, t1 = leg(min(4.0, budget_s / 3))
+    torch.set_num_threads(threads)
+    return {"value": rate, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "single_thread_value": rate1,
+            "sample": f"{n} forward calls over whole queries ({nq} distinct) x {cands} candidates = {pairs} pairs of the "
+                      f"bench workload in {t_total:.1f} s with {threads} torch threads (host has "
+                      f"{os.cpu_count()} logical CPUs); fp32 torch CPU port of colbert.py:68-75 "
+                      f"(oracle/torch_port.py: bmm, masked assign, max, sum); single-thread leg "
+                      f"(OMP_NUM_THREADS=1 as in train.py:12): {pairs1} pairs in {t1:.1f} s"}
 
 
 def measured_traffic(nq, cands, lengths):

@@ -42,13 +42,26 @@ __global__ void __launch_bounds__(256) tkl_slot_map_kernel(const int32_t* __rest
   }
 }
 
+// sat_emb_reduce1(q_ctx) (:224): one wavefront per (document, query token) -> emb[b][i]
+__global__ void __launch_bounds__(256) tkl_emb_kernel(const float* __restrict__ q_ctx, const float* __restrict__ prm,
+                                                      float* __restrict__ emb, int64_t BQ, int E) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= BQ) return;
+  const float* qr = q_ctx + row * E;
+  float s = 0.0f;
+  for (int e = lane; e < E; e += 64) s += qr[e] * prm[TklParams::emb() + e];
+  s = wave_sum(s);
+  if (lane == 0) emb[row] = s;
+}
+
 // One workgroup = kWT consecutive windows of one document.
 template <int SAT>
 __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
-                                                         const float* __restrict__ q_ctx,
+                                                         const float* __restrict__ emb_g,
                                                          const float* __restrict__ q_mask,
                                                          const float* __restrict__ prm, float* __restrict__ win,
-                                                         int C, int Q, int E, int W) {
+                                                         int C, int Q, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y;
   const int w0 = blockIdx.x * kWT;
@@ -60,28 +73,42 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
   float* red = emb + ((Q + 3) & ~3);                  // [kWT][Q] per-(window, query token) dense-weighted value
 
   // ---- stage the pair-sum rows (zeros for dropped chunks) --------------------------------------
+  // Two dependent global loads per element (slot -> packed chunk, then the row): all lookups of a
+  // batch of kStage elements are issued before the first row load, and all row loads before the
+  // first LDS store, so a thread pays ~2 memory latencies per batch instead of 2 per element
+  // (the kernel was 67 % s_waitcnt: profiles/r01_tkl_pmc.json).
   const int row4 = rowf / 4;
-  for (int idx = tid; idx < nu * row4; idx += 256) {
-    const int j = idx / row4, v = idx - j * row4;
-    const int ug = w0 + j;
-    const int c = ug / kU, uu = ug - c * kU;
-    f32x4 val = {0, 0, 0, 0};
-    if (c < C) {
-      const int p = slot2p[(int64_t)b * C + c];
-      if (p >= 0) val = *(const f32x4*)(ps + ((int64_t)p * kU + uu) * rowf + v * 4);
+  const int total4 = nu * row4;
+  constexpr int kStage = 10;
+  for (int base = tid; base < total4; base += 256 * kStage) {
+    int pidx[kStage];
+    int off[kStage];
+#pragma unroll
+    for (int s = 0; s < kStage; ++s) {
+      const int idx = base + 256 * s;
+      pidx[s] = -1;
+      off[s] = 0;
+      if (idx < total4) {
+        const int j = idx / row4, v = idx - j * row4;
+        const int ug = w0 + j;
+        const int c = ug / kU, uu = ug - c * kU;
+        off[s] = uu * rowf + v * 4;
+        if (c < C) pidx[s] = slot2p[(int64_t)b * C + c];
+      }
     }
-    *(f32x4*)(tile + (size_t)j * rowf + v * 4) = val;
-  }
-  if (SAT == MM_TKL_SAT_EMBEDDING) {
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int i = wave; i < Q; i += 4) {
-      const float* qr = q_ctx + ((int64_t)b * Q + i) * E;
-      float s = 0.0f;
-      for (int e = lane; e < E; e += 64) s += qr[e] * prm[TklParams::emb() + e];
-      s = wave_sum(s);
-      if (lane == 0) emb[i] = s;
+    f32x4 val[kStage];
+#pragma unroll
+    for (int s = 0; s < kStage; ++s) {
+      val[s] = f32x4{0, 0, 0, 0};
+      if (pidx[s] >= 0) val[s] = *(const f32x4*)(ps + (int64_t)pidx[s] * kU * rowf + off[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < kStage; ++s) {
+      const int idx = base + 256 * s;
+      if (idx < total4) *(f32x4*)(tile + (size_t)idx * 4) = val[s];
     }
   }
+  if (SAT == MM_TKL_SAT_EMBEDDING && tid < Q) emb[tid] = emb_g[(int64_t)b * Q + tid];
   __syncthreads();
 
   const float* sp = prm + TklParams::sat();
@@ -199,7 +226,7 @@ extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int
   if (B <= 0 || P < 0 || C <= 0 || Q <= 0 || K != kK) return 0;
   const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
   return align256((size_t)B * C * 4) + align256((size_t)P * kU * Q * kKC * 4) +
-         packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4);
+         packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4);
 }
 
 extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
@@ -241,9 +268,13 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
                                   params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
       return e;
   }
-  if (!win) {
-    ws = (char*)workspace + align256((size_t)B * C * 4) + ps_bytes + packed_mask_bytes(MM_MASK_F32, P, 40);
-    win = (float*)ws;
+  char* tail = (char*)workspace + align256((size_t)B * C * 4) + ps_bytes + packed_mask_bytes(MM_MASK_F32, P, 40);
+  if (!win) win = (float*)tail;
+  float* emb = (float*)(tail + align256((size_t)B * W * 4));
+  if (saturation == MM_TKL_SAT_EMBEDDING) {
+    hipLaunchKernelGGL(tkl_emb_kernel, dim3((unsigned)((B * Q + 3) / 4)), dim3(256), 0, stream, (const float*)q_ctx, params,
+                       emb, B * (int64_t)Q, E);
+    if (int e = check_launch("tkl_emb_kernel")) return e;
   }
   const int nu = kWT + kWinPairs - 1;
   const size_t lds2 = ((size_t)nu * Q * kKC + ((Q + 3) & ~3) + (size_t)kWT * Q) * 4;
@@ -253,12 +284,12 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     if (lds2 > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(256), lds2, stream, ps, slot2p,
-                       (const float*)q_ctx, q_mask, params, win, C, Q, E, W);
+                       emb, q_mask, params, win, C, Q, W);
   } else {
     if (lds2 > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(256), lds2, stream, ps, slot2p,
-                       (const float*)q_ctx, q_mask, params, win, C, Q, E, W);
+                       emb, q_mask, params, win, C, Q, W);
   }
   if (int e = check_launch("tkl_window_kernel")) return e;
   const int Wp = W < 3 ? 3 : W;
