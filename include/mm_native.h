@@ -186,6 +186,33 @@ int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask,
                int64_t B, int64_t P, int C, int Q, int E, int K, int saturation,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Brute-force inner-product top-k over one GPU's shard of the collection (dense retrieval).
+ *
+ * Replaces: FaissIdIndexer / FaissBaseIndexer.search   matchmaker/retrieval/faiss_indices.py:22-36, 49-74
+ *           (IndexIDMap(IndexFlatIP) sharded over the GPUs, useFloat16; faiss-gpu==1.7.0 is a
+ *           third-party dependency, conda-requirements.txt:1), call site dense_retrieval.py:391;
+ *           score = BERT_DOT dot product               matchmaker/models/bert_dot.py:62
+ *
+ *   queries [nq, E], corpus [n_docs, E]  float16 / bfloat16, E in {128, 256, 384, 512, 768}
+ *   out_scores [nq, k] float32 descending; out_idx [nq, k] int64 = row of `corpus` (-1 and -inf pad
+ *   a shard with fewer than k documents, as faiss does); ties: lower row first.
+ *   status [nq] int32: 0 = exact top-k delivered; 1 / 2 = the sampled threshold of that query let
+ *   too few / too many candidates through — call again for those queries with m_scale x4 / x0.25
+ *   (matchmaker_amd/retrieval.py does).  m_scale = 1 on the first call.
+ *   workspace: mm_dot_topk_workspace_bytes(n_docs, nq, k) bytes.  k <= 4096. */
+size_t mm_dot_topk_workspace_bytes(int64_t n_docs, int nq, int k);
+
+int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t n_docs, int nq, int E, int dtype, int k,
+                    float m_scale, float* out_scores, int64_t* out_idx, int32_t* status,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Final merge of a sharded index: in [nq, n_in] (score, id) rows (e.g. the all-gathered per-shard
+ * top-k lists, ids < 0 = padding) -> the k best per row, score descending, input order on ties.
+ * n_in <= 16384. */
+int mm_topk_merge(const float* in_scores, const int64_t* in_ids, int nq, int n_in, int k,
+                  float* out_scores, int64_t* out_ids, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,479 @@
+// Brute-force inner-product top-k (dense retrieval) for MI355X (gfx950 / CDNA4).
+//
+// Replaces, for one GPU's shard of the collection, the faiss flat inner-product index the reference
+// searches (matchmaker/retrieval/faiss_indices.py:22-36 `search`, :49-74 FaissIdIndexer =
+// IndexIDMap(IndexFlatIP), sharded over all GPUs with useFloat16; called from
+// matchmaker/dense_retrieval.py:391 `indexer.search(output, top_n)`); the score is BERT_DOT's dot
+// product (matchmaker/models/bert_dot.py:62).  faiss itself (faiss-gpu==1.7.0,
+// conda-requirements.txt:1) is a third-party dependency absent from the reference tree: the
+// semantics restated here are those of IndexFlatIP.search — for every query the k largest inner
+// products, in descending order, with their ids.
+//
+// Three phases, all enqueued on the caller's stream (no host synchronisation inside):
+//   1. dot_stream_kernel<SAMPLE>: scores of every query against a strided SAMPLE of the shard
+//      (S = 16384 documents), written densely; sort_rows_kernel sorts each query's sample and takes
+//      the m-th largest as the query's threshold tau (m chosen so that ~2k documents of the shard
+//      are expected above it).
+//   2. dot_stream_kernel<FILTER>: the full Q x C^T product on the bf16/fp16 matrix pipe; the
+//      epilogue keeps only scores >= tau[q] (one atomic slot claim per survivor) in a per-query
+//      candidate list of `cap` entries.  Nothing of the [nq, N] score matrix ever reaches HBM.
+//   3. sort_rows_kernel: exact top-k of each candidate list (score descending, document index
+//      ascending on ties), status[q] = 0 | 1 (fewer than k survivors: tau too high) | 2 (list
+//      overflowed: tau too low).  The host re-runs queries whose status is not 0 with another m,
+//      so the result is always the exact top-k.
+//
+// dot_stream_kernel: MaxSim's streaming structure turned into a GEMM.  A workgroup of 4 wavefronts
+// (one per SIMD, 512 registers each) keeps 4 x 32 x NQT queries as MFMA B fragments in registers for
+// its whole life and streams its slice of the collection through an LDS ring shared by the four
+// wavefronts (LDS-DMA, 32 documents x E per block, source-side bank swizzle as in maxsim.hip).
+// Every block is read once from LDS by each wavefront and multiplied against that wavefront's own
+// queries: documents on the MFMA M axis, queries on N, so one lane owns one query per tile and the
+// threshold test is a lane-local compare of its 16 accumulator registers.
+// Work map: the shard's blocks are split 8 ways by XCD (blockIdx % 8); inside an XCD the
+// workgroups are (query group g, sub-slice t): the CUs of one XCD sweep the same documents for
+// different query groups at about the same time, so the collection is fetched from HBM once per
+// XCD sweep and re-read from that XCD's L2.
+#include "mm_internal.h"
+
+namespace mm {
+
+constexpr int kDotSample = 16384;  // sample size (documents) of phase 1 when the shard is larger
+constexpr int kSortMax = 16384;    // rows of sort_rows_kernel are padded to a power of two <= this
+
+enum { DOT_SAMPLE = 0, DOT_FILTER = 1 };
+
+struct DotArgs {
+  const void* q;      // [nq, E]
+  const void* c;      // [N, E] the shard
+  int64_t ndocs;      // documents visited by this launch: doc(i) = i * stride, i < ndocs
+  int64_t stride;     // 1 = every document, > 1 = strided sample
+  int nq, E;
+  int G, T;           // query groups per launch, sub-slices per XCD  (grid = 8 * G * T)
+  int q_base;         // first query of group 0
+  // SAMPLE
+  float* all_out;     // [nq, ld_all] scores of the visited documents
+  int64_t ld_all;
+  // FILTER
+  const float* tau;   // [nq]
+  int32_t* count;     // [nq]
+  float* cand_score;  // [nq, cap]
+  int32_t* cand_idx;  // [nq, cap] document index inside the shard
+  int cap;
+};
+
+template <int DT>
+struct DotMfma;
+template <>
+struct DotMfma<MM_BF16> {
+  static __device__ __forceinline__ f32x16 run(short8 a, short8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct DotMfma<MM_F16> {
+  static __device__ __forceinline__ f32x16 run(short8 a, short8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ constexpr int drowof(int i) { return (i & 3) + 8 * (i >> 2); }
+
+// 8 x 16 B of one query row slice (256 B): chunks (2kk + h); own vmcnt(0) (prologue only)
+__device__ __forceinline__ void dot_load_q(const char* base, short8 (&qf)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off\n\t"
+      "global_load_dwordx4 %1, %8, off offset:32\n\t"
+      "global_load_dwordx4 %2, %8, off offset:64\n\t"
+      "global_load_dwordx4 %3, %8, off offset:96\n\t"
+      "global_load_dwordx4 %4, %8, off offset:128\n\t"
+      "global_load_dwordx4 %5, %8, off offset:160\n\t"
+      "global_load_dwordx4 %6, %8, off offset:192\n\t"
+      "global_load_dwordx4 %7, %8, off offset:224\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]), "=&v"(qf[4]), "=&v"(qf[5]), "=&v"(qf[6]),
+        "=&v"(qf[7])
+      : "v"(base)
+      : "memory");
+}
+
+// One LDS-DMA instruction: 4 document rows x 256 B (one 128-dim slice) -> 1 KiB of LDS at m0.
+__device__ __forceinline__ void dot_issue(const char* gbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(gbase), "s"(lds_dst)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void dot_wait() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DT, int NSL, int NQT, int MODE>
+__global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
+  constexpr int NBUF = 3;
+  constexpr int RB = NSL * 256;        // bytes per document row
+  constexpr int BLK = 32 * RB;         // bytes per 32-document block
+  constexpr int PER = 2 * NSL;         // LDS-DMA instructions per wavefront per block
+  static_assert(PER * (NBUF - 2) <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: feeds SGPR operands (m0)
+  const int r = lane & 31, h = lane >> 5;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- work map ---------------------------------------------------------------------------------
+  const int xcd = blockIdx.x & 7;
+  const int j = blockIdx.x >> 3;
+  const int g = j % a.G, t = j / a.G;
+  const int64_t nblk = (a.ndocs + 31) >> 5;
+  const int64_t x_lo = nblk * xcd / 8, x_hi = nblk * (xcd + 1) / 8;
+  const int64_t b_lo = x_lo + (x_hi - x_lo) * t / a.T, b_hi = x_lo + (x_hi - x_lo) * (t + 1) / a.T;
+  if (b_lo >= b_hi) return;
+  const int q0 = a.q_base + g * (128 * NQT) + w * (32 * NQT);
+
+  // ---- this wavefront's queries as MFMA B fragments ----------------------------------------------
+  short8 qf[NQT][NSL][8];
+  int qid[NQT];
+#pragma unroll
+  for (int n = 0; n < NQT; ++n) {
+    const int qq = q0 + 32 * n + r;
+    qid[n] = qq < a.nq ? qq : -1;
+    const char* qrow = (const char*)a.q + (int64_t)(qq < a.nq ? qq : a.nq - 1) * RB + h * 16;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) dot_load_q(qrow + sl * 256, qf[n][sl]);
+  }
+  float tau[NQT];
+#pragma unroll
+  for (int n = 0; n < NQT; ++n) tau[n] = (MODE == DOT_FILTER && qid[n] >= 0) ? a.tau[qid[n]] : __builtin_huge_valf();
+
+  // ---- LDS-DMA: this wavefront moves rows 4k..4k+3 (k = w, w + 4) of every slice of a block --------
+  const int64_t rowstep = a.stride * RB;  // bytes between consecutive visited documents
+  int lrow[2];
+  uint32_t lslot[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = w + 4 * u;
+    lrow[u] = 4 * k + (lane >> 4);
+    lslot[u] = (uint32_t)(((lane & 15) ^ (lrow[u] & 15)) * 16);  // source-side swizzle (see maxsim.hip)
+  }
+  auto issue = [&](int64_t blk, int slot) {
+    const int64_t left = a.ndocs - blk * 32;  // documents of this block that exist (>= 1)
+    const char* gb = (const char*)a.c + blk * 32 * rowstep;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int row = lrow[u];
+      if (left < 32 && row >= left) row = (int)left - 1;  // never read past the shard
+      const uint32_t voff = (uint32_t)(row * rowstep) + lslot[u];
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl)
+        dot_issue(gb + sl * 256, voff, lds0 + (uint32_t)(slot * BLK + sl * 8192 + (w + 4 * u) * 1024));
+    }
+  };
+  // A-fragment read offsets inside a slice: chunk (2kk + h) of row r at slot chunk ^ (r & 15)
+  uint32_t lo[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
+
+  int slot_i = 0;  // ring slot of block `b`
+  if (b_lo < b_hi) issue(b_lo, 0);
+  if (b_lo + 1 < b_hi) issue(b_lo + 1, 1);
+
+  for (int64_t b = b_lo; b < b_hi; ++b) {
+    // this wavefront's part of block b has landed once at most the younger block's PER loads pend
+    if (b + 1 < b_hi) dot_wait<PER>(); else dot_wait<0>();
+    __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
+    if (b + 2 < b_hi) issue(b + 2, slot_i == 0 ? 2 : slot_i - 1);  // into the slot block b - 1 used
+
+    f32x16 acc[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
+    const char* buf = smem + slot_i * BLK;
+    // A fragments are fetched three steps ahead of the MFMAs that use them (one wavefront per SIMD:
+    // nothing else hides the ~100-cycle LDS latency); the group barriers pin the order
+    // {1 LDS read, NQT MFMAs} so the compiler does not fold the reads back next to their uses
+    constexpr int STEPS = NSL * 8, AHEAD = 3;
+    short8 av[AHEAD + 1];
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) av[s] = *(const short8*)(buf + (s >> 3) * 8192 + lo[s & 7]);
+    __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);  // the first AHEAD reads go out together
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s + AHEAD < STEPS) av[(s + AHEAD) % (AHEAD + 1)] = *(const short8*)(buf + ((s + AHEAD) >> 3) * 8192 + lo[(s + AHEAD) & 7]);
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) acc[n] = DotMfma<DT>::run(av[s % (AHEAD + 1)], qf[n][s >> 3][s & 7], acc[n]);
+      __builtin_amdgcn_sched_group_barrier(0x008, NQT, 0);  // NQT MFMAs of step s
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
+    }
+    slot_i = slot_i == NBUF - 1 ? 0 : slot_i + 1;
+
+    // ---- epilogue: acc[n][i] = <document b*32 + drowof(i) + 4h, query qid[n]> ----------------------
+    const int64_t d0 = b * 32 + 4 * h;
+    if (MODE == DOT_SAMPLE) {
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) {
+        if (qid[n] < 0) continue;
+        float* dst = a.all_out + (int64_t)qid[n] * a.ld_all + d0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)  // rows 8*g4 .. 8*g4+3 (+4h) are consecutive documents
+          if (d0 + 8 * g4 + 3 < a.ndocs)
+            *(f32x4*)(dst + 8 * g4) = f32x4{acc[n][4 * g4], acc[n][4 * g4 + 1], acc[n][4 * g4 + 2], acc[n][4 * g4 + 3]};
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (d0 + 8 * g4 + e < a.ndocs) dst[8 * g4 + e] = acc[n][4 * g4 + e];
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) any = any || (acc[n][i] >= tau[n]);
+        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;  // the common case: nobody passes
+        if (!any) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t doc = d0 + drowof(i);
+          if (acc[n][i] >= tau[n] && doc < a.ndocs) {
+            const int slot = atomicAdd(a.count + qid[n], 1);
+            if (slot < a.cap) {
+              a.cand_score[(int64_t)qid[n] * a.cap + slot] = acc[n][i];
+              a.cand_idx[(int64_t)qid[n] * a.cap + slot] = (int32_t)(doc * a.stride);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row sort: one workgroup per row; (score descending, index ascending) bitonic network in LDS.
+//   SAMPLE rows: keys only, writes tau[row] = m-th largest.
+//   CANDIDATE rows: n = min(count[row], cap) valid entries; writes the first k as the result.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool before(float ka, int va, float kb, int vb) {  // a sorts before b
+  return ka > kb || (ka == kb && va < vb);
+}
+
+template <bool HAS_VAL>
+__device__ __forceinline__ void bitonic_desc(float* key, int* val, int n2, int tid, int nthreads) {
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      __syncthreads();
+      for (int idx = tid; idx < (n2 >> 1); idx += nthreads) {
+        const int lo = 2 * idx - (idx & (strd - 1));  // element with bit `strd` clear
+        const int hi = lo + strd;
+        const bool desc = (lo & size) == 0;            // direction of this sub-sequence
+        const float ka = key[lo], kb = key[hi];
+        const int va = HAS_VAL ? val[lo] : 0, vb = HAS_VAL ? val[hi] : 0;
+        const bool a_first = before(ka, va, kb, vb);
+        if (a_first != desc) {
+          key[lo] = kb; key[hi] = ka;
+          if (HAS_VAL) { val[lo] = vb; val[hi] = va; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restrict__ all, int64_t ld, int n, int n2, int m,
+                                                          float* __restrict__ tau) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* key = (float*)smem;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < n2; i += 1024) key[i] = i < n ? all[(int64_t)row * ld + i] : -__builtin_huge_valf();
+  bitonic_desc<false>(key, nullptr, n2, tid, 1024);
+  if (tid == 0) tau[row] = key[m - 1 < n ? m - 1 : n - 1];
+}
+
+__global__ void __launch_bounds__(1024) topk_rows_kernel(const float* __restrict__ cand_score,
+                                                         const int32_t* __restrict__ cand_idx,
+                                                         const int32_t* __restrict__ count, int cap, int n2, int k,
+                                                         int64_t n_total, float* __restrict__ out_score,
+                                                         int64_t* __restrict__ out_idx, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* key = (float*)smem;
+  int* val = (int*)(key + n2);
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int cnt = count[row];
+  const int n = cnt < cap ? cnt : cap;
+  for (int i = tid; i < n2; i += 1024) {
+    key[i] = i < n ? cand_score[(int64_t)row * cap + i] : -__builtin_huge_valf();
+    val[i] = i < n ? cand_idx[(int64_t)row * cap + i] : 0x7fffffff;
+  }
+  bitonic_desc<true>(key, val, n2, tid, 1024);
+  const int64_t want = k < n_total ? k : n_total;  // a shard smaller than k returns everything it has
+  for (int i = tid; i < k; i += 1024) {
+    const bool ok = i < n && i < want;
+    out_score[(int64_t)row * k + i] = ok ? key[i] : -__builtin_huge_valf();
+    out_idx[(int64_t)row * k + i] = ok ? (int64_t)val[i] : -1;  // faiss pads missing results with -1
+  }
+  if (tid == 0) status[row] = cnt > cap ? 2 : (cnt < want ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(256) fill_tau_kernel(float* tau, int n, float v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tau[i] = v;
+}
+
+static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+static int pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <int DT, int NSL, int NQT, int MODE>
+static int launch_dot(const DotArgs& a0, int nq_launch, hipStream_t stream) {
+  DotArgs a = a0;
+  constexpr int QPW = 128 * NQT;  // queries per workgroup
+  const int lds = 3 * 32 * NSL * 256;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)dot_stream_kernel<DT, NSL, NQT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (31.0 * (double)a.stride * (NSL * 256) >= 4294967296.0)
+    return set_error(MM_EUNSUPPORTED, "dot_topk: sample stride too large for 32-bit row offsets");
+  for (int qb = 0; qb < nq_launch; qb += 32 * QPW) {  // at most 32 query groups (one per CU of an XCD) per launch
+    const int nq_here = nq_launch - qb < 32 * QPW ? nq_launch - qb : 32 * QPW;
+    a.G = (nq_here + QPW - 1) / QPW;
+    a.T = 32 / a.G > 0 ? 32 / a.G : 1;
+    const int64_t nblk = (a.ndocs + 31) >> 5;
+    if (a.T > (nblk + 7) / 8) a.T = (int)((nblk + 7) / 8) > 0 ? (int)((nblk + 7) / 8) : 1;
+    a.q_base = a0.q_base + qb;
+    hipLaunchKernelGGL((dot_stream_kernel<DT, NSL, NQT, MODE>), dim3(8 * a.G * a.T), dim3(256), lds, stream, a);
+    if (int e = check_launch("dot_stream_kernel")) return e;
+  }
+  return MM_OK;
+}
+
+template <int DT, int MODE>
+static int launch_dot_e(const DotArgs& a, int nq_launch, hipStream_t stream) {
+  // NQT = 2 (64 queries per wavefront: every LDS read feeds two MFMAs) once there are enough queries
+  const bool two = nq_launch > 128;
+  switch (a.E / 128) {
+    case 1: return two ? launch_dot<DT, 1, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 1, 1, MODE>(a, nq_launch, stream);
+    case 2: return two ? launch_dot<DT, 2, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 2, 1, MODE>(a, nq_launch, stream);
+    case 3: return two ? launch_dot<DT, 3, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 3, 1, MODE>(a, nq_launch, stream);
+    case 4: return two ? launch_dot<DT, 4, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 4, 1, MODE>(a, nq_launch, stream);
+    case 6: return two ? launch_dot<DT, 6, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 6, 1, MODE>(a, nq_launch, stream);
+    default: return set_error(MM_EUNSUPPORTED, "dot_topk: E=%d (supported: 128, 256, 384, 512, 768; pad the vectors)", a.E);
+  }
+}
+
+}  // namespace mm
+
+using namespace mm;
+
+static int dot_cap(int k) { int c = pow2_ge(4 * k); return c < 1024 ? 1024 : c; }
+
+extern "C" size_t mm_dot_topk_workspace_bytes(int64_t n_docs, int nq, int k) {
+  if (n_docs <= 0 || nq <= 0 || k <= 0) return 0;
+  const int cap = dot_cap(k);
+  const int64_t s = n_docs < kDotSample ? n_docs : kDotSample;
+  return a256((size_t)nq * s * 4) + 2 * a256((size_t)nq * 4) + 2 * a256((size_t)nq * cap * 4);
+}
+
+extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t n_docs, int nq, int E, int dtype, int k,
+                               float m_scale, float* out_scores, int64_t* out_idx, int32_t* status, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!queries || !corpus || !out_scores || !out_idx || !status) return set_error(MM_EINVAL, "dot_topk: null pointer");
+  if (n_docs <= 0 || nq <= 0 || E <= 0 || k <= 0) return set_error(MM_EINVAL, "dot_topk: non-positive shape");
+  if (dtype != MM_F16 && dtype != MM_BF16)
+    return set_error(MM_EUNSUPPORTED, "dot_topk: float16 / bfloat16 vectors only (the reference's GPU flat index stores fp16)");
+  if (n_docs >= (1LL << 31)) return set_error(MM_EUNSUPPORTED, "dot_topk: more than 2^31-1 documents in one shard");
+  if (((uintptr_t)queries | (uintptr_t)corpus) & 15) return set_error(MM_EINVAL, "dot_topk: 16-byte alignment required");
+  const int cap = dot_cap(k);
+  if (cap > kSortMax) return set_error(MM_EUNSUPPORTED, "dot_topk: k=%d exceeds the candidate sorter (k <= %d)", k, kSortMax / 4);
+  const size_t need = mm_dot_topk_workspace_bytes(n_docs, nq, k);
+  if (!workspace || workspace_bytes < need) return set_error(MM_EWORKSPACE, "dot_topk: workspace needs %zu bytes", need);
+  if (!(m_scale > 0.0f)) m_scale = 1.0f;
+
+  const int64_t S = n_docs < kDotSample ? n_docs : kDotSample;
+  char* ws = (char*)workspace;
+  float* all = (float*)ws;            ws += a256((size_t)nq * S * 4);
+  float* tau = (float*)ws;            ws += a256((size_t)nq * 4);
+  int32_t* count = (int32_t*)ws;      ws += a256((size_t)nq * 4);
+  float* cand_score = (float*)ws;     ws += a256((size_t)nq * cap * 4);
+  int32_t* cand_idx = (int32_t*)ws;
+
+  DotArgs a{};
+  a.q = queries; a.c = corpus; a.nq = nq; a.E = E; a.q_base = 0;
+  a.tau = tau; a.count = count; a.cand_score = cand_score; a.cand_idx = cand_idx; a.cap = cap;
+
+  // phase 1: threshold per query
+  if (n_docs <= cap) {
+    // small shard: everything is a candidate
+    hipLaunchKernelGGL(fill_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, tau, nq, -__builtin_huge_valf());
+  } else {
+    a.ndocs = S; a.stride = n_docs / S; a.all_out = all; a.ld_all = S;
+    const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_SAMPLE>(a, nq, stream) : launch_dot_e<MM_F16, DOT_SAMPLE>(a, nq, stream);
+    if (e) return e;
+    // expected survivors of the full pass = m * n_docs / S; aim at 2k (scaled by the caller's retry factor)
+    double mt = 2.0 * k * m_scale * (double)S / (double)n_docs;
+    int m = (int)(mt + 0.5);
+    if (m < 4) m = 4;
+    if (m > S) m = (int)S;
+    const int n2 = pow2_ge((int)S);
+    if ((size_t)n2 * 4 > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)sample_tau_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4);
+    hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(1024), (size_t)n2 * 4, stream, all, S, (int)S, n2, m, tau);
+  }
+  if (int e = check_launch("dot_topk threshold")) return e;
+
+  // phase 2: full product + threshold filter
+  if (hipMemsetAsync(count, 0, (size_t)nq * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "dot_topk: memset failed");
+  a.ndocs = n_docs; a.stride = 1;
+  {
+    const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_FILTER>(a, nq, stream) : launch_dot_e<MM_F16, DOT_FILTER>(a, nq, stream);
+    if (e) return e;
+  }
+  // phase 3: exact top-k of the survivors
+  const int n2 = cap;
+  if ((size_t)n2 * 8 > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 8);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), (size_t)n2 * 8, stream, cand_score, cand_idx, count, cap, n2, k,
+                     n_docs, out_scores, out_idx, status);
+  return check_launch("topk_rows_kernel");
+}
+
+// Merge of per-shard results (the sharded index's final step): rows of n_in (score, id) pairs ->
+// the k best per row.  ids < 0 are padding.  n_in <= 16384.
+__global__ void __launch_bounds__(1024) merge_rows_kernel(const float* __restrict__ in_score, const int64_t* __restrict__ in_id,
+                                                          int n_in, int n2, int k, float* __restrict__ out_score,
+                                                          int64_t* __restrict__ out_id) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* key = (float*)smem;
+  int* val = (int*)(key + n2);  // position in the input row: ties keep shard order (then ascending position)
+  const int row = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < n2; i += 1024) {
+    const bool ok = i < n_in && in_id[(int64_t)row * n_in + i] >= 0;
+    key[i] = ok ? in_score[(int64_t)row * n_in + i] : -__builtin_huge_valf();
+    val[i] = ok ? i : 0x7fffffff;
+  }
+  bitonic_desc<true>(key, val, n2, tid, 1024);
+  for (int i = tid; i < k; i += 1024) {
+    const bool ok = i < n2 && val[i] != 0x7fffffff;
+    out_score[(int64_t)row * k + i] = ok ? key[i] : -__builtin_huge_valf();
+    out_id[(int64_t)row * k + i] = ok ? in_id[(int64_t)row * n_in + val[i]] : -1;
+  }
+}
+
+extern "C" int mm_topk_merge(const float* in_scores, const int64_t* in_ids, int nq, int n_in, int k, float* out_scores,
+                             int64_t* out_ids, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in_scores || !in_ids || !out_scores || !out_ids) return set_error(MM_EINVAL, "topk_merge: null pointer");
+  if (nq <= 0 || n_in <= 0 || k <= 0) return set_error(MM_EINVAL, "topk_merge: non-positive shape");
+  const int n2 = pow2_ge(n_in);
+  if (n2 > kSortMax) return set_error(MM_EUNSUPPORTED, "topk_merge: %d inputs per row exceed %d", n_in, kSortMax);
+  if ((size_t)n2 * 8 > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)merge_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 8);
+  hipLaunchKernelGGL(merge_rows_kernel, dim3(nq), dim3(1024), (size_t)n2 * 8, stream, in_scores, in_ids, n_in, n2, k, out_scores, out_ids);
+  return check_launch("merge_rows_kernel");
+}

@@ -33,12 +33,19 @@ struct TklParams {            // offsets into the packed float parameter vector 
   __host__ __device__ static int emb() { return 4 * kK + 13 + 15; }
 };
 
-__global__ void __launch_bounds__(256) tkl_slot_map_kernel(const int32_t* __restrict__ chunk_slot, int64_t P,
+// slot -> (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2); -1 = dropped
+// chunk.  Stage 1 only writes the blocks below a chunk's effective length, so pair rows past them are
+// taken as zeros by stage 2 instead of being zero-filled in HBM first (that memset of the whole pair
+// buffer was 255 MB at B = 256 x 2048 tokens).
+__global__ void __launch_bounds__(256) tkl_slot_map_kernel(const int32_t* __restrict__ chunk_slot,
+                                                           const int32_t* __restrict__ chunk_len, int64_t P,
                                                            int64_t BC, int32_t* __restrict__ slot2p) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p < P) {
     const int32_t s = chunk_slot[p];
-    if (s >= 0 && s < BC) slot2p[s] = (int32_t)p;
+    int len = chunk_len[p];
+    len = len < 0 ? 0 : (len > 40 ? 40 : len);
+    if (s >= 0 && s < BC) slot2p[s] = (int32_t)((p << 2) | ((len + 31) >> 5));
   }
 }
 
@@ -93,7 +100,10 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
         const int ug = w0 + j;
         const int c = ug / kU, uu = ug - c * kU;
         off[s] = uu * rowf + v * 4;
-        if (c < C) pidx[s] = slot2p[(int64_t)b * C + c];
+        if (c < C) {
+          const int info = slot2p[(int64_t)b * C + c];
+          if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;  // rows of unwritten blocks are zeros
+        }
       }
     }
     f32x4 val[kStage];
@@ -255,15 +265,14 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   ws += ps_bytes;
   size_t left = workspace_bytes - (size_t)(ws - (char*)workspace);
   float* win = win_scores;
-  hipError_t e1 = hipMemsetAsync(slot2p, 0xFF, (size_t)B * C * 4, stream);
-  hipError_t e2 = ps_bytes ? hipMemsetAsync(ps, 0, ps_bytes, stream) : hipSuccess;
-  if (e1 != hipSuccess || e2 != hipSuccess) return set_error(MM_ELAUNCH, "tkl: memset failed");
+  if (hipMemsetAsync(slot2p, 0xFF, (size_t)B * C * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "tkl: memset failed");
   if (P > 0) {
-    hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, P,
-                       B * (int64_t)C, slot2p);
-    if (int e = check_launch("tkl_slot_map_kernel")) return e;
+    if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
     PackedMask dm;
     if (int e = resolve_mask(chunk_mask, MM_MASK_F32, P, 40, &ws, &left, stream, &dm, 50, 5)) return e;
+    hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, dm.len, P,
+                       B * (int64_t)C, slot2p);
+    if (int e = check_launch("tkl_slot_map_kernel")) return e;
     if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, chunk_slot, C,
                                   params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
       return e;

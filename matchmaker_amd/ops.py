@@ -270,3 +270,100 @@ def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tenso
                               K, sat, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
         _lib.check(rc, "mm_tkl_fwd")
     return (out, win) if return_windows else out
+
+
+def dot_topk(queries: torch.Tensor, corpus: torch.Tensor, k: int, max_rounds: int = 6):
+    """Exact brute-force inner-product top-k over one shard (faiss IndexFlatIP.search semantics;
+    matchmaker/retrieval/faiss_indices.py:22-36, :49-74; score = bert_dot.py:62).
+
+    queries [nq, E], corpus [N, E] float16 / bfloat16 on the same device, E in {128,...,768} (pad
+    otherwise).  Returns (scores [nq, k] float32 descending, idx [nq, k] int64 rows of `corpus`,
+    -1 / -inf padded when N < k).  The native call thresholds every query from a sample of the
+    shard; queries whose threshold let too few / too many candidates through (status != 0, rare)
+    are re-run with a moved threshold until every row is exact."""
+    dev = _dev_check(queries, corpus)
+    if queries.dim() != 2 or corpus.dim() != 2 or queries.shape[1] != corpus.shape[1]:
+        raise NativeError(f"dot_topk: expected [nq, E] and [N, E], got {tuple(queries.shape)} {tuple(corpus.shape)}")
+    if queries.dtype != corpus.dtype or corpus.dtype not in (torch.float16, torch.bfloat16):
+        raise NativeError(f"dot_topk: float16 / bfloat16 vectors of one dtype needed, got {queries.dtype} / {corpus.dtype}")
+    queries = queries if queries.is_contiguous() else queries.contiguous()
+    corpus = corpus if corpus.is_contiguous() else corpus.contiguous()
+    nq, E = queries.shape
+    N = corpus.shape[0]
+    L = _lib.lib()
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if nq == 0:
+        return out_s, out_i
+    if N == 0:
+        return out_s.fill_(float("-inf")), out_i.fill_(-1)
+
+    def run(q, scale):
+        n = q.shape[0]
+        s = torch.empty((n, k), dtype=torch.float32, device=dev)
+        i = torch.empty((n, k), dtype=torch.int64, device=dev)
+        st = torch.empty(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            wsb = L.mm_dot_topk_workspace_bytes(N, n, k)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            rc = L.mm_dot_topk_fwd(q.data_ptr(), corpus.data_ptr(), N, n, E, _DT[q.dtype], k, scale, s.data_ptr(),
+                                   i.data_ptr(), st.data_ptr(), ws.data_ptr(), wsb, _stream(dev))
+        _lib.check(rc, "mm_dot_topk_fwd")
+        return s, i, st
+
+    s, i, st = run(queries, 1.0)
+    out_s.copy_(s)
+    out_i.copy_(i)
+    bad = torch.nonzero(st != 0).flatten().tolist()   # one small D2H: the exactness check
+    if not bad:
+        return out_s, out_i
+    # rare path: bisect the threshold scale per query (status 1 = too few survivors -> larger m,
+    # status 2 = candidate list overflowed -> smaller m)
+    codes = st[bad].tolist()
+    lo = {q: (1.0 if c == 1 else None) for q, c in zip(bad, codes)}   # largest scale known to underflow
+    hi = {q: (1.0 if c == 2 else None) for q, c in zip(bad, codes)}   # smallest scale known to overflow
+    for _ in range(max_rounds):
+        groups = {}
+        for q in bad:
+            if lo[q] is not None and hi[q] is not None:
+                sc = (lo[q] * hi[q]) ** 0.5
+            else:
+                sc = lo[q] * 4.0 if lo[q] is not None else hi[q] * 0.25
+            groups.setdefault(round(sc, 6), []).append(q)
+        still = []
+        for sc, qs in groups.items():
+            sel = torch.tensor(qs, dtype=torch.int64, device=dev)
+            s2, i2, st2 = run(queries[sel].contiguous(), float(sc))
+            st2 = st2.tolist()
+            for n, q in enumerate(qs):
+                if st2[n] == 0:
+                    out_s[q] = s2[n]
+                    out_i[q] = i2[n]
+                else:
+                    if st2[n] == 1:
+                        lo[q] = sc
+                    else:
+                        hi[q] = sc
+                    still.append(q)
+        bad = still
+        if not bad:
+            return out_s, out_i
+    raise NativeError(f"dot_topk: {len(bad)} queries without an exact top-{k} after {max_rounds} threshold re-runs "
+                      "(more than 4k documents tie at the k-th score?)")
+
+
+def topk_merge(scores: torch.Tensor, ids: torch.Tensor, k: int):
+    """Rows of (score, id) candidates [nq, n_in] -> the k best per row (score descending, input order on
+    ties); ids < 0 are padding.  The sharded index's final merge (mm_topk_merge)."""
+    dev = _dev_check(scores, ids)
+    scores = scores.to(torch.float32).contiguous()
+    ids = ids.to(torch.int64).contiguous()
+    nq, n_in = scores.shape
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if nq:
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mm_topk_merge(scores.data_ptr(), ids.data_ptr(), nq, n_in, k, out_s.data_ptr(),
+                                          out_i.data_ptr(), _stream(dev))
+        _lib.check(rc, "mm_topk_merge")
+    return out_s, out_i

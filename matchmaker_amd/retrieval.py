@@ -1,0 +1,84 @@
+"""Drop-in for matchmaker's brute-force faiss index on MI355X: same surface as
+`FaissIdIndexer` (matchmaker/retrieval/faiss_indices.py:49-74; base class :13-36) —
+`prepare(data_chunks)`, `index(ids, data_chunks)`, `search(query_vec, top_n) -> (scores, ids)` —
+with the collection resident in HBM as float16 (what `co.useFloat16` stores on the reference's GPUs)
+and the search done by the native Q x C^T + exact top-k kernels (mm_dot_topk_fwd).
+
+Multi-GPU = the reference's `co.shard = True` (:62-66): every rank holds a contiguous shard of the
+vectors; `search` runs the local top-k, all-gathers the [nq, k] (score, id) lists over RCCL and
+merges them natively (mm_topk_merge).  Used from dense_retrieval.py:308-328 (construction),
+:333-336 (prepare / index) and :391 (search).
+"""
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .sharding import shard_range
+
+
+def _pad_dim(E: int) -> int:
+    for e in (128, 256, 384, 512, 768):
+        if E <= e:
+            return e
+    raise ops.NativeError(f"token_dim {E} > 768 is not supported by the native flat index")
+
+
+class FlatIPIndexer:
+    def __init__(self, config, device=None, group=None):
+        self.token_dim = config["token_dim"]
+        self.use_fp16 = config.get("faiss_use_fp16", True)   # the native index always stores 16-bit vectors
+        self.dtype = torch.float16
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.group = group
+        self.vectors: Optional[torch.Tensor] = None           # [n_local, E_pad]
+        self.ids: Optional[torch.Tensor] = None               # [n_local] int64 external ids (IndexIDMap)
+        self.E_pad = _pad_dim(self.token_dim)
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    def prepare(self, data_chunks: List[np.ndarray]):          # base_index.py: nothing to train for a flat index
+        pass
+
+    def index(self, ids: List[np.ndarray], data_chunks: List[np.ndarray]):
+        """faiss_indices.py:22-27: one add of all vectors with their ids.  With several ranks each
+        keeps its contiguous shard (every rank is given the same full lists, as the reference's single
+        process is)."""
+        i = np.concatenate(ids).astype(np.int64)
+        n = i.shape[0]
+        world, rank = self._world()
+        lo, hi = shard_range(n, world, rank)
+        vec = torch.zeros((hi - lo, self.E_pad), dtype=self.dtype, device=self.device)
+        off = 0
+        for c in data_chunks:                                  # chunk by chunk: no second host copy
+            a, b = max(lo, off), min(hi, off + c.shape[0])
+            if a < b:
+                vec[a - lo: b - lo, : self.token_dim] = torch.from_numpy(np.ascontiguousarray(c[a - off: b - off])).to(
+                    self.device).to(self.dtype)
+            off += c.shape[0]
+        self.vectors = vec
+        self.ids = torch.from_numpy(i[lo:hi]).to(self.device)
+
+    def search(self, query_vec, top_n: int):
+        """faiss_indices.py:29-36: (scores [nq, top_n] float32 descending, ids [nq, top_n] int64)."""
+        q = torch.as_tensor(query_vec)
+        if q.dim() == 1:
+            q = q[None, :]
+        qd = torch.zeros((q.shape[0], self.E_pad), dtype=self.dtype, device=self.device)
+        qd[:, : self.token_dim] = q.to(self.device).to(self.dtype)
+        s, idx = ops.dot_topk(qd, self.vectors, top_n)
+        ids = torch.where(idx >= 0, self.ids[idx.clamp(min=0)], idx)
+        world, _ = self._world()
+        if world > 1:
+            gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+            gi = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+            dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)     # RCCL over xGMI
+            dist.all_gather_into_tensor(gi, ids.contiguous(), group=self.group)
+            s, ids = ops.topk_merge(gs.permute(1, 0, 2).reshape(s.shape[0], -1),
+                                    gi.permute(1, 0, 2).reshape(s.shape[0], -1), top_n)
+        return s.cpu().numpy(), ids.cpu().numpy()

@@ -300,6 +300,29 @@ def tkl_params_from_state(sd):
     }
 
 
+# ----------------------------------------------------------------------------- dense retrieval
+
+
+def dot_topk(queries, corpus, k, dtype=np.float32):
+    """faiss IndexFlatIP.search as the reference uses it (retrieval/faiss_indices.py:29-36 on an
+    IndexIDMap(IndexFlatIP), :65; score = BERT_DOT dot product, bert_dot.py:62): per query the k
+    largest inner products, descending.  faiss (faiss-gpu==1.7.0, conda-requirements.txt:1) is a
+    third-party dependency absent from the reference tree and from this image, so this restates its
+    published semantics ("parity unpinned" beyond that); ties are broken by the lower row index, and
+    rows are padded with (-inf, -1) when the collection has fewer than k vectors (faiss pads with -1).
+    queries [nq,E], corpus [N,E] -> (scores [nq,k], idx [nq,k] int64)."""
+    q = np.asarray(queries, dtype=dtype)
+    c = np.asarray(corpus, dtype=dtype)
+    s = q @ c.T
+    order = np.argsort(-s, axis=1, kind="stable")[:, :k]
+    top = np.take_along_axis(s, order, axis=1)
+    if order.shape[1] < k:
+        pad = k - order.shape[1]
+        top = np.pad(top, ((0, 0), (0, pad)), constant_values=-np.inf)
+        order = np.pad(order, ((0, 0), (0, pad)), constant_values=-1)
+    return top.astype(dtype), order.astype(np.int64)
+
+
 # ----------------------------------------------------------------------------- ranking
 
 

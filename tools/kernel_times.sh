@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/kt_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -o kt -- "$@" > $O/cmd.log 2>&1
 cd $R
+rocprofv3 --kernel-trace --stats -d $O/trace -o kt -- "$@" > $O/cmd.log 2>&1
 python tools/summarize_rocprof.py $O $O/summary.json "" > /dev/null
 python - "$O/summary.json" <<'PY'
 import json, sys
