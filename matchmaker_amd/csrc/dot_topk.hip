@@ -41,6 +41,7 @@ constexpr int kDotSample = 16384;  // sample size (documents) of phase 1 when th
 constexpr int kSortMax = 16384;    // rows of sort_rows_kernel are padded to a power of two <= this
 
 enum { DOT_SAMPLE = 0, DOT_FILTER = 1 };
+constexpr int kStage = 768;         // LDS staging entries (score, document, query) per workgroup
 
 struct DotArgs {
   const void* q;      // [nq, E]
@@ -55,7 +56,7 @@ struct DotArgs {
   int64_t ld_all;
   // FILTER
   const float* tau;   // [nq]
-  int32_t* count;     // [nq]
+  int32_t* count;     // [nq] survivors (may exceed cap: overflow)
   float* cand_score;  // [nq, cap]
   int32_t* cand_idx;  // [nq, cap] document index inside the shard
   int cap;
@@ -96,20 +97,30 @@ __device__ __forceinline__ void dot_load_q(const char* base, short8 (&qf)[8]) {
       : "memory");
 }
 
-// One LDS-DMA instruction: 4 document rows x 256 B (one 128-dim slice) -> 1 KiB of LDS at m0.
+// NSL LDS-DMA instructions: 4 document rows x 256 B of every 128-dim slice -> 1 KiB of LDS each, the
+// slices 8 KiB apart (m0 walks).  The per-slice source offsets come in VGPRs: an instruction offset
+// would also be added to the LDS address (LDS_addr = M0 + inst_offset + lane * 16).
+#define MM_DOT_LD(N) "s_nop 0\n\tglobal_load_lds_dwordx4 %" #N ", %7\n\ts_add_u32 m0, m0, 0x2000\n\t"
+#define MM_DOT_ISSUE(BODY)                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %8\n\t" BODY "s_mov_b32 m0, %0" \
+               : "=&s"(keep)                                                                            \
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "s"(gbase), "s"(lds_dst) \
+               : "memory", "scc")
+template <int NSL>
 __device__ __forceinline__ void dot_issue(const char* gbase, uint32_t voff, uint32_t lds_dst) {
+  static_assert(NSL == 1 || NSL == 2 || NSL == 3 || NSL == 4 || NSL == 6, "E = 128 * NSL");
   uint32_t keep;
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(gbase), "s"(lds_dst)
-      : "memory");
+  uint32_t v[6];
+#pragma unroll
+  for (int sl = 0; sl < 6; ++sl) v[sl] = voff + (sl < NSL ? sl : 0) * 256;
+  if constexpr (NSL == 1) MM_DOT_ISSUE(MM_DOT_LD(1));
+  else if constexpr (NSL == 2) MM_DOT_ISSUE(MM_DOT_LD(1) MM_DOT_LD(2));
+  else if constexpr (NSL == 3) MM_DOT_ISSUE(MM_DOT_LD(1) MM_DOT_LD(2) MM_DOT_LD(3));
+  else if constexpr (NSL == 4) MM_DOT_ISSUE(MM_DOT_LD(1) MM_DOT_LD(2) MM_DOT_LD(3) MM_DOT_LD(4));
+  else MM_DOT_ISSUE(MM_DOT_LD(1) MM_DOT_LD(2) MM_DOT_LD(3) MM_DOT_LD(4) MM_DOT_LD(5) MM_DOT_LD(6));
 }
+#undef MM_DOT_ISSUE
+#undef MM_DOT_LD
 
 template <int N>
 __device__ __forceinline__ void dot_wait() {
@@ -140,6 +151,28 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   const int64_t b_lo = x_lo + (x_hi - x_lo) * t / a.T, b_hi = x_lo + (x_hi - x_lo) * (t + 1) / a.T;
   if (b_lo >= b_hi) return;
   const int q0 = a.q_base + g * (128 * NQT) + w * (32 * NQT);
+  // Survivors are staged in LDS (slot claim = LDS atomic, returns through lgkmcnt) and flushed to the
+  // per-query candidate lists in bursts: a returning GLOBAL atomic per survivor would force
+  // vmcnt(0) — i.e. drain the LDS-DMA prefetch — on nearly every block (~4 survivors per
+  // wavefront-block at the working threshold).
+  int* stage_cnt = (int*)(smem + NBUF * BLK);          // [0] = staged entries
+  float* stage_score = (float*)(stage_cnt + 4);         // [kStage]
+  int* stage_doc = (int*)(stage_score + kStage);        // [kStage]
+  int* stage_q = stage_doc + kStage;                    // [kStage]
+  if (MODE == DOT_FILTER && tid == 0) stage_cnt[0] = 0;
+  auto append_global = [&](int qq, float sc, int doc) {
+    const int slot = atomicAdd(a.count + qq, 1);
+    if ((unsigned)slot < (unsigned)a.cap) {
+      a.cand_score[(int64_t)qq * a.cap + slot] = sc;
+      a.cand_idx[(int64_t)qq * a.cap + slot] = doc;
+    }
+  };
+  auto flush = [&]() {  // workgroup-wide; callers hold a barrier before (all appends done) and after
+    const int n = stage_cnt[0] < kStage ? stage_cnt[0] : kStage;
+    for (int i = tid; i < n; i += 256) append_global(stage_q[i], stage_score[i], stage_doc[i]);
+    __syncthreads();
+    if (tid == 0) stage_cnt[0] = 0;
+  };
 
   // ---- this wavefront's queries as MFMA B fragments ----------------------------------------------
   short8 qf[NQT][NSL][8];
@@ -174,9 +207,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       int row = lrow[u];
       if (left < 32 && row >= left) row = (int)left - 1;  // never read past the shard
       const uint32_t voff = (uint32_t)(row * rowstep) + lslot[u];
-#pragma unroll
-      for (int sl = 0; sl < NSL; ++sl)
-        dot_issue(gb + sl * 256, voff, lds0 + (uint32_t)(slot * BLK + sl * 8192 + (w + 4 * u) * 1024));
+      dot_issue<NSL>(gb, voff, lds0 + (uint32_t)(slot * BLK + (w + 4 * u) * 1024));
     }
   };
   // A-fragment read offsets inside a slice: chunk (2kk + h) of row r at slot chunk ^ (r & 15)
@@ -192,6 +223,10 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     // this wavefront's part of block b has landed once at most the younger block's PER loads pend
     if (b + 1 < b_hi) dot_wait<PER>(); else dot_wait<0>();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
+    if (MODE == DOT_FILTER && stage_cnt[0] >= kStage / 2) {  // workgroup-uniform: read after the barrier
+      flush();
+      __syncthreads();
+    }
     if (b + 2 < b_hi) issue(b + 2, slot_i == 0 ? 2 : slot_i - 1);  // into the slot block b - 1 used
 
     f32x16 acc[NQT];
@@ -238,21 +273,28 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
         bool any = false;
 #pragma unroll
         for (int i = 0; i < 16; ++i) any = any || (acc[n][i] >= tau[n]);
-        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;  // the common case: nobody passes
+        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
         if (!any) continue;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int64_t doc = d0 + drowof(i);
           if (acc[n][i] >= tau[n] && doc < a.ndocs) {
-            const int slot = atomicAdd(a.count + qid[n], 1);
-            if (slot < a.cap) {
-              a.cand_score[(int64_t)qid[n] * a.cap + slot] = acc[n][i];
-              a.cand_idx[(int64_t)qid[n] * a.cap + slot] = (int32_t)(doc * a.stride);
+            const int slot = atomicAdd(stage_cnt, 1);  // ds_add_rtn_u32
+            if (slot < kStage) {
+              stage_score[slot] = acc[n][i];
+              stage_doc[slot] = (int32_t)(doc * a.stride);
+              stage_q[slot] = qid[n];
+            } else {
+              append_global(qid[n], acc[n][i], (int32_t)(doc * a.stride));  // staging full: slow but exact
             }
           }
         }
       }
     }
+  }
+  if (MODE == DOT_FILTER) {
+    __syncthreads();
+    flush();
   }
 }
 
@@ -299,15 +341,17 @@ __global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restric
 
 __global__ void __launch_bounds__(1024) topk_rows_kernel(const float* __restrict__ cand_score,
                                                          const int32_t* __restrict__ cand_idx,
-                                                         const int32_t* __restrict__ count, int cap, int n2, int k,
+                                                         const int32_t* __restrict__ count, int cap, int k,
                                                          int64_t n_total, float* __restrict__ out_score,
                                                          int64_t* __restrict__ out_idx, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* key = (float*)smem;
-  int* val = (int*)(key + n2);
+  int* val = (int*)(key + cap);
   const int row = blockIdx.x, tid = threadIdx.x;
   const int cnt = count[row];
   const int n = cnt < cap ? cnt : cap;
+  int n2 = 2;
+  while (n2 < n) n2 <<= 1;  // sort only as much as survived (typically ~2.5 k of the 4 k capacity)
   for (int i = tid; i < n2; i += 1024) {
     key[i] = i < n ? cand_score[(int64_t)row * cap + i] : -__builtin_huge_valf();
     val[i] = i < n ? cand_idx[(int64_t)row * cap + i] : 0x7fffffff;
@@ -330,21 +374,36 @@ __global__ void __launch_bounds__(256) fill_tau_kernel(float* tau, int n, float 
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 static int pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
+// Launch geometry of one call: NQT query tiles per wavefront, query groups of 128 * NQT, at most 32
+// groups per launch (one per CU of an XCD), T sub-slices per XCD.
+struct DotGeom {
+  int nqt, qpw, T;
+};
+static DotGeom dot_geom(int64_t n_docs, int nq) {
+  DotGeom g;
+  g.nqt = nq > 128 ? 2 : 1;
+  g.qpw = 128 * g.nqt;
+  int G = (nq + g.qpw - 1) / g.qpw;
+  if (G > 32) G = 32;
+  g.T = 32 / G > 0 ? 32 / G : 1;
+  const int64_t per_xcd = ((n_docs + 31) / 32 + 7) / 8;
+  if (g.T > per_xcd) g.T = per_xcd > 0 ? (int)per_xcd : 1;
+  return g;
+}
+
 template <int DT, int NSL, int NQT, int MODE>
-static int launch_dot(const DotArgs& a0, int nq_launch, hipStream_t stream) {
+static int launch_dot(const DotArgs& a0, int nq_launch, int T, hipStream_t stream) {
   DotArgs a = a0;
   constexpr int QPW = 128 * NQT;  // queries per workgroup
-  const int lds = 3 * 32 * NSL * 256;
+  const int lds = 3 * 32 * NSL * 256 + 16 + kStage * 12;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dot_stream_kernel<DT, NSL, NQT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (31.0 * (double)a.stride * (NSL * 256) >= 4294967296.0)
     return set_error(MM_EUNSUPPORTED, "dot_topk: sample stride too large for 32-bit row offsets");
+  a.T = T;
   for (int qb = 0; qb < nq_launch; qb += 32 * QPW) {  // at most 32 query groups (one per CU of an XCD) per launch
     const int nq_here = nq_launch - qb < 32 * QPW ? nq_launch - qb : 32 * QPW;
     a.G = (nq_here + QPW - 1) / QPW;
-    a.T = 32 / a.G > 0 ? 32 / a.G : 1;
-    const int64_t nblk = (a.ndocs + 31) >> 5;
-    if (a.T > (nblk + 7) / 8) a.T = (int)((nblk + 7) / 8) > 0 ? (int)((nblk + 7) / 8) : 1;
     a.q_base = a0.q_base + qb;
     hipLaunchKernelGGL((dot_stream_kernel<DT, NSL, NQT, MODE>), dim3(8 * a.G * a.T), dim3(256), lds, stream, a);
     if (int e = check_launch("dot_stream_kernel")) return e;
@@ -353,15 +412,15 @@ static int launch_dot(const DotArgs& a0, int nq_launch, hipStream_t stream) {
 }
 
 template <int DT, int MODE>
-static int launch_dot_e(const DotArgs& a, int nq_launch, hipStream_t stream) {
+static int launch_dot_e(const DotArgs& a, int nq_launch, const DotGeom& g, hipStream_t stream) {
   // NQT = 2 (64 queries per wavefront: every LDS read feeds two MFMAs) once there are enough queries
-  const bool two = nq_launch > 128;
+  const bool two = g.nqt == 2;
   switch (a.E / 128) {
-    case 1: return two ? launch_dot<DT, 1, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 1, 1, MODE>(a, nq_launch, stream);
-    case 2: return two ? launch_dot<DT, 2, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 2, 1, MODE>(a, nq_launch, stream);
-    case 3: return two ? launch_dot<DT, 3, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 3, 1, MODE>(a, nq_launch, stream);
-    case 4: return two ? launch_dot<DT, 4, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 4, 1, MODE>(a, nq_launch, stream);
-    case 6: return two ? launch_dot<DT, 6, 2, MODE>(a, nq_launch, stream) : launch_dot<DT, 6, 1, MODE>(a, nq_launch, stream);
+    case 1: return two ? launch_dot<DT, 1, 2, MODE>(a, nq_launch, g.T, stream) : launch_dot<DT, 1, 1, MODE>(a, nq_launch, g.T, stream);
+    case 2: return two ? launch_dot<DT, 2, 2, MODE>(a, nq_launch, g.T, stream) : launch_dot<DT, 2, 1, MODE>(a, nq_launch, g.T, stream);
+    case 3: return two ? launch_dot<DT, 3, 2, MODE>(a, nq_launch, g.T, stream) : launch_dot<DT, 3, 1, MODE>(a, nq_launch, g.T, stream);
+    case 4: return two ? launch_dot<DT, 4, 2, MODE>(a, nq_launch, g.T, stream) : launch_dot<DT, 4, 1, MODE>(a, nq_launch, g.T, stream);
+    case 6: return two ? launch_dot<DT, 6, 2, MODE>(a, nq_launch, g.T, stream) : launch_dot<DT, 6, 1, MODE>(a, nq_launch, g.T, stream);
     default: return set_error(MM_EUNSUPPORTED, "dot_topk: E=%d (supported: 128, 256, 384, 512, 768; pad the vectors)", a.E);
   }
 }
@@ -370,12 +429,18 @@ static int launch_dot_e(const DotArgs& a, int nq_launch, hipStream_t stream) {
 
 using namespace mm;
 
-static int dot_cap(int k) { int c = pow2_ge(4 * k); return c < 1024 ? 1024 : c; }
+static int dot_cap(int64_t n_docs, int k) {  // candidate list capacity per query
+  int c = pow2_ge(4 * k);
+  if (c < 1024) c = 1024;
+  if (n_docs <= 4096 && c < 4096) c = 4096;  // small shards: everything is a candidate
+  return c;
+}
 
 extern "C" size_t mm_dot_topk_workspace_bytes(int64_t n_docs, int nq, int k) {
   if (n_docs <= 0 || nq <= 0 || k <= 0) return 0;
-  const int cap = dot_cap(k);
+  const int cap = dot_cap(n_docs, k);
   const int64_t s = n_docs < kDotSample ? n_docs : kDotSample;
+  // sample scores | tau | survivor counts | candidate scores + indices
   return a256((size_t)nq * s * 4) + 2 * a256((size_t)nq * 4) + 2 * a256((size_t)nq * cap * 4);
 }
 
@@ -389,12 +454,14 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
     return set_error(MM_EUNSUPPORTED, "dot_topk: float16 / bfloat16 vectors only (the reference's GPU flat index stores fp16)");
   if (n_docs >= (1LL << 31)) return set_error(MM_EUNSUPPORTED, "dot_topk: more than 2^31-1 documents in one shard");
   if (((uintptr_t)queries | (uintptr_t)corpus) & 15) return set_error(MM_EINVAL, "dot_topk: 16-byte alignment required");
-  const int cap = dot_cap(k);
-  if (cap > kSortMax) return set_error(MM_EUNSUPPORTED, "dot_topk: k=%d exceeds the candidate sorter (k <= %d)", k, kSortMax / 4);
+  if (k > kSortMax / 4) return set_error(MM_EUNSUPPORTED, "dot_topk: k=%d exceeds the candidate sorter (k <= %d)", k, kSortMax / 4);
   const size_t need = mm_dot_topk_workspace_bytes(n_docs, nq, k);
   if (!workspace || workspace_bytes < need) return set_error(MM_EWORKSPACE, "dot_topk: workspace needs %zu bytes", need);
   if (!(m_scale > 0.0f)) m_scale = 1.0f;
 
+  const DotGeom g = dot_geom(n_docs, nq);
+  const bool small = n_docs <= 4096;  // everything is a candidate: no sampling
+  const int cap = dot_cap(n_docs, k);
   const int64_t S = n_docs < kDotSample ? n_docs : kDotSample;
   char* ws = (char*)workspace;
   float* all = (float*)ws;            ws += a256((size_t)nq * S * 4);
@@ -408,15 +475,15 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   a.tau = tau; a.count = count; a.cand_score = cand_score; a.cand_idx = cand_idx; a.cap = cap;
 
   // phase 1: threshold per query
-  if (n_docs <= cap) {
-    // small shard: everything is a candidate
+  if (small) {
     hipLaunchKernelGGL(fill_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, tau, nq, -__builtin_huge_valf());
   } else {
     a.ndocs = S; a.stride = n_docs / S; a.all_out = all; a.ld_all = S;
-    const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_SAMPLE>(a, nq, stream) : launch_dot_e<MM_F16, DOT_SAMPLE>(a, nq, stream);
+    const DotGeom gs = dot_geom(S, nq);
+    const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_SAMPLE>(a, nq, gs, stream) : launch_dot_e<MM_F16, DOT_SAMPLE>(a, nq, gs, stream);
     if (e) return e;
-    // expected survivors of the full pass = m * n_docs / S; aim at 2k (scaled by the caller's retry factor)
-    double mt = 2.0 * k * m_scale * (double)S / (double)n_docs;
+    // expected survivors of the full pass ~ m * n_docs / S: aim at 2.5 k of the 4 k capacity (x the caller's retry factor)
+    double mt = 2.5 * k * m_scale * (double)S / (double)n_docs;
     int m = (int)(mt + 0.5);
     if (m < 4) m = 4;
     if (m > S) m = (int)S;
@@ -431,14 +498,13 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   if (hipMemsetAsync(count, 0, (size_t)nq * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "dot_topk: memset failed");
   a.ndocs = n_docs; a.stride = 1;
   {
-    const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_FILTER>(a, nq, stream) : launch_dot_e<MM_F16, DOT_FILTER>(a, nq, stream);
+    const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_FILTER>(a, nq, g, stream) : launch_dot_e<MM_F16, DOT_FILTER>(a, nq, g, stream);
     if (e) return e;
   }
   // phase 3: exact top-k of the survivors
-  const int n2 = cap;
-  if ((size_t)n2 * 8 > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 8);
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), (size_t)n2 * 8, stream, cand_score, cand_idx, count, cap, n2, k,
+  if ((size_t)cap * 8 > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 8);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), (size_t)cap * 8, stream, cand_score, cand_idx, count, cap, k,
                      n_docs, out_scores, out_idx, status);
   return check_launch("topk_rows_kernel");
 }
