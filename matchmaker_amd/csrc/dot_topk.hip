@@ -41,7 +41,7 @@ constexpr int kDotSample = 16384;  // sample size (documents) of phase 1 when th
 constexpr int kSortMax = 16384;    // rows of sort_rows_kernel are padded to a power of two <= this
 
 enum { DOT_SAMPLE = 0, DOT_FILTER = 1 };
-constexpr int kStage = 768;         // LDS staging entries (score, document, query) per workgroup
+constexpr int kStageW = 192;        // LDS staging entries (score, document, query) per wavefront
 
 struct DotArgs {
   const void* q;      // [nq, E]
@@ -60,6 +60,7 @@ struct DotArgs {
   float* cand_score;  // [nq, cap]
   int32_t* cand_idx;  // [nq, cap] document index inside the shard
   int cap;
+  unsigned long long* prof;  // optional [grid * 4 wavefronts][6] cycle counters (MM_DOT_PROF=1, tools only)
 };
 
 template <int DT>
@@ -151,27 +152,26 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   const int64_t b_lo = x_lo + (x_hi - x_lo) * t / a.T, b_hi = x_lo + (x_hi - x_lo) * (t + 1) / a.T;
   if (b_lo >= b_hi) return;
   const int q0 = a.q_base + g * (128 * NQT) + w * (32 * NQT);
-  // Survivors are staged in LDS (slot claim = LDS atomic, returns through lgkmcnt) and flushed to the
-  // per-query candidate lists in bursts: a returning GLOBAL atomic per survivor would force
-  // vmcnt(0) — i.e. drain the LDS-DMA prefetch — on nearly every block (~4 survivors per
-  // wavefront-block at the working threshold).
-  int* stage_cnt = (int*)(smem + NBUF * BLK);          // [0] = staged entries
-  float* stage_score = (float*)(stage_cnt + 4);         // [kStage]
-  int* stage_doc = (int*)(stage_score + kStage);        // [kStage]
-  int* stage_q = stage_doc + kStage;                    // [kStage]
-  if (MODE == DOT_FILTER && tid == 0) stage_cnt[0] = 0;
-  auto append_global = [&](int qq, float sc, int doc) {
-    const int slot = atomicAdd(a.count + qq, 1);
-    if ((unsigned)slot < (unsigned)a.cap) {
-      a.cand_score[(int64_t)qq * a.cap + slot] = sc;
-      a.cand_idx[(int64_t)qq * a.cap + slot] = doc;
+  // Survivors (~5 per wavefront-block at the working threshold) are staged in a wavefront-PRIVATE LDS
+  // area: positions come from the ballot of the compare (popcount + mbcnt), the fill level lives in a
+  // scalar register — no atomics, no waits.  A wavefront flushes its own area to the per-query
+  // candidate lists when it runs full; only that flush uses returning global atomics (which force
+  // vmcnt(0), i.e. drain this wavefront's LDS-DMA prefetch: once every ~40 blocks instead of on
+  // nearly every block).
+  float* st_score = (float*)(smem + NBUF * BLK) + w * kStageW;            // [4][kStageW]
+  int* st_doc = (int*)(smem + NBUF * BLK + 4 * kStageW * 4) + w * kStageW;  // [4][kStageW]
+  int* st_q = (int*)(smem + NBUF * BLK + 8 * kStageW * 4) + w * kStageW;    // [4][kStageW]
+  int scnt = 0;  // wave-uniform fill level
+  auto flush_wave = [&]() {
+    for (int i = lane; i < scnt; i += 64) {
+      const int qq = st_q[i];
+      const int slot = atomicAdd(a.count + qq, 1);
+      if ((unsigned)slot < (unsigned)a.cap) {
+        a.cand_score[(int64_t)qq * a.cap + slot] = st_score[i];
+        a.cand_idx[(int64_t)qq * a.cap + slot] = st_doc[i];
+      }
     }
-  };
-  auto flush = [&]() {  // workgroup-wide; callers hold a barrier before (all appends done) and after
-    const int n = stage_cnt[0] < kStage ? stage_cnt[0] : kStage;
-    for (int i = tid; i < n; i += 256) append_global(stage_q[i], stage_score[i], stage_doc[i]);
-    __syncthreads();
-    if (tid == 0) stage_cnt[0] = 0;
+    scnt = 0;
   };
 
   // ---- this wavefront's queries as MFMA B fragments ----------------------------------------------
@@ -215,28 +215,35 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
 
+  unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+  };
   int slot_i = 0;  // ring slot of block `b`
   if (b_lo < b_hi) issue(b_lo, 0);
   if (b_lo + 1 < b_hi) issue(b_lo + 1, 1);
 
   for (int64_t b = b_lo; b < b_hi; ++b) {
     // this wavefront's part of block b has landed once at most the younger block's PER loads pend
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (a.prof) t0 = now();
     if (b + 1 < b_hi) dot_wait<PER>(); else dot_wait<0>();
+    if (a.prof) t1 = now();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
-    if (MODE == DOT_FILTER && stage_cnt[0] >= kStage / 2) {  // workgroup-uniform: read after the barrier
-      flush();
-      __syncthreads();
-    }
+    if (a.prof) t2 = now();
     if (b + 2 < b_hi) issue(b + 2, slot_i == 0 ? 2 : slot_i - 1);  // into the slot block b - 1 used
 
+    if (a.prof) t3 = now();
     f32x16 acc[NQT];
 #pragma unroll
     for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
     const char* buf = smem + slot_i * BLK;
-    // A fragments are fetched three steps ahead of the MFMAs that use them (one wavefront per SIMD:
+    // A fragments are fetched AHEAD steps ahead of the MFMAs that use them (one wavefront per SIMD:
     // nothing else hides the ~100-cycle LDS latency); the group barriers pin the order
     // {1 LDS read, NQT MFMAs} so the compiler does not fold the reads back next to their uses
-    constexpr int STEPS = NSL * 8, AHEAD = 3;
+    constexpr int STEPS = NSL * 8, AHEAD = (NSL * 8 > 6) ? 6 : 3;
     short8 av[AHEAD + 1];
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) av[s] = *(const short8*)(buf + (s >> 3) * 8192 + lo[s & 7]);
@@ -250,6 +257,15 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
     }
     slot_i = slot_i == NBUF - 1 ? 0 : slot_i + 1;
+    if (a.prof) {
+      // force the accumulators to be complete before the stamp
+      float sink = 0.0f;
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) sink += acc[n][0];
+      asm volatile("" ::"v"(sink));
+      t4 = now();
+      tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += t3 - t2; tp[3] += t4 - t3;
+    }
 
     // ---- epilogue: acc[n][i] = <document b*32 + drowof(i) + 4h, query qid[n]> ----------------------
     const int64_t d0 = b * 32 + 4 * h;
@@ -268,33 +284,50 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
               if (d0 + 8 * g4 + e < a.ndocs) dst[8 * g4 + e] = acc[n][4 * g4 + e];
       }
     } else {
-#pragma unroll
-      for (int n = 0; n < NQT; ++n) {
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) any = any || (acc[n][i] >= tau[n]);
-        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
-        if (!any) continue;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t doc = d0 + drowof(i);
-          if (acc[n][i] >= tau[n] && doc < a.ndocs) {
-            const int slot = atomicAdd(stage_cnt, 1);  // ds_add_rtn_u32
-            if (slot < kStage) {
-              stage_score[slot] = acc[n][i];
-              stage_doc[slot] = (int32_t)(doc * a.stride);
-              stage_q[slot] = qid[n];
-            } else {
-              append_global(qid[n], acc[n][i], (int32_t)(doc * a.stride));  // staging full: slow but exact
+      // one flush opportunity per block keeps the per-element code to: compare, scalar branch, and for
+      // the few survivors popcount + mbcnt + three LDS writes (a full private area falls back to the
+      // direct global append: exact, only slow)
+      if (scnt > kStageW / 2) flush_wave();
+      const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
+      auto put = [&](int n, int i, bool pass) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+        if (bal == 0) return;
+        if (pass) {
+          const int pos = scnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          const int doc = (int32_t)((d0 + drowof(i)) * a.stride);
+          if (pos < kStageW) {
+            st_score[pos] = acc[n][i];
+            st_doc[pos] = doc;
+            st_q[pos] = qid[n];
+          } else {
+            const int slot = atomicAdd(a.count + qid[n], 1);
+            if ((unsigned)slot < (unsigned)a.cap) {
+              a.cand_score[(int64_t)qid[n] * a.cap + slot] = acc[n][i];
+              a.cand_idx[(int64_t)qid[n] * a.cap + slot] = doc;
             }
           }
         }
+        const int np = scnt + __builtin_popcountll(bal);
+        scnt = np < kStageW ? np : kStageW;
+      };
+      if (whole) {
+#pragma unroll
+        for (int n = 0; n < NQT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) put(n, i, acc[n][i] >= tau[n]);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NQT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) put(n, i, acc[n][i] >= tau[n] && d0 + drowof(i) < a.ndocs);
       }
     }
+    if (a.prof) tp[4] += now() - t4;
   }
-  if (MODE == DOT_FILTER) {
-    __syncthreads();
-    flush();
+  if (MODE == DOT_FILTER) flush_wave();
+  if (a.prof && lane == 0) {
+    unsigned long long* o = a.prof + ((int64_t)blockIdx.x * 4 + w) * 6;
+    o[0] = tp[0]; o[1] = tp[1]; o[2] = tp[2]; o[3] = tp[3]; o[4] = tp[4]; o[5] = (unsigned long long)(b_hi - b_lo);
   }
 }
 
@@ -329,14 +362,44 @@ __device__ __forceinline__ void bitonic_desc(float* key, int* val, int n2, int t
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restrict__ all, int64_t ld, int n, int n2, int m,
+// m-th largest of a row of n <= 16384 sample scores -> tau[row].  Values stay in registers (16 per
+// thread) as order-preserving integers; the answer is built bit by bit from the top: bit b is kept
+// iff at least m values are >= the candidate, one count (wave reduction + one LDS atomic per
+// wavefront) and ONE barrier per bit.  32 cheap rounds instead of the 105 passes of a full sort.
+__device__ __forceinline__ uint32_t f2ord(float f) {  // larger float <=> larger unsigned
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restrict__ all, int64_t ld, int n, int m,
                                                           float* __restrict__ tau) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* key = (float*)smem;
+  __shared__ int cnt[32];
   const int row = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < n2; i += 1024) key[i] = i < n ? all[(int64_t)row * ld + i] : -__builtin_huge_valf();
-  bitonic_desc<false>(key, nullptr, n2, tid, 1024);
-  if (tid == 0) tau[row] = key[m - 1 < n ? m - 1 : n - 1];
+  uint32_t key[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = tid + 1024 * e;
+    key[e] = i < n ? f2ord(all[(int64_t)row * ld + i]) : 0u;  // 0 sorts below every real value (incl. -inf)
+  }
+  if (tid < 32) cnt[tid] = 0;
+  __syncthreads();
+  if (m > n) m = n;
+  uint32_t x = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = x | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c += key[e] >= cand ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((tid & 63) == 0) atomicAdd(&cnt[bit], c);
+    __syncthreads();
+    if (cnt[bit] >= m) x = cand;  // uniform: every thread reads the same total
+  }
+  if (tid == 0) tau[row] = ord2f(x);
 }
 
 __global__ void __launch_bounds__(1024) topk_rows_kernel(const float* __restrict__ cand_score,
@@ -395,7 +458,7 @@ template <int DT, int NSL, int NQT, int MODE>
 static int launch_dot(const DotArgs& a0, int nq_launch, int T, hipStream_t stream) {
   DotArgs a = a0;
   constexpr int QPW = 128 * NQT;  // queries per workgroup
-  const int lds = 3 * 32 * NSL * 256 + 16 + kStage * 12;
+  const int lds = 3 * 32 * NSL * 256 + 4 * kStageW * 12;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dot_stream_kernel<DT, NSL, NQT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (31.0 * (double)a.stride * (NSL * 256) >= 4294967296.0)
@@ -487,16 +550,20 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
     int m = (int)(mt + 0.5);
     if (m < 4) m = 4;
     if (m > S) m = (int)S;
-    const int n2 = pow2_ge((int)S);
-    if ((size_t)n2 * 4 > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)sample_tau_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, n2 * 4);
-    hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(1024), (size_t)n2 * 4, stream, all, S, (int)S, n2, m, tau);
+    hipLaunchKernelGGL(sample_tau_kernel, dim3(nq), dim3(1024), 0, stream, all, S, (int)S, m, tau);
   }
   if (int e = check_launch("dot_topk threshold")) return e;
 
   // phase 2: full product + threshold filter
   if (hipMemsetAsync(count, 0, (size_t)nq * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "dot_topk: memset failed");
   a.ndocs = n_docs; a.stride = 1;
+  static unsigned long long* prof_buf = nullptr;  // MM_DOT_PROF=1: per-wavefront phase cycle counters (tools/dot_prof.py)
+  static int prof_on = -1;
+  if (prof_on < 0) prof_on = getenv("MM_DOT_PROF") ? atoi(getenv("MM_DOT_PROF")) : 0;
+  if (prof_on) {
+    if (!prof_buf && hipMalloc((void**)&prof_buf, 8 * 32 * 32 * 4 * 6 * 8) != hipSuccess) prof_buf = nullptr;
+    a.prof = prof_buf;
+  }
   {
     const int e = dtype == MM_BF16 ? launch_dot_e<MM_BF16, DOT_FILTER>(a, nq, g, stream) : launch_dot_e<MM_F16, DOT_FILTER>(a, nq, g, stream);
     if (e) return e;
@@ -506,7 +573,24 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
     (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 8);
   hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), (size_t)cap * 8, stream, cand_score, cand_idx, count, cap, k,
                      n_docs, out_scores, out_idx, status);
-  return check_launch("topk_rows_kernel");
+  if (int e = check_launch("topk_rows_kernel")) return e;
+  if (prof_on && prof_buf) {  // tools only: synchronous dump of the phase counters
+    static unsigned long long host[8 * 32 * 32 * 4 * 6];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(host, prof_buf, sizeof(host), hipMemcpyDeviceToHost);
+    const int nw = 8 * 32 * 4;  // first launch's workgroups x 4 wavefronts at most
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    int cntw = 0;
+    for (int i = 0; i < nw; ++i) {
+      if (host[i * 6 + 5] == 0) continue;
+      for (int j = 0; j < 5; ++j) sum[j] += (double)host[i * 6 + j] / (double)host[i * 6 + 5];
+      ++cntw;
+    }
+    if (cntw)
+      fprintf(stderr, "[MM_DOT_PROF] cycles per block (avg over %d wavefronts): wait_vm %.0f | barrier %.0f | flush+issue %.0f | mfma loop %.0f | epilogue %.0f\n",
+              cntw, sum[0] / cntw, sum[1] / cntw, sum[2] / cntw, sum[3] / cntw, sum[4] / cntw);
+  }
+  return MM_OK;
 }
 
 // Merge of per-shard results (the sharded index's final step): rows of n_in (score, id) pairs ->
