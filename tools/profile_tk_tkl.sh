@@ -13,7 +13,7 @@ for W in tk tkl; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o $W -- $CMD > $O/bench_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o $W -- $CMD > $O/bench_write.log 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o $W -- $CMD > $O/bench_sq.log 2>&1
-  MM_PROF_QUERIES=0 python tools/summarize_rocprof.py $O $O/summary.json "mm::" > /dev/null
+  MM_PROF_COMMAND="$CMD" python tools/summarize_rocprof.py $O $O/summary.json "mm::" > /dev/null
   find $O -name "*.db" -delete      # raw traces are tens of MB; the summary is what gets committed
   tail -1 $O/bench_trace.log
 done

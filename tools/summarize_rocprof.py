@@ -21,7 +21,9 @@ def main():
     res = {"source_dir": os.path.basename(os.path.normpath(root)), "kernel_filter": pat, "kernel_trace": [], "pmc": {},
            "workload": {"queries": int(os.environ.get("MM_PROF_QUERIES", 256)), "cands": 1000,
                         "lengths": os.environ.get("MM_PROF_LENGTHS", "full"),
-                        "command": "python bench.py --no-cpu-baseline (see tools/profile_maxsim.sh)"}}
+                        "command": os.environ.get("MM_PROF_COMMAND", "python bench.py --no-cpu-baseline (see tools/profile_maxsim.sh)")}}
+    if "MM_PROF_COMMAND" in os.environ:      # not the bench workload: drop the bench-specific keys
+        res["workload"] = {"command": os.environ["MM_PROF_COMMAND"]}
     for db in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         tag = os.path.basename(os.path.dirname(db))
         con = sqlite3.connect(db)
