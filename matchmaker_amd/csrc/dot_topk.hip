@@ -34,6 +34,7 @@
 // different query groups at about the same time, so the collection is fetched from HBM once per
 // XCD sweep and re-read from that XCD's L2.
 #include "mm_internal.h"
+#include <type_traits>
 
 namespace mm {
 
@@ -129,7 +130,7 @@ __device__ __forceinline__ void dot_wait() {
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int NSL, int NQT, int MODE>
+template <int DT, int NSL, int NQT, int MODE, bool PROF = false>
 __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   constexpr int NBUF = 3;
   constexpr int RB = NSL * 256;        // bytes per document row
@@ -228,14 +229,14 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   for (int64_t b = b_lo; b < b_hi; ++b) {
     // this wavefront's part of block b has landed once at most the younger block's PER loads pend
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    if (a.prof) t0 = now();
+    if (PROF) t0 = now();
     if (b + 1 < b_hi) dot_wait<PER>(); else dot_wait<0>();
-    if (a.prof) t1 = now();
+    if (PROF) t1 = now();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
-    if (a.prof) t2 = now();
+    if (PROF) t2 = now();
     if (b + 2 < b_hi) issue(b + 2, slot_i == 0 ? 2 : slot_i - 1);  // into the slot block b - 1 used
 
-    if (a.prof) t3 = now();
+    if (PROF) t3 = now();
     f32x16 acc[NQT];
 #pragma unroll
     for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     // A fragments are fetched AHEAD steps ahead of the MFMAs that use them (one wavefront per SIMD:
     // nothing else hides the ~100-cycle LDS latency); the group barriers pin the order
     // {1 LDS read, NQT MFMAs} so the compiler does not fold the reads back next to their uses
-    constexpr int STEPS = NSL * 8, AHEAD = (NSL * 8 > 6) ? 6 : 3;
+    constexpr int STEPS = NSL * 8, AHEAD = 3;
     short8 av[AHEAD + 1];
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) av[s] = *(const short8*)(buf + (s >> 3) * 8192 + lo[s & 7]);
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
     }
     slot_i = slot_i == NBUF - 1 ? 0 : slot_i + 1;
-    if (a.prof) {
+    if (PROF) {
       // force the accumulators to be complete before the stamp
       float sink = 0.0f;
 #pragma unroll
@@ -289,8 +290,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       // direct global append: exact, only slow)
       if (scnt > kStageW / 2) flush_wave();
       const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
-      auto put = [&](int n, int i, bool pass) {
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass);
+      auto put = [&](int n, int i, unsigned long long bal, bool pass) {
         if (bal == 0) return;
         if (pass) {
           const int pos = scnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -310,22 +310,40 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
         const int np = scnt + __builtin_popcountll(bal);
         scnt = np < kStageW ? np : kStageW;
       };
-      if (whole) {
+      // all compares of a tile first (each v_cmp leaves its ballot in an SGPR pair), then the scalar
+      // tests: a compare immediately followed by a branch on its result pays the VALU->SALU hazard
+      // and a taken-branch bubble per element (2.5 k cycles per block in the first version)
+      auto tiles = [&](auto whole_c) {
+        constexpr bool W = decltype(whole_c)::value;
 #pragma unroll
-        for (int n = 0; n < NQT; ++n)
+        for (int n = 0; n < NQT; ++n) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) put(n, i, acc[n][i] >= tau[n]);
-      } else {
+          for (int half = 0; half < 2; ++half) {  // 8 elements at a time: 8 SGPR pairs + 8 VGPR copies live
+            unsigned long long bal[8];
+            bool pass[8];
 #pragma unroll
-        for (int n = 0; n < NQT; ++n)
+            for (int e = 0; e < 8; ++e) {
+              const int i = 8 * half + e;
+              pass[e] = acc[n][i] >= tau[n];
+              if (!W) pass[e] = pass[e] && (d0 + drowof(i) < a.ndocs);
+              bal[e] = __builtin_amdgcn_ballot_w64(pass[e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long any = 0;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) put(n, i, acc[n][i] >= tau[n] && d0 + drowof(i) < a.ndocs);
-      }
+            for (int e = 0; e < 8; ++e) any |= bal[e];
+            if (any == 0) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) put(n, 8 * half + e, bal[e], pass[e]);
+          }
+        }
+      };
+      if (whole) tiles(std::true_type{}); else tiles(std::false_type{});
     }
-    if (a.prof) tp[4] += now() - t4;
+    if (PROF) tp[4] += now() - t4;
   }
   if (MODE == DOT_FILTER) flush_wave();
-  if (a.prof && lane == 0) {
+  if (PROF && lane == 0) {
     unsigned long long* o = a.prof + ((int64_t)blockIdx.x * 4 + w) * 6;
     o[0] = tp[0]; o[1] = tp[1]; o[2] = tp[2]; o[3] = tp[3]; o[4] = tp[4]; o[5] = (unsigned long long)(b_hi - b_lo);
   }
@@ -468,6 +486,14 @@ static int launch_dot(const DotArgs& a0, int nq_launch, int T, hipStream_t strea
     const int nq_here = nq_launch - qb < 32 * QPW ? nq_launch - qb : 32 * QPW;
     a.G = (nq_here + QPW - 1) / QPW;
     a.q_base = a0.q_base + qb;
+    if constexpr (NSL == 6 && NQT == 2 && MODE == DOT_FILTER) {
+      if (a.prof) {  // tools only (MM_DOT_PROF=1): the instantiation that carries the s_memtime stamps
+        (void)hipFuncSetAttribute((const void*)dot_stream_kernel<DT, NSL, NQT, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((dot_stream_kernel<DT, NSL, NQT, MODE, true>), dim3(8 * a.G * a.T), dim3(256), lds, stream, a);
+        if (int e = check_launch("dot_stream_kernel<prof>")) return e;
+        continue;
+      }
+    }
     hipLaunchKernelGGL((dot_stream_kernel<DT, NSL, NQT, MODE>), dim3(8 * a.G * a.T), dim3(256), lds, stream, a);
     if (int e = check_launch("dot_stream_kernel")) return e;
   }
