@@ -154,6 +154,23 @@ int mm_kernel_pool_fwd(const void* q, const void* d,
                        int Q, int D, int E, int K, int dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of mm_kernel_pool_fwd in the pair-per-row layout (training: train.py:347-348, loss.backward()
+ * :503-524; the embedding model is called from neuralIR_encoder.py:86-87).  Gradients of the score w.r.t.
+ * the contextualised embeddings and the two trainable pooling parameters (kernel_alpha_scaler
+ * ecai20_tk.py:85, kernel_bin_weights :81); mu / sigma are buffers.
+ *   grad_out [n_pairs]; grad_q [n_pairs, Q, E], grad_d [n_pairs, D, E] float32;
+ *   grad_alpha, grad_w [n_pairs, K]: per-pair contributions (sum over pairs on the host side:
+ *   deterministic, no atomics). */
+size_t mm_kernel_pool_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind);
+
+int mm_kernel_pool_bwd(const void* q, const void* d,
+                       const void* q_mask, int q_mask_kind,
+                       const void* d_mask, int d_mask_kind,
+                       const float* mu, const float* sigma, const float* alpha, const float* w,
+                       const float* grad_out, float* grad_q, float* grad_d, float* grad_alpha, float* grad_w,
+                       int64_t n_pairs, int Q, int D, int E, int K,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * TKL: match + RBF kernels per document position, sliding-window (30, stride 2) pooling with
  * learned saturation, per-window score; then top-3 non-overlapping region scoring.

@@ -30,6 +30,9 @@ SIGNATURES = {
     "mm_kernel_pool_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
     "mm_kernel_pool_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                 _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_kernel_pool_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
+    "mm_kernel_pool_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_dot_topk_workspace_bytes": (_sz, [_i64, _i, _i]),
     "mm_dot_topk_fwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _c.c_float, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mm_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

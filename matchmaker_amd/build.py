@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmm_native.so")
-SOURCES = ["common.hip", "maxsim.hip", "kernel_pool.hip", "tkl.hip", "dot_topk.hip"]
+SOURCES = ["common.hip", "maxsim.hip", "kernel_pool.hip", "kernel_pool_bwd.hip", "tkl.hip", "dot_topk.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
 
 

@@ -237,6 +237,43 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     return (out, pk) if return_per_kernel else out
 
 
+def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
+                    mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor, grad_out: torch.Tensor):
+    """Backward of kernel_pool in the pair-per-row layout (mm_kernel_pool_bwd).  Returns float32
+    (grad_q [B,Q,E], grad_d [B,D,E], grad_alpha [K], grad_w [K])."""
+    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, grad_out)
+    q, d = _emb(q, "q"), _emb(d, "d")
+    if q.dtype != torch.float32 or d.dtype != torch.float32:
+        raise NativeError("kernel_pool_bwd: float32 embeddings only")
+    B, Q, E = q.shape
+    B2, D, E2 = d.shape
+    if B != B2 or E != E2:
+        raise NativeError(f"kernel_pool_bwd needs the pair-per-row layout: q {tuple(q.shape)} vs d {tuple(d.shape)}")
+    K = mu.numel()
+    f = lambda t: t.detach().reshape(-1).to(torch.float32).contiguous()
+    mu, sigma, alpha, w = f(mu), f(sigma), f(alpha), f(w)
+    go = f(grad_out)
+    if go.numel() != B:
+        raise NativeError(f"grad_out has {go.numel()} elements for {B} pairs")
+    qm, qp, qk = _mask(q_mask, B, Q, "q_mask")
+    dm, dp, dk = _mask(d_mask, B, D, "d_mask")
+    L = _lib.lib()
+    gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
+    gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
+    ga = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    gw = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    if B:
+        with torch.cuda.device(dev):
+            wsb = L.mm_kernel_pool_bwd_workspace_bytes(B, Q, D, qk, dk)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+            rc = L.mm_kernel_pool_bwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, mu.data_ptr(), sigma.data_ptr(),
+                                      alpha.data_ptr(), w.data_ptr(), go.data_ptr(), gq.data_ptr(), gd.data_ptr(),
+                                      ga.data_ptr(), gw.data_ptr(), B, Q, D, E, K,
+                                      ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+        _lib.check(rc, "mm_kernel_pool_bwd")
+    return gq, gd, ga.sum(0), gw.sum(0)
+
+
 def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor, chunk_slot: torch.Tensor,
               q_mask: torch.Tensor, params: torch.Tensor, B: int, C: int, K: int, saturation: str = "embedding",
               return_windows: bool = False):

@@ -28,7 +28,8 @@ def sinusoid_positions(dim: int, length: int, min_timescale: float = 1.0, max_ti
 
 
 class _KernelPoolFn(torch.autograd.Function):
-    """Native forward; backward re-derives the block with torch ops on the device (training only)."""
+    """Native forward (mm_kernel_pool_fwd) and native backward (mm_kernel_pool_bwd) of the pooling block
+    for the training path (train.py:347-348 / :503-524)."""
 
     @staticmethod
     def forward(ctx, q, d, q_mask, d_mask, mu, sigma, alpha, w):
@@ -38,17 +39,7 @@ class _KernelPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         q, d, q_mask, d_mask, mu, sigma, alpha, w = ctx.saved_tensors
-        with torch.enable_grad():
-            leaves = [t.detach().requires_grad_(True) for t in (q, d, alpha, w)]
-            q_, d_, a_, w_ = leaves
-            qn = q_ / (q_.norm(p=2, dim=-1, keepdim=True) + 1e-13)
-            dn = d_ / (d_.norm(p=2, dim=-1, keepdim=True) + 1e-13)
-            cos = torch.bmm(qn, dn.transpose(-1, -2)).unsqueeze(-1)
-            k = torch.exp(-(cos - mu.view(1, 1, 1, -1)) ** 2 / (2 * sigma.view(1, 1, 1, -1) ** 2))
-            pkq = (k * d_mask.unsqueeze(1).unsqueeze(-1)).sum(2)
-            lg = torch.log(torch.clamp(pkq * a_.view(1, 1, -1), min=1e-10)) * q_mask.unsqueeze(-1)
-            s = lg.sum(1) @ w_.view(-1)
-            gq, gd, ga, gw = torch.autograd.grad(s, leaves, g)
+        gq, gd, ga, gw = ops.kernel_pool_bwd(q, d, q_mask, d_mask, mu, sigma, alpha, w, g)
         return gq, gd, None, None, None, None, ga.view_as(alpha), gw.view_as(w)
 
 

@@ -101,3 +101,51 @@ def test_kernel_pool_config1_scale_properties():
                            (np.arange(D)[None] < d_len[sel.to(dev)].cpu().numpy()[:, None]),
                            MU, SIGMA, p[2].cpu().numpy(), p[3].cpu().numpy(), dtype=np.float64)
     np.testing.assert_allclose(out[sel.to(dev)].cpu().numpy(), ref, atol=util.TOL_FP32)
+
+
+@pytest.mark.parametrize("B,Q,D,E", [(4, 20, 200, 300), (3, 30, 47, 64), (2, 5, 3, 8), (3, 33, 70, 128)])
+def test_kernel_pool_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
+    """mm_kernel_pool_bwd vs autograd through the torch port of ecai20_tk.py:105-124 (CPU, float64 and
+    float32), incl. the two trainable pooling parameters, and through the drop-in's autograd function."""
+    from matchmaker_amd import ops
+    from oracle import torch_port as TP
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(B * 100 + D)
+    q = torch.randn(B, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    for b in range(B):                                    # near matches so that the high-mu kernels carry gradient
+        d[b, b % D] = q[b, b % Q] * 1.3 + 0.05 * torch.randn(E, generator=g)
+    q_len = torch.randint(1, Q + 1, (B,), generator=g)
+    d_len = torch.randint(1, D + 1, (B,), generator=g)
+    d_len[0] = D
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D)[None] < d_len[:, None]).float()
+    if D > 2:
+        dm[0, 1] = 0.0                                    # a hole
+    alpha = torch.rand(11, generator=g) + 0.5
+    w = torch.randn(11, generator=g) * 0.3
+    go = torch.randn(B, generator=g)
+    mu, sigma = torch.tensor(MU), torch.tensor(SIGMA)
+
+    def ref(dtype):
+        leaves = [t.detach().to(dtype).clone().requires_grad_(True) for t in (q, d, alpha, w)]
+        q_, d_, a_, w_ = leaves
+        s = TP.tk_kernel_pool(q_, d_, qm.to(dtype), dm.to(dtype), mu.to(dtype).view(1, 1, 1, -1),
+                              sigma.to(dtype).view(1, 1, 1, -1), a_.view(1, 1, -1), w_.view(1, -1))
+        s.backward(go.to(dtype))
+        return [t.grad for t in leaves]
+
+    r64 = ref(torch.float64)
+    gq, gd, ga, gw = ops.kernel_pool_bwd(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev),
+                                         alpha.to(dev), w.to(dev), go.to(dev))
+    for got, want, name in ((gq, r64[0], "grad_q"), (gd, r64[1], "grad_d"), (ga, r64[2], "grad_alpha"), (gw, r64[3], "grad_w")):
+        want = want.numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), want, atol=2e-4 * scale, rtol=2e-3, err_msg=name)
+    # through the drop-in's autograd function (what train.py's loss.backward() reaches)
+    from matchmaker_amd.tk import _KernelPoolFn
+    leaves = [t.to(dev).requires_grad_(True) for t in (q, d, alpha, w)]
+    s = _KernelPoolFn.apply(leaves[0], leaves[1], qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev), leaves[2], leaves[3])
+    (s * go.to(dev)).sum().backward()
+    np.testing.assert_allclose(leaves[0].grad.cpu().numpy(), gq.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(leaves[3].grad.cpu().numpy(), gw.cpu().numpy(), atol=1e-6)
