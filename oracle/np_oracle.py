@@ -143,6 +143,27 @@ def tk_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, dtype=np.float32,
     return score
 
 
+def knrm_kernel_pool(q, d, q_mask, d_mask, mu, sigma, w, dtype=np.float32, return_per_kernel=False):
+    """KNRM.forward scoring block — matchmaker/models/knrm.py:55-84 (q, d already multiplied by their
+    masks by forward_representation, :94-95).  mu, sigma [K]; w = dense.weight[0] [K]."""
+    qm = np.asarray(q_mask, dtype=dtype)
+    dm = np.asarray(d_mask, dtype=dtype)
+    qd = qm[:, :, None] * dm[:, None, :]                                         # :55 query_by_doc_mask
+    cos = cosine_matrix(q, d, dtype) * qd                                        # :62-63
+    mu = np.asarray(mu, dtype=dtype).reshape(1, 1, 1, -1)
+    sigma = np.asarray(sigma, dtype=dtype).reshape(1, 1, 1, -1)
+    raw = np.exp(-np.power(cos[..., None] - mu, 2) / (2 * np.power(sigma, 2)))   # :71
+    masked = raw * qd[..., None]                                                 # :72
+    pkq = masked.sum(2, dtype=dtype)                                             # :74
+    lg = np.log(np.maximum(pkq, dtype(1e-10))) * dtype(0.01)                     # :75
+    lg = lg * qm[..., None]                                                      # :76
+    per_kernel = lg.sum(1, dtype=dtype)                                          # :78
+    score = per_kernel @ np.asarray(w, dtype=dtype).reshape(-1)                  # :84
+    if return_per_kernel:
+        return score, per_kernel
+    return score
+
+
 # ----------------------------------------------------------------------------- TKL
 
 TKL_CHUNK = 40       # sigir20_tkl.py:52

@@ -162,6 +162,24 @@ def tk_forward(model, q, d, q_mask, d_mask, secondary=False):
         return model.forward(q, d, q_mask, d_mask, secondary)
 
 
+# --------------------------------------------------------------------------- KNRM
+def make_knrm(n_kernels=11, seed=0):
+    """Real KNRM (matchmaker/models/knrm.py); its constructor builds mu/sigma with torch.cuda.FloatTensor
+    (:31-32), aliased to the CPU type by install_shims()."""
+    install_shims()
+    from matchmaker.models.knrm import KNRM
+
+    torch.manual_seed(seed)
+    m = KNRM(n_kernels)
+    m.eval()
+    return m
+
+
+def knrm_forward(model, q, d, q_mask, d_mask, secondary=False):
+    with torch.no_grad():
+        return model.forward(q, d, q_mask, d_mask, secondary)
+
+
 # --------------------------------------------------------------------------- TKL
 def make_tkl(embsize=300, mu=TK_MU, sigma=TK_SIGMA, saturation_type="embedding",
              bypass_contextualizer=True, seed=0, att_heads=10, att_layer=2, att_ff_dim=300,

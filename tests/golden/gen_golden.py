@@ -104,6 +104,30 @@ def gen_tk():
                         score=score.numpy(), per_kernel=sec["per_kernel"].numpy())
 
 
+def gen_knrm():
+    # KNRM (knrm.py:44-92): 11 kernels incl. the exact-match one (sigma 1e-4); word-embedding-like inputs
+    g = torch.Generator().manual_seed(1101)
+    B, Q, D, E = 5, 14, 60, 300
+    q = fp16_round(torch.randn(B, Q, E, generator=g))
+    d = fp16_round(torch.randn(B, D, E, generator=g))
+    d[0, 3] = q[0, 1]                                          # exact matches feed the sigma = 1e-4 kernel
+    d[1, 7] = q[1, 0]
+    d[1, 8] = fp16_round(q[1, 2] + 0.05 * torch.randn(E, generator=g))
+    q_len = torch.tensor([14, 3, 9, 1, 14])
+    d_len = torch.tensor([60, 20, 1, 33, 0])
+    qm = prefix_mask(q_len, Q, torch.float32)
+    dm = prefix_mask(d_len, D, torch.float32)
+    m = R.make_knrm(11, seed=7)
+    q_in, d_in = m.forward_representation(q, qm), m.forward_representation(d, dm)     # knrm.py:94-95
+    score, sec = R.knrm_forward(m, q_in, d_in, qm, dm, secondary=True)
+    np.savez_compressed(os.path.join(OUT, "knrm_q14_d60_e300.npz"),
+                        q_fp16=q_in.to(torch.float16).numpy(), d_fp16=d_in.to(torch.float16).numpy(),
+                        q_mask=qm.numpy(), d_mask=dm.numpy(),
+                        mu=m.mu.numpy().reshape(-1), sigma=m.sigma.numpy().reshape(-1),
+                        w=m.dense.weight.detach().numpy().reshape(-1),
+                        score=score.numpy(), per_kernel=sec["per_kernel"].numpy())
+
+
 def gen_tkl():
     for name, (B, Q, D, E, heads, seed, sat) in {
         "tkl_d333_e300_embedding": (2, 20, 333, 300, 10, 3003, "embedding"),
@@ -148,6 +172,7 @@ def gen_tkl():
 if __name__ == "__main__":
     gen_colbert()
     gen_tk()
+    gen_knrm()
     gen_tkl()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -149,3 +149,36 @@ def test_kernel_pool_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
     (s * go.to(dev)).sum().backward()
     np.testing.assert_allclose(leaves[0].grad.cpu().numpy(), gq.cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(leaves[3].grad.cpu().numpy(), gw.cpu().numpy(), atol=1e-6)
+
+
+def test_knrm_dropin_matches_reference_golden_and_trains():
+    """matchmaker_amd.knrm.KNRM (native pooling) vs the real KNRM.forward outputs (knrm.py:44-92), and its
+    backward vs autograd through the oracle's torch port of the same ops."""
+    from matchmaker_amd.knrm import KNRM
+    from oracle import torch_port as TP
+    dev = util.require_gpu()
+    g = util.load("knrm_q14_d60_e300.npz")
+    m = KNRM(11).to(dev)
+    with torch.no_grad():
+        m.dense.weight.copy_(_t(g["w"], dev).view(1, -1))
+    q, d, qm, dm = (_t(g[k], dev) for k in ("q", "d", "q_mask", "d_mask"))
+    with torch.no_grad():
+        score, sec = m(q, d, qm, dm, output_secondary_output=True)
+    np.testing.assert_allclose(score.cpu().numpy(), g["score"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(sec["per_kernel"].cpu().numpy(), g["per_kernel"], atol=2e-4, rtol=1e-4)
+    # training: gradients w.r.t. the embeddings and dense.weight
+    qg = q.clone().requires_grad_(True)
+    dg = d.clone().requires_grad_(True)
+    go = torch.linspace(-1, 1, q.shape[0], device=dev)
+    (m(qg, dg, qm, dm) * go).sum().backward()
+    qc = q.cpu().double().requires_grad_(True)
+    dc = d.cpu().double().requires_grad_(True)
+    wc = torch.from_numpy(g["w"]).double().requires_grad_(True)
+    s = TP.tk_kernel_pool(qc, dc, qm.cpu().double(), dm.cpu().double(), torch.from_numpy(g["mu"]).double().view(1, 1, 1, -1),
+                          torch.from_numpy(g["sigma"]).double().view(1, 1, 1, -1), torch.ones(1, 1, 11, dtype=torch.float64),
+                          (wc * 0.01).view(1, -1))
+    (s * go.cpu().double()).sum().backward()
+    for got, want, name in ((qg.grad, qc.grad, "q"), (dg.grad, dc.grad, "d"), (m.dense.weight.grad.view(-1), wc.grad, "w")):
+        want = want.numpy()
+        scale = max(1e-3, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), want, atol=5e-4 * scale, rtol=5e-3, err_msg=name)
