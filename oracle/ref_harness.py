@@ -180,6 +180,17 @@ def knrm_forward(model, q, d, q_mask, d_mask, secondary=False):
         return model.forward(q, d, q_mask, d_mask, secondary)
 
 
+def make_conv_knrm(embsize=300, n_grams=3, n_kernels=11, conv_out_dim=128, seed=0):
+    """Real Conv_KNRM (matchmaker/models/conv_knrm.py)."""
+    install_shims()
+    from matchmaker.models.conv_knrm import Conv_KNRM
+
+    torch.manual_seed(seed)
+    m = Conv_KNRM(embsize, n_grams, n_kernels, conv_out_dim)
+    m.eval()
+    return m
+
+
 # --------------------------------------------------------------------------- TKL
 def make_tkl(embsize=300, mu=TK_MU, sigma=TK_SIGMA, saturation_type="embedding",
              bypass_contextualizer=True, seed=0, att_heads=10, att_layer=2, att_ff_dim=300,

@@ -128,6 +128,27 @@ def gen_knrm():
                         score=score.numpy(), per_kernel=sec["per_kernel"].numpy())
 
 
+def gen_conv_knrm():
+    # Conv-KNRM (conv_knrm.py:63-173): 3 n-gram convolutions (out dim 128) -> 9 match matrices x 11 kernels
+    g = torch.Generator().manual_seed(1201)
+    B, Q, D, E = 4, 12, 50, 64
+    q_len = torch.tensor([12, 3, 7, 12])
+    d_len = torch.tensor([50, 20, 5, 0])
+    qm = prefix_mask(q_len, Q, torch.float32)
+    dm = prefix_mask(d_len, D, torch.float32)
+    q = fp16_round(torch.randn(B, Q, E, generator=g)) * qm.unsqueeze(-1)        # embeddings arrive masked
+    d = fp16_round(torch.randn(B, D, E, generator=g)) * dm.unsqueeze(-1)
+    d[0, 3] = q[0, 1]
+    d[0, 4] = q[0, 2]                                          # a matching bigram
+    m = R.make_conv_knrm(E, 3, 11, 128, seed=9)
+    with torch.no_grad():
+        score = m.forward(q, d, qm, dm)
+    sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "conv_knrm_q12_d50_e64.npz"),
+                        q_fp16=q.to(torch.float16).numpy(), d_fp16=d.to(torch.float16).numpy(),
+                        q_mask=qm.numpy(), d_mask=dm.numpy(), score=score.numpy(), **sd)
+
+
 def gen_tkl():
     for name, (B, Q, D, E, heads, seed, sat) in {
         "tkl_d333_e300_embedding": (2, 20, 333, 300, 10, 3003, "embedding"),
@@ -173,6 +194,7 @@ if __name__ == "__main__":
     gen_colbert()
     gen_tk()
     gen_knrm()
+    gen_conv_knrm()
     gen_tkl()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

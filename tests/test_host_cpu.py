@@ -195,3 +195,28 @@ def test_token_store_reads_the_reference_layout(tmp_path):
         ref = np.asarray(storage[f][a:z])
         got = st.tokens[int(b[i]): int(e[i])].numpy()
         assert np.array_equal(ref, got) and np.array_equal(ref, docs[i][:-2])
+
+
+def test_conv_knrm_block_decomposition_matches_the_real_class():
+    """Conv_KNRM's concat + dense (conv_knrm.py:132-137) as a sum over (i, t) blocks of KNRM-style pooling with
+    weight slices: checked on CPU with the drop-in's own (torch) convolutions + the numpy oracle against the
+    real class's golden scores — the decomposition the native path (matchmaker_amd/conv_knrm.py) relies on."""
+    from tests import util
+    from matchmaker_amd.conv_knrm import Conv_KNRM
+    g = util.load("conv_knrm_q12_d50_e64.npz")
+    m = Conv_KNRM(64, 3, 11, 128)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")})
+    q, d = torch.from_numpy(g["q"]), torch.from_numpy(g["d"])
+    with torch.no_grad():
+        qg = [c(q.transpose(1, 2)).transpose(1, 2).numpy() for c in m.convolutions]
+        dg = [c(d.transpose(1, 2)).transpose(1, 2).numpy() for c in m.convolutions]
+    w = g["param.dense.weight"].reshape(-1)
+    mu, sigma = m.mu.view(-1).numpy(), m.sigma.view(-1).numpy()
+    assert abs(float(sigma[0]) - 1e-3) < 1e-9          # conv_knrm's exact-match sigma (KNRM: 1e-4)
+    score = np.zeros(q.shape[0], np.float32)
+    blk = 0
+    for a in qg:
+        for b in dg:
+            score += O.knrm_kernel_pool(a, b, g["q_mask"], g["d_mask"], mu, sigma, w[blk * 11:(blk + 1) * 11])
+            blk += 1
+    np.testing.assert_allclose(score, g["score"], atol=2e-5, rtol=1e-4)
