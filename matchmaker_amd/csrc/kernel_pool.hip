@@ -714,6 +714,278 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// TKL stage 1, grouped (the default TKL path for E == 100*NS, Q <= 32).
+//
+// A chunk contributes its 40 centre rows = one full 32-row MFMA block + an 8-row remainder that costs
+// a full block of split / MFMA / LDS-DMA work.  Up to four consecutive packed chunks of the SAME
+// document (same query) are therefore treated as one virtual document of 40n rows: n = 4 gives exactly
+// five full blocks instead of eight.  LDS-DMA sources are per-lane addresses anyway, so virtual row i
+// simply maps to row 5 + i % 40 of chunk p + i / 40; position pairs never straddle a chunk (40 is even).
+// Every pair of every chunk of the run is written (zeros where the mask says padding), so stage 2 needs
+// no per-chunk block count.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sload4_u32(const void* base, int64_t idx, uint32_t (&v)[4]) {
+  const uint32_t* p = (const uint32_t*)base + idx;
+  asm volatile(
+      "s_load_dword %0, %4, 0x0\n\t"
+      "s_load_dword %1, %4, 0x4\n\t"
+      "s_load_dword %2, %4, 0x8\n\t"
+      "s_load_dword %3, %4, 0xc\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]), "=&s"(v[3])
+      : "s"(p));
+}
+
+// Epilogue of block t of a run: pairs of virtual rows (i0, i0 + 1), i0 = 32t + rowof(2ip) + 4h, belong
+// to chunk i0 / 40, pair (i0 % 40) / 2.  rows_blk = rows of this block that exist (multiple of 8).
+template <int K>
+__device__ __forceinline__ void tkl_block_run(float* ps_run, int Q, int t, int rows_blk, int r, int h, const f32x16& acc,
+                                              const float (&rdr)[16], float rq, uint32_t vbits, const Rbf& rbf) {
+  constexpr int KC = K + 1;
+  constexpr int KP = (K + 1) / 2;
+  static_assert(KC % 4 == 0 && K % 2 == 1, "K kernels + the count channel must fill whole float4s");
+#pragma unroll
+  for (int ip = 0; ip < 8; ++ip) {
+    if (rowof(2 * ip) < rows_blk) {  // wave-uniform (rows_blk is a multiple of 8, rowof(2ip) + 4h + 1 < its 8-row group end)
+      f32x2 o2[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) o2[k] = f32x2{0.0f, 0.0f};
+      float cnt = 0.0f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int i = 2 * ip + half;
+        float c = (acc[i] * rq) * rdr[i];
+        c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;  // masked: every kernel underflows to exactly 0 (:194)
+        const f32x2 cc = {c, c};
+        f32x2 any2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+          const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+          const f32x2 av = -(sv * sv);
+          const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+          o2[kp] += e;
+          any2 += e;
+        }
+        cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;  // (:210)
+      }
+      const int i0 = 32 * t + rowof(2 * ip) + 4 * h;
+      const int ci = (i0 * 205) >> 13;  // i0 / 40 for i0 < 400
+      const int u = (i0 - 40 * ci) >> 1;
+      if (r < Q) {
+        f32x4* dst = (f32x4*)(ps_run + (int64_t)ci * (20 * Q * KC) + ((int64_t)u * Q + r) * KC);
+#pragma unroll
+        for (int v = 0; v < KC / 4 - 1; ++v) dst[v] = f32x4{o2[2 * v][0], o2[2 * v][1], o2[2 * v + 1][0], o2[2 * v + 1][1]};
+        dst[KC / 4 - 1] = f32x4{o2[KP - 2][0], o2[KP - 2][1], o2[KP - 1][0], cnt};
+      }
+    }
+  }
+}
+
+template <int NS, int K, int NBUF, bool NT>
+__global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
+  static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  constexpr int E = 100 * NS;
+  constexpr int RB = E * 4;  // row bytes
+  const int Q = a.Q;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* rdbuf = (float*)(smem + NBUF * kSliceBytes);
+
+  // slice image: slot s = 64n + lane -> (row, 16-B column) of the 32-row x 25-chunk slice
+  int srow[kSliceInstr];
+  uint32_t scol[kSliceInstr];
+#pragma unroll
+  for (int n = 0; n < kSliceInstr; ++n) {
+    int s = 64 * n + lane;
+    if (s > 32 * kSC - 1) s = 32 * kSC - 1;
+    srow[n] = s / kSC;
+    scol[n] = (uint32_t)((s - srow[n] * kSC) * 16);
+  }
+  const uint32_t a_off = (uint32_t)(r * (kSC * 16) + h * 32);
+  const uint32_t l_off = (uint32_t)(r * (kSC * 16) + 24 * 16);
+
+  Rbf rbf;
+  load_rbf<K>(a.mu, a.sigma, nullptr, nullptr, rbf);
+
+  const char* dbase = (const char*)a.d;
+  // run of up to 4 consecutive packed chunks of one document starting at chunk p (inside [p, p1))
+  auto run_len = [&](int64_t p) -> int {
+    if (p + 4 <= a.n_pairs) {
+      uint32_t sl[4];
+      sload4_u32(a.chunk_slot, p, sl);
+      const int b0 = (int)sl[0] / a.C;
+      int n = 1;
+      while (n < 4 && p + n < p1 && (int)sl[n] / a.C == b0) ++n;
+      return n;
+    }
+    const int b0 = (int)sload_u32(a.chunk_slot, p) / a.C;
+    int n = 1;
+    while (n < 4 && p + n < p1 && (int)sload_u32(a.chunk_slot, p + n) / a.C == b0) ++n;
+    return n;
+  };
+
+  // ---- producer cursor over (run, block, slice) ------------------------------------------------
+  int64_t pp = p0;
+  int prun = run_len(pp), pn = (40 * prun + 31) >> 5, pt = 0, ps = 0;
+  uint32_t vrun[kSliceInstr];
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      if (ps == 0) {  // source offsets of block pt of the run: virtual row i -> chunk i / 40, row 5 + i % 40
+        const int last = 40 * prun - 1;
+#pragma unroll
+        for (int n = 0; n < kSliceInstr; ++n) {
+          int i = 32 * pt + srow[n];
+          i = i < last ? i : last;  // rows past the run re-read its last row (excluded by the masks)
+          const int ci = (i * 205) >> 13;
+          vrun[n] = (uint32_t)((ci * 50 + 5 + (i - 40 * ci)) * RB) + scol[n];
+        }
+      }
+      const char* g = dbase + pp * 50 * (int64_t)RB + ps * (kSC * 16);
+      issue_slice<NT>(g, vrun, 0u, false, lds0 + (uint32_t)pbuf * kSliceBytes);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (++ps == NS) {
+        ps = 0;
+        if (++pt == pn) {
+          pt = 0;
+          pp += prun;
+          if (pp < p1) {
+            prun = run_len(pp);
+            pn = (40 * prun + 31) >> 5;
+          }
+        }
+      }
+    }
+  };
+  top_up();
+
+  bf16x8 qhi[NS][kSplitSteps], qlo[NS][kSplitSteps], qhiL, qloL;
+  float rq = 0.0f;
+  int64_t cur_q = -1;
+
+  for (int64_t pair = p0; pair < p1;) {
+    const int crun = run_len(pair);
+    const int nb = (40 * crun + 31) >> 5;
+    const int64_t qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
+    if (qi != cur_q) {
+      cur_q = qi;
+      const int qr = r < Q ? r : Q - 1;
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
+      float ss = 0.0f;
+      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        f32x4 raw[13];
+        load_q_slice_split(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw);
+#pragma unroll
+        for (int p = 0; p < kSplitSteps; ++p) {
+          split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
+          ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
+        }
+        if (h == 0) ss += sumsq4(raw[12]);
+        if (h == (s >> 1)) park[s & 1] = raw[12];
+      }
+      split8(park[0], park[1], qhiL, qloL);
+      ss += __shfl_xor(ss, 32, 64);
+      rq = 1.0f / (sqrtf(ss) + 1e-13f);
+    }
+    float* ps_run = a.ps_out + pair * (20 * (int64_t)Q * (K + 1));
+
+    for (int t = 0; t < nb; ++t) {
+      f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+      f32x2 ss2 = {0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        top_up();
+        wait_slices(inflight - 1);
+        const char* buf = smem + cbuf * kSliceBytes;
+        f32x4 x[13];
+#pragma unroll
+        for (int p = 0; p < kSplitSteps; ++p) {
+          x[2 * p] = *(const f32x4*)(buf + a_off + p * 64);
+          x[2 * p + 1] = *(const f32x4*)(buf + a_off + p * 64 + 16);
+        }
+        x[12] = *(const f32x4*)(buf + l_off);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ah, al;
+        split8(x[0], x[1], ah, al);
+#pragma unroll
+        for (int p = 0; p < kSplitSteps; ++p) {
+          bf16x8 nh = ah, nl = al;
+          if (p + 1 < kSplitSteps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
+          acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
+          acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
+          acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
+          acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
+          {
+            const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
+            const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
+            ss2 += a0 * a0;
+            ss2 += a1 * a1;
+            ss2 += b0 * b0;
+            ss2 += b1 * b1;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+          }
+          ah = nh;
+          al = nl;
+        }
+        const f32x4 xl = x[12];
+        if (h == 0) ss2 += f32x2{xl[0] * xl[0] + xl[1] * xl[1], xl[2] * xl[2] + xl[3] * xl[3]};
+        if (h == (s >> 1)) park[s & 1] = xl;
+        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+        --inflight;
+      }
+      {
+        bf16x8 ah, al;
+        split8(park[0], park[1], ah, al);
+        acc_hh = mfma_bf16(ah, qhiL, acc_hh);
+        acc_lh = mfma_bf16(al, qhiL, acc_lh);
+        acc_xl = mfma_bf16(ah, qloL, acc_xl);
+        acc_xl = mfma_bf16(al, qloL, acc_xl);
+      }
+      float ss = ss2[0] + ss2[1];
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      float rdr[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
+        rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
+      }
+      // validity bits of virtual rows 32t .. 32t+31: they span at most two chunks of the run
+      const int i0 = 32 * t;
+      const int c0 = (i0 * 205) >> 13, r0 = i0 - 40 * c0;
+      uint32_t va;
+      {
+        const uint32_t w0 = sload_u32(a.dm.bits, (pair + c0) * 2), w1 = sload_u32(a.dm.bits, (pair + c0) * 2 + 1);
+        const unsigned long long b0 = ((unsigned long long)(w1 & 0xffu) << 32) | w0;
+        va = (uint32_t)(b0 >> r0);
+        const int n0 = 40 - r0;  // rows of this block that come from chunk c0 (when < 32)
+        if (n0 < 32 && c0 + 1 < crun) va |= sload_u32(a.dm.bits, (pair + c0 + 1) * 2) << n0;
+      }
+      const int rows_blk = 40 * crun - i0 < 32 ? 40 * crun - i0 : 32;
+      if (rows_blk < 32) va &= (1u << rows_blk) - 1u;
+      tkl_block_run<K>(ps_run, Q, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+    }
+    pair += crun;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic kernel: one wavefront per pair, direct fragment loads, any E % 4 == 0, any Q / D.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool TKL>
@@ -840,16 +1112,33 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
       hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
     return check_launch("kernel_pool_stream_kernel");
   }
-  if (a.E == 100)
-    hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
-  else if (a.E == 200)
-    hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, true, TKL>), grid, block, lds, stream, a);
-  else
-    hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
-  return check_launch("kernel_pool_split_kernel");
+  if constexpr (TKL) {  // grouped runs of chunks (tkl_stage1_run_kernel)
+    if (a.E == 100)
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, true>), grid, block, lds, stream, a);
+    else if (a.E == 200)
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<2, K, NBUF, true>), grid, block, lds, stream, a);
+    else
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, true>), grid, block, lds, stream, a);
+    return check_launch("tkl_stage1_run_kernel");
+  } else {
+    if (a.E == 100)
+      hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, true, false>), grid, block, lds, stream, a);
+    else if (a.E == 200)
+      hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, true, false>), grid, block, lds, stream, a);
+    else
+      hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, true, false>), grid, block, lds, stream, a);
+    return check_launch("kernel_pool_split_kernel");
+  }
 }
 
 bool kp_stream_supported(int Q, int E) { return Q <= 32 && (E == 100 || E == 200 || E == 300); }
+
+// true when TKL stage 1 runs the grouped kernel, which writes every pair of every packed chunk
+bool tkl_stage1_writes_all_pairs(int Q, int E) {
+  const char* g = getenv("MM_KP_GENERIC");
+  const char* f = getenv("MM_KP_F32MFMA");
+  return kp_stream_supported(Q, E) && !(g && atoi(g)) && !(f && atoi(f));
+}
 
 // TKL stage 1 entry (called from tkl.hip): chunks [P,50,E] -> ps_out [P,20,Q,12]
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,

@@ -44,6 +44,7 @@ int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, siz
 
 // kernel_pool.hip exports used by tkl.hip
 bool kp_stream_supported(int Q, int E);
+bool tkl_stage1_writes_all_pairs(int Q, int E);
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
                       const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream);
 

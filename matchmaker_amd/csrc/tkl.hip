@@ -39,13 +39,14 @@ struct TklParams {            // offsets into the packed float parameter vector 
 // buffer was 255 MB at B = 256 x 2048 tokens).
 __global__ void __launch_bounds__(256) tkl_slot_map_kernel(const int32_t* __restrict__ chunk_slot,
                                                            const int32_t* __restrict__ chunk_len, int64_t P,
-                                                           int64_t BC, int32_t* __restrict__ slot2p) {
+                                                           int64_t BC, int all_pairs, int32_t* __restrict__ slot2p) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p < P) {
     const int32_t s = chunk_slot[p];
     int len = chunk_len[p];
     len = len < 0 ? 0 : (len > 40 ? 40 : len);
-    if (s >= 0 && s < BC) slot2p[s] = (int32_t)((p << 2) | ((len + 31) >> 5));
+    // the grouped stage-1 kernel writes every pair of a chunk; the per-chunk kernels only the blocks below its length
+    if (s >= 0 && s < BC) slot2p[s] = (int32_t)((p << 2) | (all_pairs ? 2 : ((len + 31) >> 5)));
   }
 }
 
@@ -271,7 +272,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     PackedMask dm;
     if (int e = resolve_mask(chunk_mask, MM_MASK_F32, P, 40, &ws, &left, stream, &dm, 50, 5)) return e;
     hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, dm.len, P,
-                       B * (int64_t)C, slot2p);
+                       B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, slot2p);
     if (int e = check_launch("tkl_slot_map_kernel")) return e;
     if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, chunk_slot, C,
                                   params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))

@@ -114,6 +114,23 @@ def colbert_forward(q, d, q_mask, d_mask, grad=False):
                          {"vecs": d, "attention_mask": d_mask}, use_fp16=False)
 
 
+def make_colbert_with_encoder(encoder, compression_dim):
+    """Real ColBERT class (colbert.py) around a given HF encoder: the constructor (:37-52) downloads weights by
+    name and its config class does not validate under transformers >= 5, so the object is assembled the way
+    the constructor does — bert_model, compressor = Linear(hidden, compression_dim) (:50), return_vecs — and
+    every method that runs afterwards (forward :54-86, forward_representation :88-98) is the reference's own."""
+    install_shims()
+    from matchmaker.models.colbert import ColBERT  # noqa
+
+    m = ColBERT.__new__(ColBERT)
+    nn.Module.__init__(m)
+    m.bert_model = encoder
+    m.compressor = nn.Linear(encoder.config.hidden_size, compression_dim)
+    m.return_vecs = False
+    m.eval()
+    return m
+
+
 def colbert_forward_aggregation(q, d):
     """Real ColBERT.forward_aggregation (colbert.py:100-112); does not use self."""
     install_shims()

@@ -76,6 +76,34 @@ def gen_colbert():
                                 R.colbert_forward_inbatch_aggregation(q, qm, d, dm).numpy()))
 
 
+def gen_colbert_e2e():
+    # the real ColBERT.forward end to end (encoder + compressor + scoring, colbert.py:54-98) on token ids, with
+    # a tiny randomly initialised BERT: what eval.py:108 calls, minus the checkpoint download
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(11)
+    enc = BertModel(BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                               vocab_size=500, max_position_embeddings=256, hidden_dropout_prob=0.0,
+                               attention_probs_dropout_prob=0.0))
+    m = R.make_colbert_with_encoder(enc, 128)
+    g = torch.Generator().manual_seed(12)
+    B, Q, D = 7, 32, 180
+    ql = torch.randint(3, Q + 1, (B,), generator=g)
+    dl = torch.randint(8, D + 1, (B,), generator=g)
+    mk = lambda L, n: {"input_ids": torch.randint(1, 500, (B, n), generator=g),
+                       "attention_mask": (torch.arange(n)[None] < L[:, None]).long()}
+    query, doc = mk(ql, Q), mk(dl, D)
+    with torch.no_grad():
+        score = m.forward(query, doc, use_fp16=False)
+        qv = m.forward_representation(query, "query_encode")
+        dv = m.forward_representation(doc, "doc_encode")
+        agg = m.forward_aggregation(qv, dv)
+    sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "colbert_e2e_tinybert.npz"),
+                        q_ids=query["input_ids"].numpy(), q_mask=query["attention_mask"].numpy(),
+                        d_ids=doc["input_ids"].numpy(), d_mask=doc["attention_mask"].numpy(),
+                        forward=score.numpy(), forward_aggregation=agg.numpy(), **sd)
+
+
 def gen_tk():
     # BASELINE.json config 1 shapes (1 query x candidates, Q=20/D=200/E=300), B cut to 4 for size
     g = torch.Generator().manual_seed(1001)
@@ -192,6 +220,7 @@ def gen_tkl():
 
 if __name__ == "__main__":
     gen_colbert()
+    gen_colbert_e2e()
     gen_tk()
     gen_knrm()
     gen_conv_knrm()

@@ -93,3 +93,33 @@ def test_training_backward_flows_through_native_forward():
     ref = s.max(-1).values.masked_fill(~query["attention_mask"].bool(), 0).sum(-1)
     ref.sum().backward()
     torch.testing.assert_close(m.compressor.weight.grad, g, rtol=1e-3, atol=1e-4)
+
+
+def test_full_forward_matches_the_real_colbert_class_end_to_end():
+    """tests/golden/colbert_e2e_tinybert.npz holds the REAL ColBERT class's outputs (colbert.py:54-98: tiny
+    random BERT + compressor + scoring) on token-id batches, with its state_dict.  The drop-in loads that
+    state_dict unchanged (strict) and must reproduce forward() — the call eval.py:108 / train.py:347 makes —
+    and the encode + forward_aggregation route of dense_retrieval.py."""
+    from transformers import BertConfig, BertModel
+    from matchmaker_amd.colbert import ColBERT, ColBERTConfig
+    dev = util.require_gpu()
+    g = util.load("colbert_e2e_tinybert.npz")
+    enc = BertModel(BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                               vocab_size=500, max_position_embeddings=256, hidden_dropout_prob=0.0,
+                               attention_probs_dropout_prob=0.0))
+    m = ColBERT(ColBERTConfig(bert_model="(injected)", compression_dim=128), bert_model=enc)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}, strict=True)
+    m = m.to(dev).eval()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    query = {"input_ids": t("q_ids"), "attention_mask": t("q_mask")}
+    doc = {"input_ids": t("d_ids"), "attention_mask": t("d_mask")}
+    with torch.no_grad():
+        score = m.forward(query, doc, use_fp16=False)
+        agg = m.forward_aggregation(m.forward_representation(query, "query_encode"),
+                                    m.forward_representation(doc, "doc_encode"))
+        score16 = m.forward(query, doc, use_fp16=True)
+    # the encoder runs on a different device / BLAS than the golden run: scores are sums of ~20 maxima of size ~30
+    np.testing.assert_allclose(score.cpu().numpy(), g["forward"], atol=5e-3, rtol=2e-5)
+    np.testing.assert_allclose(agg.cpu().numpy(), g["forward_aggregation"], atol=5e-3, rtol=2e-5)
+    np.testing.assert_allclose(score16.cpu().numpy(), g["forward"], atol=0.5, rtol=2e-3)     # fp16 autocast encoder
+    assert np.array_equal(np.argsort(-score.cpu().numpy(), kind="stable"), np.argsort(-g["forward"], kind="stable"))
