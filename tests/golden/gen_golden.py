@@ -98,7 +98,7 @@ def gen_colbert_e2e():
         dv = m.forward_representation(doc, "doc_encode")
         agg = m.forward_aggregation(qv, dv)
     sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
-    np.savez_compressed(os.path.join(OUT, "colbert_e2e_tinybert.npz"),
+    np.savez_compressed(os.path.join(OUT, "e2e_colbert_tinybert.npz"),
                         q_ids=query["input_ids"].numpy(), q_mask=query["attention_mask"].numpy(),
                         d_ids=doc["input_ids"].numpy(), d_mask=doc["attention_mask"].numpy(),
                         forward=score.numpy(), forward_aggregation=agg.numpy(), **sd)

@@ -96,14 +96,14 @@ def test_training_backward_flows_through_native_forward():
 
 
 def test_full_forward_matches_the_real_colbert_class_end_to_end():
-    """tests/golden/colbert_e2e_tinybert.npz holds the REAL ColBERT class's outputs (colbert.py:54-98: tiny
+    """tests/golden/e2e_colbert_tinybert.npz holds the REAL ColBERT class's outputs (colbert.py:54-98: tiny
     random BERT + compressor + scoring) on token-id batches, with its state_dict.  The drop-in loads that
     state_dict unchanged (strict) and must reproduce forward() — the call eval.py:108 / train.py:347 makes —
     and the encode + forward_aggregation route of dense_retrieval.py."""
     from transformers import BertConfig, BertModel
     from matchmaker_amd.colbert import ColBERT, ColBERTConfig
     dev = util.require_gpu()
-    g = util.load("colbert_e2e_tinybert.npz")
+    g = util.load("e2e_colbert_tinybert.npz")
     enc = BertModel(BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
                                vocab_size=500, max_position_embeddings=256, hidden_dropout_prob=0.0,
                                attention_probs_dropout_prob=0.0))
