@@ -104,6 +104,37 @@ def gen_colbert_e2e():
                         forward=score.numpy(), forward_aggregation=agg.numpy(), **sd)
 
 
+def gen_e2e_tk_tkl():
+    # the real ECAI20_TK / TKL_sigir20 classes END TO END (positional encoding + Transformer contextualiser +
+    # mixer + chunking + pooling), eval mode, random init: what NeuralIR_Encoder.forward calls
+    # (neuralIR_encoder.py:86-87).  Small dims keep the fixture small.
+    g = torch.Generator().manual_seed(1301)
+    B, Q, D, E = 5, 12, 70, 60
+    q = torch.randn(B, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    qm = prefix_mask(torch.tensor([12, 3, 7, 12, 1]), Q, torch.float32)
+    dm = prefix_mask(torch.tensor([70, 20, 5, 33, 64]), D, torch.float32)
+    m = R.make_tk(E, bypass_contextualizer=False, att_heads=6, att_ff_dim=32, max_length=80, seed=21)
+    with torch.no_grad():
+        m.kernel_alpha_scaler.uniform_(0.5, 1.5, generator=g)
+        m.kernel_bin_weights.weight.uniform_(-0.5, 0.5, generator=g)
+    score = R.tk_forward(m, q, d, qm, dm)
+    sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "e2e_tk_q12_d70_e60.npz"), q=q.numpy(), d=d.numpy(), q_mask=qm.numpy(),
+                        d_mask=dm.numpy(), score=score.numpy(), **sd)
+
+    B, Q, D, E = 3, 10, 333, 64
+    q = torch.randn(B, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    qm = prefix_mask(torch.tensor([10, 4, 7]), Q, torch.float32)
+    dm = prefix_mask(torch.tensor([333, 120, 41]), D, torch.float32)
+    m = R.make_tkl(E, bypass_contextualizer=False, att_heads=8, att_ff_dim=32, seed=22)
+    score = R.tkl_forward(m, q, d, qm, dm)
+    sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "e2e_tkl_q10_d333_e64.npz"), q=q.numpy(), d=d.numpy(), q_mask=qm.numpy(),
+                        d_mask=dm.numpy(), score=score.numpy(), **sd)
+
+
 def gen_tk():
     # BASELINE.json config 1 shapes (1 query x candidates, Q=20/D=200/E=300), B cut to 4 for size
     g = torch.Generator().manual_seed(1001)
@@ -221,6 +252,7 @@ def gen_tkl():
 if __name__ == "__main__":
     gen_colbert()
     gen_colbert_e2e()
+    gen_e2e_tk_tkl()
     gen_tk()
     gen_knrm()
     gen_conv_knrm()

@@ -145,3 +145,31 @@ def test_tk_and_tkl_full_models_wire_native_pooling_correctly():
     with torch.no_grad():
         s_tkl = tkl.forward(q[:2].detach(), dl, qm[:2], dml)
     assert s_tkl.shape == (2,) and torch.isfinite(s_tkl).all()
+
+
+def test_full_tk_and_tkl_forward_match_the_real_classes_end_to_end():
+    """e2e_*.npz hold the REAL ECAI20_TK / TKL_sigir20 outputs with their Transformer contextualisers enabled
+    (CPU, eval) and their state_dicts.  The drop-ins load them strictly and must reproduce forward() — the
+    call NeuralIR_Encoder makes (neuralIR_encoder.py:86-87) — with the contextualiser in PyTorch on the GPU
+    and the match / pooling / windows / regions native.  E = 60 / 64: the generic fp32 kernels."""
+    from matchmaker_amd.tk import ECAI20_TK
+    from matchmaker_amd.tkl import TKL_sigir20
+    dev = util.require_gpu()
+    g = util.load("e2e_tk_q12_d70_e60.npz")
+    m = ECAI20_TK(60, MU, SIGMA, 6, 2, 32, 80, True, True)
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}, strict=True)
+    m = m.to(dev).eval()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    with torch.no_grad():
+        s = m.forward(t("q"), t("d"), t("q_mask"), t("d_mask"))
+    # contextualiser on another device/BLAS: ~1e-6 relative on the embeddings; scores are sums of ~130 logs
+    np.testing.assert_allclose(s.cpu().numpy(), g["score"], atol=5e-3, rtol=1e-4)
+
+    g = util.load("e2e_tkl_q10_d333_e64.npz")
+    m = TKL_sigir20(64, MU, SIGMA, 8, 2, 32, 2000, True, True, "embedding")
+    m.load_state_dict({k[len("param."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("param.")}, strict=True)
+    m = m.to(dev).eval()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    with torch.no_grad():
+        s = m.forward(t("q"), t("d"), t("q_mask"), t("d_mask"))
+    np.testing.assert_allclose(s.cpu().numpy(), g["score"], atol=5e-3, rtol=2e-4)
