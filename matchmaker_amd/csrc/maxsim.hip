@@ -219,7 +219,10 @@ __device__ __forceinline__ void wait_block(int younger) {
 
 // NSL = E / 128: a 32-token block is streamed as NSL slices of 32 rows x 256 B (one ring slot each);
 // the accumulator runs across the slices, the query tile is NSL x 32 VGPRs of B fragments.
-template <int DT, int NBUF, bool NT, int NSL, bool RAG>
+// NQT = query tiles of 32 tokens held in registers (Q <= 32 * NQT): the reference's defaults stay under 32
+// (max_query_length 30, defaults.yaml:127) but ColBERT's [MASK] query augmentation
+// (query_augment_mask_number, independent_reranking_loader.py:106-112) pushes Q to 38.
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT>
 __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -302,12 +305,15 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   };
   top_up();
 
-  // ---- query tile as MFMA B fragments ---------------------------------------------------------
-  short8 qf[NSL][8];
-  bool qvalid = false;
+  // ---- query tile(s) as MFMA B fragments ------------------------------------------------------
+  short8 qf[NQT][NSL][8];
+  bool qvalid[NQT];
+#pragma unroll
+  for (int n = 0; n < NQT; ++n) qvalid[n] = false;
   int64_t cur_q = -1;
   int64_t qi = p0 / a.ppq;
   int64_t q_left = a.ppq - (p0 - qi * a.ppq);  // pairs left on this query
+  const int qwords = (Q + 31) >> 5;
 
   for (int64_t pair = p0; pair < p1; ++pair) {
     if (q_left == 0) {
@@ -317,24 +323,32 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     --q_left;
     if (qi != cur_q) {
       cur_q = qi;
-      const int qr = r < Q ? r : Q - 1;
-      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
-#pragma unroll
-      for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[sl]);
       const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
-      qvalid = r < Q && r < qlen;
-      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) {
+        const int qt = 32 * n + r;
+        const int qr = qt < Q ? qt : Q - 1;
+        const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
+        qvalid[n] = qt < Q && qt < qlen;
+        if (a.qm.bits && n < qwords) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qi * qwords + n) >> r) & 1u);
+      }
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
     // ragged documents have no padded positions; an empty one scores like a fully padded one
     const float fill = (RAG ? len == 0 : len < D) ? -1000.0f : neg_inf();
-    float m[16];
+    float m[NQT][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m[i] = fill;
+    for (int n = 0; n < NQT; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m[n][i] = fill;
 
     for (int t = 0; t < nb; ++t) {
-      f32x16 acc = {0};
+      f32x16 acc[NQT];
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) {
         top_up();
@@ -343,7 +357,8 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const short8 av = *(const short8*)(buf + lo[kk]);
-          acc = Mfma32x16<DT>::run(av, qf[sl][kk], acc);
+#pragma unroll
+          for (int n = 0; n < NQT; ++n) acc[n] = Mfma32x16<DT>::run(av, qf[n][sl][kk], acc[n]);
         }
         cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
         --inflight;
@@ -351,9 +366,12 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
-      block_max(m, acc, ex, va, fill, h);
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) block_max(m[n], acc[n], ex, va, fill, h);
     }
-    const float s = finish_pair(m, qvalid, h);
+    float s = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) s += finish_pair(m[n], qvalid[n], h);  // tiles in index order: deterministic
     if (lane == 0) a.out[pair] = s;
   }
 }
@@ -594,7 +612,7 @@ static void read_env() {
   if (g_stream_nbuf > 4) g_stream_nbuf = 4;
 }
 
-template <int DT, int NBUF, bool NT, int NSL, bool RAG>
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT = 1>
 static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   MaxsimArgs a = a0;
   const int lds = NBUF * kBlkBytes;
@@ -604,13 +622,16 @@ static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL, RAG>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL, RAG, NQT>), dim3((unsigned)waves), dim3(64), lds, stream, a);
   return check_launch("maxsim_stream_kernel");
 }
 
 template <int DT, int NSL, bool RAG>
 static int launch_stream_nsl(const MaxsimArgs& a, hipStream_t stream) {
   const bool nt = g_stream_nt != 0;
+  if constexpr (NSL <= 4) {
+    if (a.Q > 32) return launch_stream<DT, 2, true, NSL, RAG, 2>(a, stream);  // two query tiles in registers
+  }
   if (NSL == 1 && !RAG) {  // the tuning knobs are only instantiated for the headline shape
     switch (g_stream_nbuf) {
       case 3: return nt ? launch_stream<DT, 3, true, NSL, false>(a, stream) : launch_stream<DT, 3, false, NSL, false>(a, stream);
@@ -672,7 +693,7 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-  const bool stream_ok = !g_force_generic && dtype != MM_F32 && Q <= 32 &&
+  const bool stream_ok = !g_force_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
   return launch_generic(a, dtype, stream);
@@ -727,7 +748,7 @@ extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
-  const bool stream_ok = !g_force_generic && dtype != MM_F32 && Q <= 32 &&
+  const bool stream_ok = !g_force_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, true>(a, stream) : launch_stream_cfg<MM_F16, true>(a, stream);
   return launch_generic(a, dtype, stream);

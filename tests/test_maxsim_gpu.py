@@ -171,3 +171,33 @@ def test_errors_are_loud():
         ops.maxsim(q.cpu(), d.cpu(), pairs_per_query=2)              # no CPU fallback
     with pytest.raises(NativeError):
         ops.maxsim(torch.zeros(3, 4, 16, device=dev), torch.zeros(2, 5, 16, device=dev), pairs_per_query=2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, util.TOL_BF16), (torch.float16, util.TOL_BF16)])
+@pytest.mark.parametrize("Q,D,E,ppq", [(38, 180, 128, 7), (64, 200, 128, 1), (33, 47, 256, 3), (40, 100, 512, 2),
+                                       (38, 90, 768, 2)])
+def test_queries_longer_than_one_tile(dtype, tol, Q, D, E, ppq):
+    """Q = 30 + 8 [MASK] tokens (ColBERT query augmentation, independent_reranking_loader.py:106-112) needs two
+    query tiles: streaming kernel with NQT = 2 up to E = 512, generic kernel for E = 768."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 17 + E)
+    nq = 3
+    B = nq * ppq
+    q = (torch.randn(nq, Q, E, generator=g) / E ** 0.5).to(dtype)
+    d = (torch.randn(B, D, E, generator=g) / E ** 0.5).to(dtype)
+    q_len = torch.randint(1, Q + 1, (nq,), generator=g)
+    q_len[0] = Q
+    d_len = torch.randint(0, D + 1, (B,), generator=g)
+    d_len[0] = D
+    qm = (torch.arange(Q)[None] < q_len[:, None]).long()
+    qm[1, 0] = 0                                      # hole in the first query word
+    if Q > 33:
+        qm[0, 33] = 0                                 # hole in the second query word
+    dm = (torch.arange(D)[None] < d_len[:, None]).long()
+    out = ops.maxsim(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), pairs_per_query=ppq).cpu().numpy()
+    qi = np.arange(B) // ppq
+    ref = O.maxsim_paired(q.float().numpy()[qi], d.float().numpy(), qm.numpy()[qi], dm.numpy())
+    np.testing.assert_allclose(out, ref, atol=tol, rtol=1e-4)
+    out2 = ops.maxsim(q.to(dev), d.to(dev), None, None, pairs_per_query=ppq).cpu().numpy()
+    np.testing.assert_allclose(out2, O.maxsim_unmasked(q.float().numpy()[qi], d.float().numpy()), atol=tol, rtol=1e-4)
