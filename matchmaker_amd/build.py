@@ -5,39 +5,59 @@
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the repo snapshot to
 the GPU box.  No torch headers are involved: the library is a plain C-ABI shared object
 (include/mm_native.h) bound from Python with ctypes (matchmaker_amd/_lib.py).
+Each translation unit is compiled to an object file (in parallel, only when it or a header changed),
+then linked.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libmm_native.so")
 SOURCES = ["common.hip", "maxsim.hip", "kernel_pool.hip", "kernel_pool_bwd.hip", "tkl.hip", "dot_topk.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment"]
+HEADERS = [os.path.join(CSRC, "mm_internal.h"), os.path.join(HERE, "..", "include", "mm_native.h")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 
 
 def _sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = _sources() + [os.path.join(CSRC, "mm_internal.h"),
-                         os.path.join(HERE, "..", "include", "mm_native.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + _sources()
-    if verbose:
-        print("[matchmaker_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    srcs = _sources()
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [s for s in srcs if force or _newer(_obj(s), [s] + HEADERS)]
+
+    def compile_one(src):
+        cmd = [hipcc] + CFLAGS + ["-c", "-o", _obj(src), src]
+        if verbose:
+            print("[matchmaker_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, todo))
+    objs = [_obj(s) for s in srcs]
+    if force or todo or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[matchmaker_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
     return LIB
 
 
