@@ -127,17 +127,25 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
     const int wl = item / Q, i = item - wl * Q;
     float val = 0.0f;
     if (w0 + wl < W) {
-      float pk[kKC];
+      // 15 pair rows x 12 channels, summed in row order with packed adds (v_pk_add_f32: two channels per
+      // instruction; the same additions in the same order as the scalar form)
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      f32x2 pk2[kKC / 2];
 #pragma unroll
-      for (int k = 0; k < kKC; ++k) pk[k] = 0.0f;
+      for (int k = 0; k < kKC / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
+#pragma unroll
       for (int j = 0; j < kWinPairs; ++j) {
         const f32x4* src = (const f32x4*)(tile + (size_t)(wl + j) * rowf + i * kKC);
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
           const f32x4 x = src[v];
-          pk[4 * v] += x[0]; pk[4 * v + 1] += x[1]; pk[4 * v + 2] += x[2]; pk[4 * v + 3] += x[3];
+          pk2[2 * v] += f32x2{x[0], x[1]};
+          pk2[2 * v + 1] += f32x2{x[2], x[3]};
         }
       }
+      float pk[kKC];
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) pk[k] = pk2[k >> 1][k & 1];
       const float len = pk[kK];                                        // :210 (exact small integer)
       const float factor = q_mask[(int64_t)b * Q + i] * (len > 0.0f ? 1.0f : 0.0f);   // :248
       if (SAT == MM_TKL_SAT_EMBEDDING) {
