@@ -27,11 +27,16 @@ def _pad_dim(E: int) -> int:
 
 
 class FlatIPIndexer:
-    def __init__(self, config, device=None, group=None):
+    def __init__(self, config, device=None, group=None, topk_fn=None, merge_fn=None):
+        """topk_fn(queries, vectors, k) / merge_fn(scores, ids, k) default to the native operators
+        (ops.dot_topk / ops.topk_merge); the CPU test-suite injects oracle stand-ins to exercise the
+        sharding logic under gloo."""
+        self._topk = topk_fn if topk_fn is not None else ops.dot_topk
+        self._merge = merge_fn if merge_fn is not None else ops.topk_merge
         self.token_dim = config["token_dim"]
         self.use_fp16 = config.get("faiss_use_fp16", True)   # the native index always stores 16-bit vectors
         self.dtype = torch.float16
-        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())  # noqa: E501
         self.group = group
         self.vectors: Optional[torch.Tensor] = None           # [n_local, E_pad]
         self.ids: Optional[torch.Tensor] = None               # [n_local] int64 external ids (IndexIDMap)
@@ -71,14 +76,15 @@ class FlatIPIndexer:
             q = q[None, :]
         qd = torch.zeros((q.shape[0], self.E_pad), dtype=self.dtype, device=self.device)
         qd[:, : self.token_dim] = q.to(self.device).to(self.dtype)
-        s, idx = ops.dot_topk(qd, self.vectors, top_n)
+        s, idx = self._topk(qd, self.vectors, top_n)
         ids = torch.where(idx >= 0, self.ids[idx.clamp(min=0)], idx)
         world, _ = self._world()
         if world > 1:
-            gs = torch.empty((world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
-            gi = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-            dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)     # RCCL over xGMI
+            nq = s.shape[0]
+            gs = torch.empty((world * nq, top_n), dtype=s.dtype, device=s.device)        # rank-major concatenation
+            gi = torch.empty((world * nq, top_n), dtype=ids.dtype, device=ids.device)
+            dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)             # RCCL over xGMI
             dist.all_gather_into_tensor(gi, ids.contiguous(), group=self.group)
-            s, ids = ops.topk_merge(gs.permute(1, 0, 2).reshape(s.shape[0], -1),
-                                    gi.permute(1, 0, 2).reshape(s.shape[0], -1), top_n)
+            s, ids = self._merge(gs.view(world, nq, top_n).permute(1, 0, 2).reshape(nq, -1),
+                                 gi.view(world, nq, top_n).permute(1, 0, 2).reshape(nq, -1), top_n)
         return s.cpu().numpy(), ids.cpu().numpy()

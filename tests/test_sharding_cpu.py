@@ -70,3 +70,49 @@ def test_two_rank_gloo_rerank_equals_single_process(tmp_path, nq):
     mp.spawn(_worker, args=(world, _free_port(), nq, 7, str(tmp_path)), nprocs=world, join=True)
     a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
     assert a.shape == (nq, 7) and (a == b).all()
+
+
+# ---- sharded flat inner-product index (retrieval.FlatIPIndexer) under gloo ------------------------------
+
+def _index_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import np_oracle as O
+    from matchmaker_amd.retrieval import FlatIPIndexer
+
+    def topk_fn(q, c, k):                                       # oracle stand-in for ops.dot_topk
+        s, i = O.dot_topk(q.float().numpy(), c.float().numpy(), k)
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    def merge_fn(s, ids, k):                                    # oracle stand-in for ops.topk_merge
+        s = s.clone()
+        s[ids < 0] = float("-inf")
+        order = torch.sort(s, dim=1, descending=True, stable=True).indices[:, :k]
+        return torch.gather(s, 1, order), torch.gather(ids, 1, order)
+
+    rng = np.random.default_rng(17)                             # every rank is handed the same full lists
+    E, n = 40, 1001                                             # odd size: uneven shards; E is padded to 128
+    chunks = [rng.standard_normal((400, E)).astype(np.float16), rng.standard_normal((601, E)).astype(np.float16)]
+    ids = [np.arange(0, 400, dtype=np.int64) * 3 + 5, np.arange(400, 1001, dtype=np.int64) * 3 + 5]
+    ix = FlatIPIndexer({"token_dim": E}, device="cpu", topk_fn=topk_fn, merge_fn=merge_fn)
+    ix.prepare(chunks)
+    ix.index(ids, chunks)
+    lo, hi = __import__("matchmaker_amd.sharding", fromlist=["shard_range"]).shard_range(n, world, rank)
+    assert ix.vectors.shape == (hi - lo, 128) and ix.ids.tolist() == np.concatenate(ids)[lo:hi].tolist()
+    qv = rng.standard_normal((6, E)).astype(np.float32)
+    s, i = ix.search(qv, 25)
+    allv = np.concatenate(chunks).astype(np.float32)
+    ref_s, ref_i = O.dot_topk(qv.astype(np.float16).astype(np.float32), allv, 25)
+    np.testing.assert_allclose(s, ref_s, atol=1e-5)
+    assert (i == ref_i * 3 + 5).all(), "merged ids differ from the single-index result"
+    np.save(os.path.join(out_dir, f"ids{rank}.npy"), i)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_index_equals_single_index(tmp_path):
+    world = 2
+    mp.spawn(_index_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "ids0.npy"), np.load(tmp_path / "ids1.npy")
+    assert a.shape == (6, 25) and (a == b).all()
