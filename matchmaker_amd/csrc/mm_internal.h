@@ -42,9 +42,28 @@ size_t packed_mask_bytes(int kind, int64_t rows, int L);
 int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, size_t* ws_left,
                  hipStream_t stream, PackedMask* out, int64_t row_stride = 0, int col0 = 0);
 
+constexpr int kK = 11;   // RBF kernels of TK / TKL (tk.yaml:18-19, tkl.yaml)
+constexpr int kKC = 12;  // K + the non-zero-count channel of TKL's pair sums
+
+struct TklParams {            // offsets into the packed float parameter vector (see mm_native.h)
+  __host__ __device__ static int mu() { return 0; }
+  __host__ __device__ static int sigma() { return kK; }
+  __host__ __device__ static int dense() { return 2 * kK; }
+  __host__ __device__ static int kmult() { return 3 * kK; }
+  __host__ __device__ static int sat() { return 4 * kK; }       // w1[2] b1 w2[2] b2 w3[2] b3 lnw[2] lnb[2]
+  __host__ __device__ static int chunk_scoring() { return 4 * kK + 13; }
+  __host__ __device__ static int emb() { return 4 * kK + 13 + 15; }
+};
+
 // kernel_pool.hip exports used by tkl.hip
 bool kp_stream_supported(int Q, int E);
 bool tkl_stage1_writes_all_pairs(int Q, int E);
+// Fused TKL stages 1 + 2 (one workgroup per document; kernel_pool.hip).  Returns MM_EUNSUPPORTED without
+// launching when the shape does not fit (caller falls back to the two-kernel path).
+bool tkl_fused_supported(int C, int Q, int E);
+int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* slot2p, const float* q_mask,
+              const float* prm, const float* emb, float* win, int64_t B, int C, int Q, int E, int W, int saturation,
+              hipStream_t stream);
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
                       const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream);
 

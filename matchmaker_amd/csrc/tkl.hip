@@ -17,21 +17,10 @@
 
 namespace mm {
 
-constexpr int kK = 11;
-constexpr int kKC = 12;       // K + count channel
 constexpr int kU = 20;        // position pairs per chunk
 constexpr int kWinPairs = 15; // 30 positions, stride 2
 constexpr int kWT = 64;       // windows per workgroup in stage 2
 
-struct TklParams {            // offsets into the packed float parameter vector (see mm_native.h)
-  __host__ __device__ static int mu() { return 0; }
-  __host__ __device__ static int sigma() { return kK; }
-  __host__ __device__ static int dense() { return 2 * kK; }
-  __host__ __device__ static int kmult() { return 3 * kK; }
-  __host__ __device__ static int sat() { return 4 * kK; }       // w1[2] b1 w2[2] b2 w3[2] b3 lnw[2] lnb[2]
-  __host__ __device__ static int chunk_scoring() { return 4 * kK + 13; }
-  __host__ __device__ static int emb() { return 4 * kK + 13 + 15; }
-};
 
 // slot -> (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2); -1 = dropped
 // chunk.  Stage 1 only writes the blocks below a chunk's effective length, so pair rows past them are
@@ -275,17 +264,6 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   size_t left = workspace_bytes - (size_t)(ws - (char*)workspace);
   float* win = win_scores;
   if (hipMemsetAsync(slot2p, 0xFF, (size_t)B * C * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "tkl: memset failed");
-  if (P > 0) {
-    if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
-    PackedMask dm;
-    if (int e = resolve_mask(chunk_mask, MM_MASK_F32, P, 40, &ws, &left, stream, &dm, 50, 5)) return e;
-    hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, dm.len, P,
-                       B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, slot2p);
-    if (int e = check_launch("tkl_slot_map_kernel")) return e;
-    if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, chunk_slot, C,
-                                  params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
-      return e;
-  }
   char* tail = (char*)workspace + align256((size_t)B * C * 4) + ps_bytes + packed_mask_bytes(MM_MASK_F32, P, 40);
   if (!win) win = (float*)tail;
   float* emb = (float*)(tail + align256((size_t)B * W * 4));
@@ -294,22 +272,44 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
                        emb, B * (int64_t)Q, E);
     if (int e = check_launch("tkl_emb_kernel")) return e;
   }
-  const int nu = kWT + kWinPairs - 1;
-  const size_t lds2 = ((size_t)nu * Q * kKC + ((Q + 3) & ~3) + (size_t)kWT * Q) * 4;
-  if (lds2 > 160 * 1024) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
-  const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
-  if (saturation == MM_TKL_SAT_EMBEDDING) {
-    if (lds2 > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(256), lds2, stream, ps, slot2p,
-                       emb, q_mask, params, win, C, Q, W);
-  } else {
-    if (lds2 > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(256), lds2, stream, ps, slot2p,
-                       emb, q_mask, params, win, C, Q, W);
+  // Stages 1 + 2 fused per document (pair sums stay in LDS) when the shape fits; otherwise stage 1 writes the
+  // pair sums to the workspace and the window kernel reads them back.
+  const bool fused = tkl_fused_supported(C, Q, E);
+  PackedMask dm;
+  if (P > 0) {
+    if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
+    if (int e = resolve_mask(chunk_mask, MM_MASK_F32, P, 40, &ws, &left, stream, &dm, 50, 5)) return e;
+    hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, dm.len, P,
+                       B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, slot2p);
+    if (int e = check_launch("tkl_slot_map_kernel")) return e;
+    if (!fused) {
+      if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, chunk_slot, C,
+                                    params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
+        return e;
+    }
   }
-  if (int e = check_launch("tkl_window_kernel")) return e;
+  if (fused) {
+    if (int e = tkl_fused((const float*)q_ctx, (const float*)chunks, dm, slot2p, q_mask, params,
+                          saturation == MM_TKL_SAT_EMBEDDING ? emb : nullptr, win, B, C, Q, E, W, saturation, stream))
+      return e;
+  } else {
+    const int nu = kWT + kWinPairs - 1;
+    const size_t lds2 = ((size_t)nu * Q * kKC + ((Q + 3) & ~3) + (size_t)kWT * Q) * 4;
+    if (lds2 > 160 * 1024) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
+    const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
+    if (saturation == MM_TKL_SAT_EMBEDDING) {
+      if (lds2 > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(256), lds2, stream, ps, slot2p,
+                         emb, q_mask, params, win, C, Q, W);
+    } else {
+      if (lds2 > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(256), lds2, stream, ps, slot2p,
+                         emb, q_mask, params, win, C, Q, W);
+    }
+    if (int e = check_launch("tkl_window_kernel")) return e;
+  }
   const int Wp = W < 3 ? 3 : W;
   hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(64), (size_t)Wp * 8, stream, win, params, out, W);
   return check_launch("tkl_region_kernel");
