@@ -112,31 +112,47 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
   __syncthreads();
 
   const float* sp = prm + TklParams::sat();
-  for (int item = tid; item < kWT * Q; item += 256) {
-    const int wl = item / Q, i = item - wl * Q;
-    float val = 0.0f;
-    if (w0 + wl < W) {
-      // 15 pair rows x 12 channels, summed in row order with packed adds (v_pk_add_f32: two channels per
-      // instruction; the same additions in the same order as the scalar form)
-      typedef __attribute__((ext_vector_type(2))) float f32x2;
-      f32x2 pk2[kKC / 2];
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  // One item = TWO adjacent windows of one query token: windows wl and wl + 1 share 14 of their 15 pair rows,
+  // so the shared rows are summed once (16 row reads and 15 row additions for two windows instead of 30 and
+  // 28).  Only additions of non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
+  for (int item = tid; item < (kWT / 2) * Q; item += 256) {
+    const int wp = item / Q, i = item - wp * Q;
+    const int wl = 2 * wp;
+    if (w0 + wl >= W) {
+      red[wl * Q + i] = 0.0f;
+      red[(wl + 1) * Q + i] = 0.0f;
+      continue;
+    }
+    auto row = [&](int j, f32x2 (&dst)[kKC / 2]) {
+      const f32x4* src = (const f32x4*)(tile + (size_t)(wl + j) * rowf + i * kKC);
 #pragma unroll
-      for (int k = 0; k < kKC / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
-#pragma unroll
-      for (int j = 0; j < kWinPairs; ++j) {
-        const f32x4* src = (const f32x4*)(tile + (size_t)(wl + j) * rowf + i * kKC);
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-          const f32x4 x = src[v];
-          pk2[2 * v] += f32x2{x[0], x[1]};
-          pk2[2 * v + 1] += f32x2{x[2], x[3]};
-        }
+      for (int v = 0; v < 3; ++v) {
+        const f32x4 x = src[v];
+        dst[2 * v] = f32x2{x[0], x[1]};
+        dst[2 * v + 1] = f32x2{x[2], x[3]};
       }
+    };
+    f32x2 core[kKC / 2], first[kKC / 2], last[kKC / 2], tmp[kKC / 2];
+    row(0, first);
+    row(1, core);
+#pragma unroll
+    for (int j = 2; j < kWinPairs; ++j) {
+      row(j, tmp);
+#pragma unroll
+      for (int k = 0; k < kKC / 2; ++k) core[k] += tmp[k];
+    }
+    row(kWinPairs, last);
+    const float qmv = q_mask[(int64_t)b * Q + i];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
       float pk[kKC];
 #pragma unroll
-      for (int k = 0; k < kKC; ++k) pk[k] = pk2[k >> 1][k & 1];
+      for (int k = 0; k < kKC; ++k)
+        pk[k] = which == 0 ? first[k >> 1][k & 1] + core[k >> 1][k & 1] : core[k >> 1][k & 1] + last[k >> 1][k & 1];
+      float val = 0.0f;
       const float len = pk[kK];                                        // :210 (exact small integer)
-      const float factor = q_mask[(int64_t)b * Q + i] * (len > 0.0f ? 1.0f : 0.0f);   // :248
+      const float factor = qmv * (len > 0.0f ? 1.0f : 0.0f);          // :248
       if (SAT == MM_TKL_SAT_EMBEDDING) {
         const float x0 = emb[i], x1 = len;                             // :224-225
         const float mean = (x0 + x1) * 0.5f;                           // LayerNorm(2) :228
@@ -161,8 +177,8 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
           val += prm[TklParams::dense() + k] * (sat * factor);
         }
       }
+      red[(wl + which) * Q + i] = (w0 + wl + which < W) ? val : 0.0f;
     }
-    red[wl * Q + i] = val;
   }
   __syncthreads();
   if (tid < kWT && w0 + tid < W) {                                     // :249 sum over query tokens, :251 dense
