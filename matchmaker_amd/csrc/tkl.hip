@@ -19,7 +19,7 @@ namespace mm {
 
 constexpr int kU = 20;        // position pairs per chunk
 constexpr int kWinPairs = 15; // 30 positions, stride 2
-constexpr int kWT = 64;       // windows per workgroup in stage 2
+constexpr int kWT = 32;       // windows per workgroup in stage 2
 
 
 // slot -> (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2); -1 = dropped
