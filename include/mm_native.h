@@ -154,6 +154,26 @@ int mm_kernel_pool_fwd(const void* q, const void* d,
                        int Q, int D, int E, int K, int dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Variants of the pooling block that share its arithmetic:
+ *   d_gate     optional float32 [n_pairs, D], >= 0: every activation of document token j is multiplied by
+ *              d_gate[p, j] on top of d_mask — TK-Sparse's learned stop-word vector
+ *              (matchmaker/models/published/cikm20_tk_sparse.py:133-135; negative values count as 0, the
+ *              reference's gate is a ReLU output).  NULL = no gate (= mm_kernel_pool_fwd).
+ *   clamp_min  the floor inside the log: 1e-10 for TK / TK-Sparse (ecai20_tk.py:121, cikm20_tk_sparse.py:142),
+ *              1e-4 for the IDCM passage sampler (matchmaker/models/published/sigir21_idcm.py:182-186, whose
+ *              pre-normalised vectors make the cosine's own normalisation a no-op).  Must be > 0.
+ * Everything else as mm_kernel_pool_fwd (which calls this with NULL, 1e-10). */
+int mm_kernel_pool_ex_fwd(const void* q, const void* d,
+                          const void* q_mask, int q_mask_kind,
+                          const void* d_mask, int d_mask_kind,
+                          const float* d_gate,
+                          const float* mu, const float* sigma, const float* alpha, const float* w,
+                          float clamp_min,
+                          float* out, float* per_kernel,
+                          int64_t n_pairs, int64_t pairs_per_query,
+                          int Q, int D, int E, int K, int dtype,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of mm_kernel_pool_fwd in the pair-per-row layout (training: train.py:347-348, loss.backward()
  * :503-524; the embedding model is called from neuralIR_encoder.py:86-87).  Gradients of the score w.r.t.
  * the contextualised embeddings and the two trainable pooling parameters (kernel_alpha_scaler
@@ -170,6 +190,20 @@ int mm_kernel_pool_bwd(const void* q, const void* d,
                        const float* grad_out, float* grad_q, float* grad_d, float* grad_alpha, float* grad_w,
                        int64_t n_pairs, int Q, int D, int E, int K,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of mm_kernel_pool_ex_fwd: as mm_kernel_pool_bwd, plus grad_gate [n_pairs, D] (may be NULL;
+ * needs d_gate), the gradient w.r.t. the gate values (training of TK-Sparse's stop-word MLP,
+ * cikm20_tk_sparse.py:133-135). */
+int mm_kernel_pool_ex_bwd(const void* q, const void* d,
+                          const void* q_mask, int q_mask_kind,
+                          const void* d_mask, int d_mask_kind,
+                          const float* d_gate,
+                          const float* mu, const float* sigma, const float* alpha, const float* w,
+                          float clamp_min,
+                          const float* grad_out, float* grad_q, float* grad_d, float* grad_gate,
+                          float* grad_alpha, float* grad_w,
+                          int64_t n_pairs, int Q, int D, int E, int K,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TKL: match + RBF kernels per document position, sliding-window (30, stride 2) pooling with

@@ -47,6 +47,12 @@ struct KpArgs {
   const int32_t* chunk_slot;
   int C;
   float* ps_out;
+  // variants of the pooling block (same arithmetic family):
+  //   dw != nullptr: per document token gate >= 0 multiplying all its activations (TK-Sparse stop-word
+  //   vector, cikm20_tk_sparse.py:133-135), [n_pairs, D] float32;
+  //   clamp_min: floor inside the log (1e-10 TK :121; 1e-4 IDCM sampler, sigir21_idcm.py:185)
+  const float* dw;
+  float clamp_min;
 };
 
 __device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
@@ -115,9 +121,11 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
 // v_pk_fma + v_pk_mul + 2 v_exp + v_pk_add.  The fp32 MFMA shares the SIMD's FMA lanes with the
 // VALU (measured: zero overlap, profiles/r01_kernel_pool_pmc.json), so every VALU op removed here
 // is wall time.
-template <int K>
+// W: lw[i] = log2(gate of row i) rides in the exponent (exp2(x + log2 g) = g exp2(x); g = 0 -> -inf -> 0),
+// which turns the pk_mul of the square into a pk_fma: the gate costs no instruction.
+template <int K, bool W = false>
 __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
-                                          uint32_t va, int h, const Rbf& rbf) {
+                                          uint32_t va, int h, const Rbf& rbf, const float* lw = nullptr) {
   // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
   // 4g..4g+3 hold rows 8g..8g+7 (both lane halves), so a group with no real row is skipped as a
   // whole (the last block of a document: D = 200 -> 8 of 32 rows) and a group of 8 real rows needs
@@ -134,16 +142,20 @@ __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16&
       float c = (acc[i] * rq) * rdr[i];
       if (!full) c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
       const f32x2 cc = {c, c};
+      const f32x2 lwv = W ? f32x2{lw[i], lw[i]} : f32x2{0.0f, 0.0f};
 #pragma unroll
       for (int kp = 0; kp < (K + 1) / 2; ++kp) {
         const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
-        const f32x2 av = -(sv * sv);
+        const f32x2 av = W ? lwv - sv * sv : -(sv * sv);
         const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
         pk2[kp] += e;
       }
     }
   }
 }
+
+// log2 of a TK-Sparse gate (a ReLU output, so >= 0; anything below 0 is treated as 0)
+__device__ __forceinline__ float gate_log2(float g) { return __builtin_amdgcn_logf(fmaxf(g, 0.0f)); }
 
 // TKL epilogue of one block of a chunk's centre tokens (block t = rows 32t..32t+31 of the 40):
 // per position pair u the K summed activations (ecai-style RBF, masked: sigir20_tkl.py:192-194) and
@@ -200,7 +212,7 @@ __device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const
   float total = 0.0f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], 1e-10f));
+    float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
     lg = (qvalid && lane < 32) ? lg : 0.0f;  // both halves hold the combined sums: count one
     const float s = wave_sum(lg);
     if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
@@ -512,8 +524,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NS, int K, int NBUF, bool NT, bool TKL>
+template <int NS, int K, int NBUF, bool NT, bool TKL, bool W = false>
 __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
+  static_assert(!(TKL && W), "the gate is a TK-Sparse feature");
   static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -528,6 +541,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
   const int rows_last = D - 32 * (nblk_tot - 1);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   float* rdbuf = (float*)(smem + NBUF * kSliceBytes);  // 32 floats: 1/(|d|+tiny) of the block's rows
+  float* wbuf = rdbuf + 32;                            // W: log2 gate of every row of the current document
 
   uint32_t voff[kSliceInstr];
 #pragma unroll
@@ -620,6 +634,12 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
     f32x2 pk2[kMaxK / 2];
 #pragma unroll
     for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
+    if (W) {
+      // plain loads share the vmcnt queue with the LDS-DMA slices, so this wait also lands the prefetched
+      // slices: one drain per document (7 blocks of 3 slices at D = 200), refilled by the next top_up()
+      const float* gw = a.dw + pair * (int64_t)D;
+      for (int j = lane; j < 32 * nb; j += 64) wbuf[j] = j < D ? gate_log2(gw[j]) : -INFINITY;
+    }
 
     for (int t = 0; t < nb; ++t) {
       f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
@@ -696,10 +716,19 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
-      if (TKL)
+      if constexpr (TKL) {
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
-      else
+      } else if constexpr (W) {
+        float lw[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = *(const f32x4*)(wbuf + 32 * t + 8 * g + 4 * h);
+          lw[4 * g + 0] = v[0]; lw[4 * g + 1] = v[1]; lw[4 * g + 2] = v[2]; lw[4 * g + 3] = v[3];
+        }
+        rbf_block<K, true>(pk2, acc, rdr, rq, va, h, rbf, lw);
+      } else {
         rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
+      }
     }
     if (!TKL) {
       float pk[kMaxK];
@@ -1358,9 +1387,10 @@ int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int3
 // ---------------------------------------------------------------------------------------------
 // generic kernel: one wavefront per pair, direct fragment loads, any E % 4 == 0, any Q / D.
 // ---------------------------------------------------------------------------------------------
-template <int K, bool TKL>
+template <int K, bool TKL, bool W = false>
 __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a) {
   __shared__ float rdbuf[32];
+  __shared__ float lwbuf[32];
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
   const int64_t pair = blockIdx.x;
@@ -1428,24 +1458,27 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
       ss += __shfl_xor(ss, 32, 64);
       __syncthreads();
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      if (W && h == 1) lwbuf[r] = drow < D ? gate_log2(a.dw[pair * (int64_t)D + drow]) : -INFINITY;
       __syncthreads();
-      float rdr[16];
+      float rdr[16], lw[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) rdr[i] = rdbuf[rowof(i) + 4 * h];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lw[i] = W ? lwbuf[rowof(i) + 4 * h] : 0.0f;
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (a.dm.bits[pair * nblk_tot + t] & ex) : ex;
       if (TKL)
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, qtok, h, acc, rdr, rq, va >> (4 * h), rbf);
       else
-        rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
+        rbf_block<K, W>(pk2, acc, rdr, rq, va, h, rbf, lw);
     }
     if (TKL) continue;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float pkk = pk2[k >> 1][k & 1];
       const float v = pkk + __shfl_xor(pkk, 32, 64);
-      float lg = __logf(fmaxf(v * rbf.alpha[k], 1e-10f));
+      float lg = __logf(fmaxf(v * rbf.alpha[k], a.clamp_min));
       tot[k] += wave_sum((qvalid && h == 0) ? lg : 0.0f);
     }
   }
@@ -1459,11 +1492,11 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
   if (lane == 0) a.out[pair] = total;
 }
 
-template <int K, bool TKL>
+template <int K, bool TKL, bool W = false>
 static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   KpArgs a = a0;
   constexpr int NBUF = 3;
-  const int lds = NBUF * kSliceBytes + 128;
+  const int lds = NBUF * kSliceBytes + 128 + (W ? 128 * ((a.D + 31) >> 5) : 0);
   int64_t waves = (int64_t)kCUs * 4;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
@@ -1473,7 +1506,7 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   // the default is the split-bf16 kernel (same numerics class, 4x less matrix-pipe time)
   static int f32mfma = -1;
   if (f32mfma < 0) f32mfma = getenv("MM_KP_F32MFMA") ? atoi(getenv("MM_KP_F32MFMA")) : 0;
-  if (f32mfma) {
+  if (f32mfma && !W) {
     if (a.E == 100)
       hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
     else if (a.E == 200)
@@ -1492,11 +1525,11 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
     return check_launch("tkl_stage1_run_kernel");
   } else {
     if (a.E == 100)
-      hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, true, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, true, false, W>), grid, block, lds, stream, a);
     else if (a.E == 200)
-      hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, true, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, true, false, W>), grid, block, lds, stream, a);
     else
-      hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, true, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, true, false, W>), grid, block, lds, stream, a);
     return check_launch("kernel_pool_split_kernel");
   }
 }
@@ -1535,6 +1568,12 @@ static int launch_k(const KpArgs& a0, hipStream_t stream) {
   }
   const bool stream_ok = !force_generic && a.Q <= 32 && (a.E == 100 || a.E == 200 || a.E == 300);
   (void)nbuf_env;
+  if (a.dw) {  // gated (TK-Sparse); the gate vector of a document sits in LDS: D <= 4096 on the streaming path (LDS stays under 64 KB)
+    if (stream_ok && a.D <= 4096) return launch_stream<K, false, true>(a, stream);
+    if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
+    hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false, true>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
+    return check_launch("kernel_pool_generic_kernel<gated>");
+  }
   if (stream_ok) return launch_stream<K, false>(a, stream);
   if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
   hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
@@ -1552,16 +1591,17 @@ extern "C" size_t mm_kernel_pool_workspace_bytes(int64_t n_pairs, int64_t pairs_
          packed_mask_bytes(d_mask_kind, n_pairs, D);
 }
 
-extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
-                                  const void* d_mask, int d_mask_kind, const float* mu, const float* sigma,
-                                  const float* alpha, const float* w, float* out, float* per_kernel,
-                                  int64_t n_pairs, int64_t pairs_per_query, int Q, int D, int E, int K, int dtype,
-                                  void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
+                                     const void* d_mask, int d_mask_kind, const float* d_gate, const float* mu,
+                                     const float* sigma, const float* alpha, const float* w, float clamp_min, float* out,
+                                     float* per_kernel, int64_t n_pairs, int64_t pairs_per_query, int Q, int D, int E,
+                                     int K, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!q || !d || !out || !mu || !sigma || !alpha || !w) return set_error(MM_EINVAL, "kernel_pool: null pointer");
   if (dtype != MM_F32)
     return set_error(MM_EUNSUPPORTED, "kernel_pool: float32 only (the reference cosine rejects bf16; tk.yaml use_fp16: False)");
   if (n_pairs < 0 || Q <= 0 || D <= 0 || E <= 0 || pairs_per_query <= 0) return set_error(MM_EINVAL, "kernel_pool: bad shape");
+  if (!(clamp_min > 0.0f)) return set_error(MM_EINVAL, "kernel_pool: clamp_min must be > 0 (it sits inside a log)");
   if (K != 11) return set_error(MM_EUNSUPPORTED, "kernel_pool: K=%d kernels (only the reference's 11 are instantiated)", K);
   if (E % 4) return set_error(MM_EUNSUPPORTED, "kernel_pool: E=%d rows are not 16-byte multiples", E);
   if (((uintptr_t)q | (uintptr_t)d) & 15) return set_error(MM_EINVAL, "kernel_pool: q/d must be 16-byte aligned");
@@ -1571,10 +1611,20 @@ extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_ma
   a.out = out; a.per_kernel = per_kernel; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
   a.Q = Q; a.D = D; a.E = E; a.K = K;
   a.d_doc_rows = D; a.d_row0 = 0;
+  a.dw = d_gate; a.clamp_min = clamp_min;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, (n_pairs + pairs_per_query - 1) / pairs_per_query, Q, &ws, &left, stream, &a.qm))
     return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
   return launch_k<11>(a, stream);
+}
+
+extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
+                                  const void* d_mask, int d_mask_kind, const float* mu, const float* sigma,
+                                  const float* alpha, const float* w, float* out, float* per_kernel,
+                                  int64_t n_pairs, int64_t pairs_per_query, int Q, int D, int E, int K, int dtype,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  return mm_kernel_pool_ex_fwd(q, d, q_mask, q_mask_kind, d_mask, d_mask_kind, nullptr, mu, sigma, alpha, w, 1e-10f, out,
+                               per_kernel, n_pairs, pairs_per_query, Q, D, E, K, dtype, workspace, workspace_bytes, stream_);
 }

@@ -13,6 +13,10 @@
 //   grad_alpha_k = g w_k sum_i qmask_i [alpha_k pkq_ik >= 1e-10] / alpha_k
 // (the norm's gradient at a zero vector is 0, as torch.norm's backward defines it).
 //
+// Variants (mm_kernel_pool_ex_bwd): a document-token gate s_j >= 0 (TK-Sparse, cikm20_tk_sparse.py:133-135)
+// replaces dmask_j by dmask_j s_j in pkq and G, and gets grad_s_j = dmask_j sum_ik A_ik e_ijk; the floor
+// 1e-10 inside the log is a parameter (1e-4: IDCM sampler, sigir21_idcm.py:185).
+//
 // One workgroup (256 threads) per pair, fp32 VALU throughout: training batches are tens of pairs, so
 // this is a correctness path — what matters is that loss.backward() stays on the device without a
 // [B,Q,D,K] tensor.  Pair-per-row layout (the one train.py feeds: neuralIR_encoder.py:86-87).
@@ -31,6 +35,9 @@ struct KpBwdArgs {
   const float* alpha;
   const float* w;
   const float* go;
+  const float* dw;  // optional gate [n_pairs, D]
+  float* gdw;       // optional grad of the gate [n_pairs, D]
+  float clamp_min;
   float* gq;
   float* gd;
   float* galpha;  // [n_pairs, K]
@@ -78,7 +85,12 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a)
     if (lane == 0) {
       const float n = sqrtf(ss);
       if (row < Q) { nq[row] = n; rq[row] = 1.0f / (n + 1e-13f); qmf[row] = mask_bit(a.qm, pair, qwords, row, Q) ? 1.0f : 0.0f; }
-      else { nd[row - Q] = n; rd[row - Q] = 1.0f / (n + 1e-13f); dmf[row - Q] = mask_bit(a.dm, pair, dwords, row - Q, D) ? 1.0f : 0.0f; }
+      else {
+        const int j = row - Q;
+        nd[j] = n; rd[j] = 1.0f / (n + 1e-13f);
+        const float gate = a.dw ? fmaxf(a.dw[pair * D + j], 0.0f) : 1.0f;   // dmf = mask x gate
+        dmf[j] = mask_bit(a.dm, pair, dwords, j, D) ? gate : 0.0f;
+      }
     }
   }
   __syncthreads();
@@ -103,9 +115,9 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a)
       pk += dmf[j] * __expf(t * t * c2);
     }
     const float al = a.alpha[k];
-    const bool live = al * pk >= 1e-10f;
+    const bool live = al * pk >= a.clamp_min;
     A[i * kBK + k] = live ? g * qmf[i] * a.w[k] / pk : 0.0f;
-    pw[i * kBK + k] = qmf[i] * __logf(fmaxf(al * pk, 1e-10f));   // -> grad_w
+    pw[i * kBK + k] = qmf[i] * __logf(fmaxf(al * pk, a.clamp_min));   // -> grad_w
     pa[i * kBK + k] = live ? qmf[i] * a.w[k] / al : 0.0f;        // -> grad_alpha
   }
   __syncthreads();
@@ -132,9 +144,27 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a)
         s += A[i * kBK + k] * __expf(-0.5f * t * t * inv) * (-t * inv);
       }
     }
-    G[idx] = s;
+    G[idx] = s * dmf[j];
   }
   __syncthreads();
+  // 4b. gradient of the gate: sum_ik A_ik e_ijk on real tokens whose gate is open (relu'(x) = 0 at x <= 0 is
+  // the caller's chain rule; a closed gate still gets the gradient of the product, as autograd gives it)
+  if (a.gdw) {
+    for (int j = tid; j < D; j += 256) {
+      float s = 0.0f;
+      if (mask_bit(a.dm, pair, dwords, j, D)) {
+        for (int i = 0; i < Q; ++i) {
+          const float c = C[i * D + j];
+          for (int k = 0; k < K; ++k) {
+            const float sg = a.sigma[k];
+            const float t = c - a.mu[k];
+            s += A[i * kBK + k] * __expf(-0.5f * t * t / (sg * sg));
+          }
+        }
+      }
+      a.gdw[pair * D + j] = s;
+    }
+  }
   // 5. sum_j G c (per query token) and sum_i G c (per document token)
   for (int i = tid; i < Q; i += 256) {
     float s = 0.0f;
@@ -175,15 +205,18 @@ extern "C" size_t mm_kernel_pool_bwd_workspace_bytes(int64_t n_pairs, int Q, int
   return packed_mask_bytes(q_mask_kind, n_pairs, Q) + packed_mask_bytes(d_mask_kind, n_pairs, D);
 }
 
-extern "C" int mm_kernel_pool_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
-                                  int d_mask_kind, const float* mu, const float* sigma, const float* alpha, const float* w,
-                                  const float* grad_out, float* grad_q, float* grad_d, float* grad_alpha, float* grad_w,
-                                  int64_t n_pairs, int Q, int D, int E, int K, void* workspace, size_t workspace_bytes,
-                                  void* stream_) {
+extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
+                                     int d_mask_kind, const float* d_gate, const float* mu, const float* sigma,
+                                     const float* alpha, const float* w, float clamp_min, const float* grad_out,
+                                     float* grad_q, float* grad_d, float* grad_gate, float* grad_alpha, float* grad_w,
+                                     int64_t n_pairs, int Q, int D, int E, int K, void* workspace, size_t workspace_bytes,
+                                     void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!q || !d || !mu || !sigma || !alpha || !w || !grad_out || !grad_q || !grad_d || !grad_alpha || !grad_w)
     return set_error(MM_EINVAL, "kernel_pool_bwd: null pointer");
+  if (grad_gate && !d_gate) return set_error(MM_EINVAL, "kernel_pool_bwd: grad_gate without d_gate");
   if (n_pairs < 0 || Q <= 0 || D <= 0 || E <= 0 || K <= 0) return set_error(MM_EINVAL, "kernel_pool_bwd: bad shape");
+  if (!(clamp_min > 0.0f)) return set_error(MM_EINVAL, "kernel_pool_bwd: clamp_min must be > 0");
   if (K > kBK) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: K=%d kernels (max %d)", K, kBK);
   if (n_pairs == 0) return MM_OK;
   if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: too many pairs for one launch");
@@ -191,6 +224,7 @@ extern "C" int mm_kernel_pool_bwd(const void* q, const void* d, const void* q_ma
   if (lds > 160 * 1024) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: Q x D = %d x %d exceeds the LDS tile", Q, D);
   KpBwdArgs a{};
   a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w; a.go = grad_out;
+  a.dw = d_gate; a.gdw = grad_gate; a.clamp_min = clamp_min;
   a.gq = grad_q; a.gd = grad_d; a.galpha = grad_alpha; a.gw = grad_w; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E; a.K = K;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
@@ -200,4 +234,14 @@ extern "C" int mm_kernel_pool_bwd(const void* q, const void* d, const void* q_ma
     (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kernel_pool_bwd_kernel, dim3((unsigned)n_pairs), dim3(256), lds, stream, a);
   return check_launch("kernel_pool_bwd_kernel");
+}
+
+extern "C" int mm_kernel_pool_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
+                                  int d_mask_kind, const float* mu, const float* sigma, const float* alpha, const float* w,
+                                  const float* grad_out, float* grad_q, float* grad_d, float* grad_alpha, float* grad_w,
+                                  int64_t n_pairs, int Q, int D, int E, int K, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
+  return mm_kernel_pool_ex_bwd(q, d, q_mask, q_mask_kind, d_mask, d_mask_kind, nullptr, mu, sigma, alpha, w, 1e-10f, grad_out,
+                               grad_q, grad_d, nullptr, grad_alpha, grad_w, n_pairs, Q, D, E, K, workspace, workspace_bytes,
+                               stream_);
 }

@@ -198,12 +198,15 @@ def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Ten
 
 def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
                 mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor,
-                pairs_per_query: int = 1, return_per_kernel: bool = False):
+                pairs_per_query: int = 1, return_per_kernel: bool = False,
+                d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10):
     """TK kernel pooling (matchmaker/models/published/ecai20_tk.py:105-124).
 
     q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings; mu/sigma/alpha/w [K].
+    d_gate [n_pairs, D] >= 0 (optional): TK-Sparse's stop-word vector (cikm20_tk_sparse.py:133-135);
+    clamp_min: floor inside the log (1e-4: IDCM sampler, sigir21_idcm.py:185).
     Returns float32 [n_pairs] (and per_kernel [n_pairs, K] when asked)."""
-    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w)
+    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != torch.float32 or d.dtype != torch.float32:
         raise NativeError("kernel_pool: float32 embeddings only (the reference cosine rejects bf16, "
@@ -221,6 +224,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
         raise NativeError("kernel_pool: mu/sigma/alpha/w must all have K elements")
     qm, qp, qk = _mask(q_mask, nq, Q, "q_mask")
     dm, dp, dk = _mask(d_mask, B, D, "d_mask")
+    gate = _gate(d_gate, B, D)
     L = _lib.lib()
     out = torch.empty(B, dtype=torch.float32, device=dev)
     pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
@@ -228,20 +232,32 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
         with torch.cuda.device(dev):
             wsb = L.mm_kernel_pool_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-            rc = L.mm_kernel_pool_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, mu.data_ptr(), sigma.data_ptr(),
-                                      alpha.data_ptr(), w.data_ptr(), out.data_ptr(),
-                                      pk.data_ptr() if pk is not None else None, B, pairs_per_query,
-                                      Q, D, E, K, _lib.MM_F32, ws.data_ptr() if ws is not None else None, wsb,
-                                      _stream(dev))
-        _lib.check(rc, "mm_kernel_pool_fwd")
+            rc = L.mm_kernel_pool_ex_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
+                                         gate.data_ptr() if gate is not None else None, mu.data_ptr(),
+                                         sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
+                                         out.data_ptr(), pk.data_ptr() if pk is not None else None, B,
+                                         pairs_per_query, Q, D, E, K, _lib.MM_F32,
+                                         ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+        _lib.check(rc, "mm_kernel_pool_ex_fwd")
     return (out, pk) if return_per_kernel else out
 
 
+def _gate(d_gate, B, D):
+    if d_gate is None:
+        return None
+    g = d_gate.detach().reshape(B, -1).to(torch.float32).contiguous()
+    if g.shape[1] != D:
+        raise NativeError(f"d_gate has shape {tuple(d_gate.shape)} for {B} documents of {D} tokens")
+    return g
+
+
 def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
-                    mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor, grad_out: torch.Tensor):
-    """Backward of kernel_pool in the pair-per-row layout (mm_kernel_pool_bwd).  Returns float32
-    (grad_q [B,Q,E], grad_d [B,D,E], grad_alpha [K], grad_w [K])."""
-    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, grad_out)
+                    mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor, grad_out: torch.Tensor,
+                    d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10):
+    """Backward of kernel_pool in the pair-per-row layout (mm_kernel_pool_ex_bwd).  Returns float32
+    (grad_q [B,Q,E], grad_d [B,D,E], grad_alpha [K], grad_w [K]) and, with d_gate, grad_gate [B,D] as a
+    fifth element."""
+    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, grad_out, d_gate)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != torch.float32 or d.dtype != torch.float32:
         raise NativeError("kernel_pool_bwd: float32 embeddings only")
@@ -262,15 +278,21 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
     gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
     ga = torch.zeros((B, K), dtype=torch.float32, device=dev)
     gw = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    gate = _gate(d_gate, B, D)
+    gg = torch.zeros((B, D), dtype=torch.float32, device=dev) if gate is not None else None
     if B:
         with torch.cuda.device(dev):
             wsb = L.mm_kernel_pool_bwd_workspace_bytes(B, Q, D, qk, dk)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-            rc = L.mm_kernel_pool_bwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, mu.data_ptr(), sigma.data_ptr(),
-                                      alpha.data_ptr(), w.data_ptr(), go.data_ptr(), gq.data_ptr(), gd.data_ptr(),
-                                      ga.data_ptr(), gw.data_ptr(), B, Q, D, E, K,
-                                      ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
-        _lib.check(rc, "mm_kernel_pool_bwd")
+            rc = L.mm_kernel_pool_ex_bwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
+                                         gate.data_ptr() if gate is not None else None, mu.data_ptr(),
+                                         sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
+                                         go.data_ptr(), gq.data_ptr(), gd.data_ptr(),
+                                         gg.data_ptr() if gg is not None else None, ga.data_ptr(), gw.data_ptr(),
+                                         B, Q, D, E, K, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+        _lib.check(rc, "mm_kernel_pool_ex_bwd")
+    if gate is not None:
+        return gq, gd, ga.sum(0), gw.sum(0), gg
     return gq, gd, ga.sum(0), gw.sum(0)
 
 

@@ -28,19 +28,23 @@ def sinusoid_positions(dim: int, length: int, min_timescale: float = 1.0, max_ti
 
 
 class _KernelPoolFn(torch.autograd.Function):
-    """Native forward (mm_kernel_pool_fwd) and native backward (mm_kernel_pool_bwd) of the pooling block
-    for the training path (train.py:347-348 / :503-524)."""
+    """Native forward (mm_kernel_pool_ex_fwd) and native backward (mm_kernel_pool_ex_bwd) of the pooling
+    block for the training path (train.py:347-348 / :503-524).  gate / clamp_min: the TK-Sparse and IDCM
+    variants (ops.kernel_pool)."""
 
     @staticmethod
-    def forward(ctx, q, d, q_mask, d_mask, mu, sigma, alpha, w):
-        ctx.save_for_backward(q, d, q_mask, d_mask, mu, sigma, alpha, w)
-        return ops.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w)
+    def forward(ctx, q, d, q_mask, d_mask, mu, sigma, alpha, w, gate=None, clamp_min=1e-10):
+        ctx.save_for_backward(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate)
+        ctx.clamp_min = clamp_min
+        return ops.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate=gate, clamp_min=clamp_min)
 
     @staticmethod
     def backward(ctx, g):
-        q, d, q_mask, d_mask, mu, sigma, alpha, w = ctx.saved_tensors
-        gq, gd, ga, gw = ops.kernel_pool_bwd(q, d, q_mask, d_mask, mu, sigma, alpha, w, g)
-        return gq, gd, None, None, None, None, ga.view_as(alpha), gw.view_as(w)
+        q, d, q_mask, d_mask, mu, sigma, alpha, w, gate = ctx.saved_tensors
+        r = ops.kernel_pool_bwd(q, d, q_mask, d_mask, mu, sigma, alpha, w, g, d_gate=gate, clamp_min=ctx.clamp_min)
+        gq, gd, ga, gw = r[:4]
+        gg = r[4].view_as(gate) if gate is not None else None
+        return gq, gd, None, None, None, None, ga.view_as(alpha), gw.view_as(w), gg, None
 
 
 class ECAI20_TK(nn.Module):

@@ -164,6 +164,52 @@ def knrm_kernel_pool(q, d, q_mask, d_mask, mu, sigma, w, dtype=np.float32, retur
     return score
 
 
+def tk_sparse_kernel_pool(q, d, q_mask, d_mask, stop_words, mu, sigma, alpha, w, dtype=np.float32,
+                          return_per_kernel=False):
+    """CIKM20_TK_Sparse.forward scoring block — published/cikm20_tk_sparse.py:106-146.
+
+    q, d: the mixed (and masked, :170) contextualised embeddings; stop_words [B, D] = document_stop_words
+    (:133, ReLU output already multiplied by the document mask) — the MLP that makes it stays PyTorch."""
+    qm = np.asarray(q_mask, dtype=dtype)
+    dm = np.asarray(d_mask, dtype=dtype)
+    qd = qm[:, :, None] * dm[:, None, :]                                         # :106
+    cos = cosine_matrix(q, d, dtype) * qd                                        # :113-114
+    mu = np.asarray(mu, dtype=dtype).reshape(1, 1, 1, -1)
+    sigma = np.asarray(sigma, dtype=dtype).reshape(1, 1, 1, -1)
+    raw = np.exp(-np.power(cos[..., None] - mu, 2) / (2 * np.power(sigma, 2)))   # :122
+    sw = np.asarray(stop_words, dtype=dtype)
+    masked = raw * qd[..., None] * sw[:, None, :, None]                          # :135
+    pkq = masked.sum(2, dtype=dtype)                                             # :141
+    alpha = np.asarray(alpha, dtype=dtype).reshape(1, 1, -1)
+    lg = np.log(np.maximum(pkq * alpha, dtype(1e-10))) * qm[..., None]           # :142-143
+    per_kernel = lg.sum(1, dtype=dtype)                                          # :144
+    score = per_kernel @ np.asarray(w, dtype=dtype).reshape(-1)                  # :145
+    if return_per_kernel:
+        return score, per_kernel
+    return score
+
+
+def idcm_sampler_scores(query_ctx, document_ctx, q_mask, d_mask, mu, sigma, alpha, w, bias, dtype=np.float32):
+    """IDCM's fast passage-selection score (ESM) — published/sigir21_idcm.py:169-186.
+
+    query_ctx [P,Q,E], document_ctx [P,D,E]: the sampler's contextualised vectors BEFORE
+    torch.nn.functional.normalize (:169-170: x / max(|x|_2, 1e-12)); masks {0,1}; w [K], bias scalar =
+    sampling_binweights (Linear(11, 1, bias=True), :102).  Returns packed_patch_scores [P]."""
+    def normalize(x):
+        x = np.asarray(x, dtype=dtype)
+        n = np.sqrt((x * x).sum(-1, keepdims=True, dtype=dtype))
+        return x / np.maximum(n, dtype(1e-12))
+    cos = np.matmul(normalize(query_ctx), np.swapaxes(normalize(document_ctx), -1, -2))        # :182
+    mu = np.asarray(mu, dtype=dtype).reshape(1, 1, 1, -1)
+    sigma = np.asarray(sigma, dtype=dtype).reshape(1, 1, 1, -1)
+    dm = np.asarray(d_mask, dtype=dtype)
+    act = np.exp(-np.power(cos[..., None] - mu, 2) / (2 * np.power(sigma, 2))) * dm[:, None, :, None]   # :184
+    alpha = np.asarray(alpha, dtype=dtype).reshape(1, 1, -1)
+    qm = np.asarray(q_mask, dtype=dtype)
+    res = np.log(np.maximum(act.sum(2, dtype=dtype) * alpha, dtype(1e-4))) * qm[..., None]     # :185
+    return res.sum(1, dtype=dtype) @ np.asarray(w, dtype=dtype).reshape(-1) + dtype(bias)      # :186
+
+
 # ----------------------------------------------------------------------------- TKL
 
 TKL_CHUNK = 40       # sigir20_tkl.py:52

@@ -179,6 +179,44 @@ def tk_forward(model, q, d, q_mask, d_mask, secondary=False):
         return model.forward(q, d, q_mask, d_mask, secondary)
 
 
+# --------------------------------------------------------------------------- TK-Sparse
+def make_tk_sparse(embsize=300, mu=TK_MU, sigma=TK_SIGMA, bypass_contextualizer=True, seed=0,
+                   att_heads=10, att_layer=2, att_ff_dim=300, max_length=200):
+    """Real CIKM20_TK_Sparse (published/cikm20_tk_sparse.py).  bypass: forward_representation returns
+    (emb * mask, emb) — the mask multiply of :170 kept, positional encoding + Transformer dropped — so the
+    scoring block :106-146 and the stop-word MLP :132-133 run on known inputs."""
+    install_shims()
+    from matchmaker.models.published.cikm20_tk_sparse import CIKM20_TK_Sparse
+
+    class TKS(CIKM20_TK_Sparse):
+        def get_range_vector(self, size, device):  # CPU branch of cikm20_tk_sparse.py:237-245
+            return torch.arange(0, size, dtype=torch.long)
+
+    class TKSBypass(TKS):
+        def forward_representation(self, emb, mask, positional_features=None):
+            return emb * mask.unsqueeze(-1), emb
+
+    torch.manual_seed(seed)
+    cls = TKSBypass if bypass_contextualizer else TKS
+    m = cls(embsize, mu, sigma, att_heads, att_layer, 32, att_ff_dim, max_length, True)
+    m.eval()
+    return m
+
+
+# --------------------------------------------------------------------------- IDCM
+def make_idcm(bert, sample_n=2, sample_context="ck-small", top_k_chunks=2, chunk_size=50, overlap=7,
+              sample_train_type="mseloss", seed=0):
+    """Real IDCM (published/sigir21_idcm.py) around a given (randomly initialised) DistilBERT."""
+    install_shims()
+    from matchmaker.models.published.sigir21_idcm import IDCM
+
+    torch.manual_seed(seed)
+    m = IDCM(bert, sample_train_type=sample_train_type, sample_n=sample_n, sample_context=sample_context,
+             top_k_chunks=top_k_chunks, chunk_size=chunk_size, overlap=overlap, padding_idx=0)
+    m.eval()
+    return m
+
+
 # --------------------------------------------------------------------------- KNRM
 def make_knrm(n_kernels=11, seed=0):
     """Real KNRM (matchmaker/models/knrm.py); its constructor builds mu/sigma with torch.cuda.FloatTensor

@@ -56,3 +56,30 @@ def tk_kernel_pool(query_embeddings, document_embeddings, query_mask, document_m
     log_per_kernel_query_masked = log_per_kernel_query * query_mask.unsqueeze(-1)               # :122
     per_kernel = torch.sum(log_per_kernel_query_masked, 1)                                      # :123
     return torch.nn.functional.linear(per_kernel, weight).squeeze(1)                            # :124
+
+
+def tk_sparse_kernel_pool(query_embeddings, document_embeddings, query_mask, document_mask, document_stop_words,
+                          mu, sigma, alpha, weight):
+    """CIKM20_TK_Sparse.forward scoring block — published/cikm20_tk_sparse.py:106-146.
+    document_stop_words [B,1,D] (:133); mu, sigma [1,1,1,K]; alpha [1,1,K]; weight [1,K]."""
+    query_by_doc_mask = torch.bmm(query_mask.unsqueeze(-1), document_mask.unsqueeze(-1).transpose(-1, -2))   # :106
+    cosine_masked = cosine_matrix(query_embeddings, document_embeddings) * query_by_doc_mask                # :113-114
+    raw_kernel_results = torch.exp(- torch.pow(cosine_masked.unsqueeze(-1) - mu, 2) / (2 * torch.pow(sigma, 2)))  # :122
+    kernel_results_masked = raw_kernel_results * query_by_doc_mask.unsqueeze(-1) * document_stop_words.unsqueeze(-1)  # :135
+    per_kernel_query = torch.sum(kernel_results_masked, 2)                                      # :141
+    log_per_kernel_query = torch.log(torch.clamp(per_kernel_query * alpha, min=1e-10))          # :142
+    per_kernel = torch.sum(log_per_kernel_query * query_mask.unsqueeze(-1), 1)                  # :143-144
+    return torch.nn.functional.linear(per_kernel, weight).squeeze(1)                            # :145
+
+
+def idcm_sampler_scores(query_ctx, document_ctx, query_mask, document_mask, mu, sigma, alpha, weight, bias):
+    """IDCM passage-sampler score — published/sigir21_idcm.py:169-186 (query_ctx / document_ctx BEFORE the
+    normalize of :169-170).  mu, sigma [1,1,1,K]; alpha [1,1,K]; weight [1,K], bias [1]."""
+    query_ctx = torch.nn.functional.normalize(query_ctx, p=2, dim=-1)                           # :169
+    document_ctx = torch.nn.functional.normalize(document_ctx, p=2, dim=-1)                     # :170
+    cosine_matrix_ = torch.bmm(query_ctx, document_ctx.transpose(-1, -2)).unsqueeze(-1)         # :182
+    kernel_activations = torch.exp(- torch.pow(cosine_matrix_ - mu, 2) / (2 * torch.pow(sigma, 2))) * \
+        document_mask.unsqueeze(-1).unsqueeze(1)                                                # :184
+    kernel_res = torch.log(torch.clamp(torch.sum(kernel_activations, 2) * alpha, min=1e-4)) * \
+        query_mask.unsqueeze(-1)                                                                # :185
+    return torch.nn.functional.linear(torch.sum(kernel_res, 1), weight, bias)                   # :186  [P,1]

@@ -249,14 +249,91 @@ def gen_tkl():
                             **{"param." + k: v for k, v in sd.items()})
 
 
+def gen_tk_sparse():
+    # TK-Sparse scoring block (cikm20_tk_sparse.py:106-146) at TK's shapes with the contextualiser bypassed
+    # (the stop-word MLP :132-133 is live), and the whole class end to end at small dims.
+    g = torch.Generator().manual_seed(1401)
+    B, Q, D, E = 4, 20, 200, 300
+    q = fp16_round(torch.randn(B, Q, E, generator=g))
+    d = fp16_round(torch.randn(B, D, E, generator=g))
+    d[0, 3] = q[0, 1]
+    d[1, 7] = fp16_round(q[1, 2] + 0.05 * torch.randn(E, generator=g))
+    qm = prefix_mask(torch.tensor([20, 11, 3, 20]), Q, torch.float32)
+    dm = prefix_mask(torch.tensor([200, 10, 77, 133]), D, torch.float32)
+    m = R.make_tk_sparse(E, seed=31)
+    with torch.no_grad():
+        m.kernel_alpha_scaler.uniform_(0.5, 1.5, generator=g)
+        m.kernel_bin_weights.weight.uniform_(-0.5, 0.5, generator=g)
+        m.stop_word_reducer2.weight.uniform_(-0.3, 0.3, generator=g)   # a gate that is closed for about half the tokens
+        m.stop_word_reducer2.bias.fill_(0.05)
+        score, sec, stop = m.forward(q, d, qm, dm, True)
+    assert 0.2 < (stop[0, 0] == 0).float().mean() < 0.8
+    sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()
+          if not k.startswith("contextualizer") and not k.startswith("positional")}
+    np.savez_compressed(os.path.join(OUT, "sparse_tk_q20_d200_e300.npz"),
+                        q_fp16=q.to(torch.float16).numpy(), d_fp16=d.to(torch.float16).numpy(),
+                        q_mask=qm.numpy(), d_mask=dm.numpy(), score=score.numpy(),
+                        per_kernel=sec["per_kernel"].numpy(), document_stop_words=stop.numpy(), **sd)
+
+    B, Q, D, E = 5, 12, 70, 60
+    q = torch.randn(B, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    qm = prefix_mask(torch.tensor([12, 3, 7, 12, 1]), Q, torch.float32)
+    dm = prefix_mask(torch.tensor([70, 20, 5, 33, 64]), D, torch.float32)
+    m = R.make_tk_sparse(E, bypass_contextualizer=False, att_heads=6, att_ff_dim=32, max_length=80, seed=32)
+    with torch.no_grad():
+        m.kernel_alpha_scaler.uniform_(0.5, 1.5, generator=g)
+        m.kernel_bin_weights.weight.uniform_(-0.5, 0.5, generator=g)
+        m.stop_word_reducer2.weight.uniform_(-0.3, 0.3, generator=g)
+        m.stop_word_reducer2.bias.fill_(0.05)
+        score, stop = m.forward(q, d, qm, dm)
+    sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "e2e_sparse_tk_q12_d70_e60.npz"), q=q.numpy(), d=d.numpy(), q_mask=qm.numpy(),
+                        d_mask=dm.numpy(), score=score.numpy(), document_stop_words=stop.numpy(), **sd)
+
+
+def gen_idcm():
+    # the real IDCM class end to end (sigir21_idcm.py:111-274), eval mode, around a tiny random DistilBERT:
+    # windowing, the kernel-pooling passage sampler (:167-186), selection, BERT passage scores, top-k combination
+    from transformers import DistilBertConfig, DistilBertModel
+    for ctx_kind, seed in (("ck", 41), ("ck-small", 42)):
+        cfg = DistilBertConfig(vocab_size=200, dim=64, n_heads=4, hidden_dim=128, n_layers=2,
+                               max_position_embeddings=128, dropout=0.0, attention_dropout=0.0)
+        torch.manual_seed(seed)
+        bert = DistilBertModel(cfg).eval()
+        m = R.make_idcm(bert, sample_n=2, sample_context=ctx_kind, top_k_chunks=2, seed=seed + 100)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            m.kernel_alpha_scaler.uniform_(0.5, 1.5, generator=g)
+            m.sampling_binweights.weight.uniform_(-0.5, 0.5, generator=g)
+            m.sampling_binweights.bias.fill_(0.3)
+            m.top_k_scoring.uniform_(0.5, 1.5, generator=g)
+        B, LQ, LD = 4, 12, 221
+        q_len = torch.tensor([12, 7, 12, 3])
+        d_len = torch.tensor([221, 60, 120, 8])
+        q_mask = prefix_mask(q_len, LQ, torch.long)
+        d_mask = prefix_mask(d_len, LD, torch.long)
+        q_ids = torch.randint(1, 200, (B, LQ), generator=g) * q_mask
+        d_ids = torch.randint(1, 200, (B, LD), generator=g) * d_mask
+        d_ids[0, 60:70] = q_ids[0, 1:11]                           # a passage that repeats the query
+        with torch.no_grad():
+            score, bert_scores, sec, _, _ = m.forward({"input_ids": q_ids, "attention_mask": q_mask},
+                                                      {"input_ids": d_ids, "attention_mask": d_mask},
+                                                      use_fp16=False, output_secondary_output=True)
+        sd = {("param." + k): v.detach().numpy() for k, v in m.state_dict().items()}
+        np.savez_compressed(os.path.join(OUT, "idcm_" + ctx_kind.replace("-", "_") + ".npz"),
+                            q_ids=q_ids.numpy(), q_mask=q_mask.numpy(), d_ids=d_ids.numpy(), d_mask=d_mask.numpy(),
+                            score=score.numpy(), bert_scores=bert_scores.numpy(),
+                            sampling_scores=sec["sampling_scores"].numpy(),
+                            packed_indices=sec["packed_indices"].numpy(), **sd)
+
+
+GENERATORS = {"colbert": gen_colbert, "colbert_e2e": gen_colbert_e2e, "e2e_tk_tkl": gen_e2e_tk_tkl, "tk": gen_tk,
+              "knrm": gen_knrm, "conv_knrm": gen_conv_knrm, "tkl": gen_tkl, "tk_sparse": gen_tk_sparse, "idcm": gen_idcm}
+
 if __name__ == "__main__":
-    gen_colbert()
-    gen_colbert_e2e()
-    gen_e2e_tk_tkl()
-    gen_tk()
-    gen_knrm()
-    gen_conv_knrm()
-    gen_tkl()
+    for name in (sys.argv[1:] or list(GENERATORS)):      # python gen_golden.py [generator ...]
+        GENERATORS[name]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

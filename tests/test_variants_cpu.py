@@ -1,0 +1,113 @@
+"""CPU: the TK-Sparse and IDCM-sampler restatements (oracle/np_oracle.py, oracle/torch_port.py) against golden
+vectors of the real classes (tests/golden/gen_golden.py: gen_tk_sparse, gen_idcm), and the host logic of the
+IDCM drop-in (windowing, selection, top-k combination) with the oracle standing in for the native operator —
+tests may use the oracle; the product path has no CPU fallback (asserted at the end)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from oracle import torch_port as TP
+from tests import util
+
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+SIGMA = [0.1] * 11
+
+
+def _params(g):
+    return {k[len("param."):]: v for k, v in g.items() if k.startswith("param.")}
+
+
+def test_tk_sparse_oracle_matches_reference_golden():
+    g = util.load("sparse_tk_q20_d200_e300.npz")
+    p = _params(g)
+    q, d, qm, dm = g["q"], g["d"], g["q_mask"], g["d_mask"]
+    # the gate as the reference's MLP makes it (:132-133; bypassed contextualiser: both mix inputs are d)
+    h = np.tanh(d @ p["stop_word_reducer.weight"].T + p["stop_word_reducer.bias"])
+    gate = np.maximum(h @ p["stop_word_reducer2.weight"].T + p["stop_word_reducer2.bias"], 0)[..., 0] * dm
+    np.testing.assert_allclose(gate, g["document_stop_words"][:, 0], atol=2e-5)
+    assert 0.2 < (gate[0] == 0).mean() < 0.8, "the fixture must exercise closed and open gates"
+    qin, din = q * qm[..., None], d * dm[..., None]                # forward_representation's mask multiply (:170)
+    for dtype, tol in ((np.float32, 3e-4), (np.float64, 3e-4)):
+        s, pk = O.tk_sparse_kernel_pool(qin, din, qm, dm, g["document_stop_words"][:, 0], MU, SIGMA,
+                                        p["kernel_alpha_scaler"].reshape(-1), p["kernel_bin_weights.weight"].reshape(-1),
+                                        dtype=dtype, return_per_kernel=True)
+        np.testing.assert_allclose(pk, g["per_kernel"], atol=tol, rtol=2e-5)
+        np.testing.assert_allclose(s, g["score"], atol=tol, rtol=2e-5)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).float()
+    st = TP.tk_sparse_kernel_pool(t(qin), t(din), t(qm), t(dm), t(g["document_stop_words"]),
+                                  torch.tensor(MU).view(1, 1, 1, -1), torch.tensor(SIGMA).view(1, 1, 1, -1),
+                                  t(p["kernel_alpha_scaler"]), t(p["kernel_bin_weights.weight"]))
+    np.testing.assert_allclose(st.numpy(), g["score"], atol=3e-4, rtol=2e-5)
+
+
+def test_gate_is_tk_with_weighted_document_mask():
+    """The scoring block of TK-Sparse equals TK's with the {0,1} document mask replaced by mask x gate: the
+    identity the native kernel relies on (cosine masking before the kernels, :114, changes no pooled sum)."""
+    rng = np.random.default_rng(5)
+    B, Q, D, E = 3, 7, 19, 16
+    q, d = rng.standard_normal((B, Q, E)).astype(np.float32), rng.standard_normal((B, D, E)).astype(np.float32)
+    qm = (np.arange(Q)[None] < np.array([7, 3, 1])[:, None]).astype(np.float32)
+    dm = (np.arange(D)[None] < np.array([19, 4, 11])[:, None]).astype(np.float32)
+    gate = np.maximum(rng.standard_normal((B, D)), 0).astype(np.float32) * dm
+    alpha, w = rng.random(11).astype(np.float32) + 0.5, rng.standard_normal(11).astype(np.float32)
+    a = O.tk_sparse_kernel_pool(q, d, qm, dm, gate, MU, SIGMA, alpha, w, dtype=np.float64)
+    b = O.tk_kernel_pool(q, d, qm, gate, MU, SIGMA, alpha, w, dtype=np.float64)       # gate in the mask's place
+    np.testing.assert_allclose(a, b, atol=1e-9)
+
+
+def _tiny_distilbert():
+    from transformers import DistilBertConfig, DistilBertModel
+    cfg = DistilBertConfig(vocab_size=200, dim=64, n_heads=4, hidden_dim=128, n_layers=2,
+                           max_position_embeddings=128, dropout=0.0, attention_dropout=0.0)
+    return DistilBertModel(cfg).eval()
+
+
+def _oracle_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, clamp_min=1e-10, **kw):
+    assert clamp_min == 1e-4 and kw.get("d_gate") is None
+    n = lambda t: t.detach().cpu().numpy()
+    s = O.idcm_sampler_scores(n(q), n(d), n(q_mask), n(d_mask), n(mu).reshape(-1), n(sigma).reshape(-1),
+                              n(alpha).reshape(-1), n(w).reshape(-1), 0.0)
+    return torch.from_numpy(s.astype(np.float32))
+
+
+@pytest.mark.parametrize("fname,ctx_kind", [("idcm_ck.npz", "ck"), ("idcm_ck_small.npz", "ck-small")])
+def test_idcm_host_logic_and_sampler_oracle_match_reference_golden(monkeypatch, fname, ctx_kind):
+    from matchmaker_amd import idcm, ops
+    g = util.load(fname)
+    m = idcm.IDCM(_tiny_distilbert(), sample_n=2, sample_context=ctx_kind, top_k_chunks=2, chunk_size=50, overlap=7,
+                  padding_idx=0, sample_train_type="mseloss")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _params(g).items()}, strict=True)
+    m.eval()
+    monkeypatch.setattr(ops, "kernel_pool", _oracle_kernel_pool)
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        score, bert_scores, sec, _, _ = m.forward({"input_ids": t("q_ids"), "attention_mask": t("q_mask")},
+                                                  {"input_ids": t("d_ids"), "attention_mask": t("d_mask")},
+                                                  use_fp16=False, output_secondary_output=True)
+        plain = m.forward({"input_ids": t("q_ids"), "attention_mask": t("q_mask")},
+                          {"input_ids": t("d_ids"), "attention_mask": t("d_mask")}, use_fp16=False)
+    assert (sec["packed_indices"].numpy() == g["packed_indices"]).all()
+    np.testing.assert_allclose(sec["sampling_scores"].numpy(), g["sampling_scores"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(bert_scores.numpy(), g["bert_scores"], atol=1e-5)
+    np.testing.assert_allclose(score.numpy(), g["score"], atol=1e-5)
+    # the cached-BERT path (re-ranking with stored passage scores) reproduces the same document score
+    with torch.no_grad():
+        cached = m.forward({"input_ids": t("q_ids"), "attention_mask": t("q_mask")},
+                           {"input_ids": t("d_ids"), "attention_mask": t("d_mask")}, use_fp16=False,
+                           output_secondary_output=True, bert_part_cached=torch.from_numpy(g["bert_scores"]).clone())[0]
+    np.testing.assert_allclose(cached.numpy(), g["score"], atol=1e-5)
+    # training mode without the secondary output: (score, passage scores, [[loss]], orders)
+    m.train()
+    out = m.forward({"input_ids": t("q_ids"), "attention_mask": t("q_mask")},
+                    {"input_ids": t("d_ids"), "attention_mask": t("d_mask")}, use_fp16=False)
+    assert len(out) == 4 and out[2][0][0].dim() == 0 and out[3][0].shape == g["packed_indices"].shape
+    assert isinstance(plain, tuple) and len(plain) == 4      # eval without secondary output takes the same branch
+
+
+def test_variant_operators_have_no_cpu_fallback():
+    from matchmaker_amd import ops
+    q, d = torch.zeros(1, 4, 8), torch.zeros(1, 5, 8)
+    z = torch.zeros(11)
+    with pytest.raises(ops.NativeError):
+        ops.kernel_pool(q, d, None, None, z, z + 0.1, z + 1, z, d_gate=torch.ones(1, 5), clamp_min=1e-4)
