@@ -162,11 +162,17 @@ int mm_kernel_pool_fwd(const void* q, const void* d,
  *   clamp_min  the floor inside the log: 1e-10 for TK / TK-Sparse (ecai20_tk.py:121, cikm20_tk_sparse.py:142),
  *              1e-4 for the IDCM passage sampler (matchmaker/models/published/sigir21_idcm.py:182-186, whose
  *              pre-normalised vectors make the cosine's own normalisation a no-op).  Must be > 0.
- * Everything else as mm_kernel_pool_fwd (which calls this with NULL, 1e-10). */
+ *   pair_query optional int32 [n_pairs]: the query row of every pair, for ragged groups — IDCM scores a
+ *              different number of passages per document against the document's query (the reference
+ *              materialises one query copy per passage, sigir21_idcm.py:143-144).  With it q / q_mask have
+ *              n_queries rows and pairs_per_query is ignored; NULL = the uniform pairs_per_query layout.
+ *              Consecutive equal entries reuse the query tile already in registers.
+ * Everything else as mm_kernel_pool_fwd (which calls this with NULL, NULL, 0, ..., 1e-10). */
 int mm_kernel_pool_ex_fwd(const void* q, const void* d,
                           const void* q_mask, int q_mask_kind,
                           const void* d_mask, int d_mask_kind,
                           const float* d_gate,
+                          const int32_t* pair_query, int64_t n_queries,
                           const float* mu, const float* sigma, const float* alpha, const float* w,
                           float clamp_min,
                           float* out, float* per_kernel,

@@ -1,0 +1,278 @@
+// Streaming kernel pooling for embedding widths that are multiples of 64 floats (E = 64*NSL <= 384):
+// Conv-KNRM's n-gram vectors (conv_out_dim 128, conv_knrm.py:144-170), IDCM's passage sampler
+// ("ck-small" 128, "tk" 384; sigir21_idcm.py:167-186) and any TK / KNRM run on 64n-wide embeddings.
+// Same arithmetic as kernel_pool_split_kernel (split-bf16 dot products: x = hi + lo, 4 bf16 MFMAs per
+// 16-wide K step; RBF epilogue of kp_device.h), different tiling of the stream:
+//
+//   slice  = 32 document tokens x 64 floats (16 chunks of 16 B) = 8 KiB = 8 LDS-DMA instructions;
+//            a block of 32 tokens is NSL slices, NBUF = 4 slices (32 KiB) in flight per wavefront so that
+//            four single-wave workgroups fit a CU's 160 KiB;
+//   LDS    row stride 256 B would put the 16 rows of a ds_read_b128 service group on one bank slot, so
+//            chunk c of row r is stored at slot c ^ (r & 15) — the swizzle costs nothing because every
+//            LDS-DMA lane fetches from its own global address;
+//   K step p (0..3) of a slice: lane (r, h) feeds floats 16p + 8h .. +7 of row r (chunks 4p+2h, 4p+2h+1);
+//   query  tile as bf16 hi / lo B fragments in VGPRs: 4*NSL steps x 8 registers (192 at E = 384).
+#include "mm_internal.h"
+#include "kp_device.h"
+
+namespace mm {
+
+constexpr int kS128Instr = 8;
+constexpr int kS128Bytes = kS128Instr * 1024;
+constexpr int kS128Steps = 4;
+constexpr int kS128Nbuf = 4;
+
+__device__ __forceinline__ void issue_slice8(const char* gbase, const uint32_t (&v)[kS128Instr], uint32_t lds_dst) {
+  uint32_t keep;
+#define MM_GLDS(N) "s_nop 0\n\tglobal_load_lds_dwordx4 %" #N ", %9 nt\n\ts_add_u32 m0, m0, 0x400\n\t"
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %10\n\t" MM_GLDS(1) MM_GLDS(2) MM_GLDS(3) MM_GLDS(4)
+                   MM_GLDS(5) MM_GLDS(6) MM_GLDS(7) MM_GLDS(8) "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(gbase),
+                 "s"(lds_dst)
+               : "memory", "scc");
+#undef MM_GLDS
+}
+
+// wait until at most `younger` whole slices are still in flight (extra vector loads in the queue — the
+// query tile, the gate — only make this wait longer, never shorter: completion is in order)
+__device__ __forceinline__ void wait_slices8(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+  }
+}
+
+template <int NSL, int K, bool W>
+__global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NBUF = kS128Nbuf;
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  constexpr int E = 64 * NSL;
+  constexpr int RB = E * 4;
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* rdbuf = (float*)(smem + NBUF * kS128Bytes);
+  float* wbuf = rdbuf + 32;
+
+  // LDS-DMA source offsets: slot s = 64n + lane -> row s >> 4, stored chunk s & 15 <- global chunk (s & 15) ^ (row & 15)
+  uint32_t voff[kS128Instr], voff_tail[kS128Instr];
+#pragma unroll
+  for (int n = 0; n < kS128Instr; ++n) {
+    const int s = 64 * n + lane;
+    const int row = s >> 4, c = (s & 15) ^ (row & 15);
+    const int row_t = row < rows_last ? row : rows_last - 1;  // last block of a document: stay inside it
+    voff[n] = (uint32_t)(row * RB + c * 16);
+    voff_tail[n] = (uint32_t)(row_t * RB + c * 16);
+  }
+  // A-fragment read offsets of this lane inside a slice (swizzled)
+  uint32_t aoff[kS128Steps][2];
+#pragma unroll
+  for (int p = 0; p < kS128Steps; ++p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) aoff[p][j] = (uint32_t)(r * 256 + (((4 * p + 2 * h + j) ^ (r & 15)) << 4));
+
+  Rbf rbf;
+  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+
+  const char* dbase = (const char*)a.d;
+  auto doc_len = [&](int64_t p) -> int {
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
+    return len < 0 ? 0 : (len > D ? D : len);
+  };
+
+  int64_t pp = p0;
+  int pt = 0, ps = 0, pn = 0;
+  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      const char* g = dbase + (pp * (int64_t)D + (int64_t)pt * 32) * RB + ps * 256;
+      if (pt == nblk_tot - 1 && rows_last != 32)
+        issue_slice8(g, voff_tail, lds0 + (uint32_t)pbuf * kS128Bytes);
+      else
+        issue_slice8(g, voff, lds0 + (uint32_t)pbuf * kS128Bytes);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (++ps == NSL) {
+        ps = 0;
+        if (++pt == pn) {
+          pt = 0;
+          ++pp;
+          while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+        }
+      }
+    }
+  };
+  top_up();
+
+  bf16x8 qhi[NSL][kS128Steps], qlo[NSL][kS128Steps];
+  float rq = 0.0f;
+  bool qvalid = false;
+  int64_t cur_q = -1;
+  int64_t qi = p0 / a.ppq;
+  int64_t q_left = a.ppq - (p0 - qi * a.ppq);
+
+  for (int64_t pair = p0; pair < p1; ++pair) {
+    if (a.pair_q) {
+      qi = (int64_t)(int)sload_u32(a.pair_q, pair);
+    } else {
+      if (q_left == 0) {
+        ++qi;
+        q_left = a.ppq;
+      }
+      --q_left;
+    }
+    if (qi != cur_q) {
+      cur_q = qi;
+      const int qr = r < Q ? r : Q - 1;
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB + h * 32;
+      float ss = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+#pragma unroll
+        for (int p = 0; p < kS128Steps; ++p) {
+          const f32x4 x0 = *(const f32x4*)(qrow + s * 256 + p * 64);
+          const f32x4 x1 = *(const f32x4*)(qrow + s * 256 + p * 64 + 16);
+          split8(x0, x1, qhi[s][p], qlo[s][p]);
+          ss += sumsq4(x0) + sumsq4(x1);
+        }
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      rq = 1.0f / (sqrtf(ss) + 1e-13f);
+      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      qvalid = r < Q && r < qlen;
+      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+    }
+    const int len = doc_len(pair);
+    const int nb = (len + 31) >> 5;
+    f32x2 pk2[kMaxK / 2];
+#pragma unroll
+    for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
+    if (W) {
+      const float* gw = a.dw + pair * (int64_t)D;
+      for (int j = lane; j < 32 * nb; j += 64) wbuf[j] = j < D ? gate_log2(gw[j]) : -INFINITY;
+    }
+
+    for (int t = 0; t < nb; ++t) {
+      f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+      f32x2 ss2 = {0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+        top_up();
+        wait_slices8(inflight - 1);
+        const char* buf = smem + cbuf * kS128Bytes;
+        f32x4 x[2 * kS128Steps];
+#pragma unroll
+        for (int p = 0; p < kS128Steps; ++p) {
+          x[2 * p] = *(const f32x4*)(buf + aoff[p][0]);
+          x[2 * p + 1] = *(const f32x4*)(buf + aoff[p][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ah, al;
+        split8(x[0], x[1], ah, al);
+#pragma unroll
+        for (int p = 0; p < kS128Steps; ++p) {
+          bf16x8 nh = ah, nl = al;
+          if (p + 1 < kS128Steps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
+          acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
+          acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
+          acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
+          acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
+          {
+            const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
+            const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
+            ss2 += a0 * a0;
+            ss2 += a1 * a1;
+            ss2 += b0 * b0;
+            ss2 += b1 * b1;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 VALU in its shadow
+          }
+          ah = nh;
+          al = nl;
+        }
+        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+        --inflight;
+      }
+      float ss = ss2[0] + ss2[1];
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      float rdr[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
+        rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
+      }
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      if constexpr (W) {
+        float lw[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = *(const f32x4*)(wbuf + 32 * t + 8 * g + 4 * h);
+          lw[4 * g + 0] = v[0]; lw[4 * g + 1] = v[1]; lw[4 * g + 2] = v[2]; lw[4 * g + 3] = v[3];
+        }
+        rbf_block<K, true>(pk2, acc, rdr, rq, va, h, rbf, lw);
+      } else {
+        rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
+      }
+    }
+    float pk[kMaxK];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pk[k] = pk2[k >> 1][k & 1];
+      pk[k] += __shfl_xor(pk[k], 32, 64);
+    }
+    finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+  }
+}
+
+bool kp128_supported(int Q, int D, int E, bool gated) {
+  if (Q > 32 || E % 64 || E > 384) return false;
+  const int nsl = E / 64;
+  if (nsl == 5) return false;  // not instantiated
+  return !gated || D <= 4096;
+}
+
+template <int NSL, bool W>
+static int launch128(const KpArgs& a, const dim3 grid, int lds, hipStream_t stream) {
+  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, W>), grid, dim3(64), lds, stream, a);
+  return check_launch("kernel_pool_split128_kernel");
+}
+
+int kp128_launch(const KpArgs& a0, hipStream_t stream) {
+  KpArgs a = a0;
+  const bool gated = a.dw != nullptr;
+  const int lds = kS128Nbuf * kS128Bytes + 128 + (gated ? 128 * ((a.D + 31) >> 5) : 0);
+  int64_t waves = (int64_t)kCUs * 4;
+  if (waves > a.n_pairs) waves = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
+  waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  const dim3 grid((unsigned)waves);
+  switch (a.E / 64) {
+    case 1: return gated ? launch128<1, true>(a, grid, lds, stream) : launch128<1, false>(a, grid, lds, stream);
+    case 2: return gated ? launch128<2, true>(a, grid, lds, stream) : launch128<2, false>(a, grid, lds, stream);
+    case 3: return gated ? launch128<3, true>(a, grid, lds, stream) : launch128<3, false>(a, grid, lds, stream);
+    case 4: return gated ? launch128<4, true>(a, grid, lds, stream) : launch128<4, false>(a, grid, lds, stream);
+    case 6: return gated ? launch128<6, true>(a, grid, lds, stream) : launch128<6, false>(a, grid, lds, stream);
+  }
+  return set_error(MM_EUNSUPPORTED, "kernel_pool: E=%d has no 64-float streaming kernel", a.E);
+}
+
+}  // namespace mm

@@ -1,0 +1,198 @@
+// Device helpers shared by the kernel-pooling translation units (kernel_pool.hip, kernel_pool128.hip).
+#pragma once
+#include "mm_internal.h"
+
+namespace mm {
+
+constexpr int kMaxK = 16;
+
+struct KpArgs {
+  const float* q;
+  const float* d;
+  PackedMask qm, dm;
+  const float* mu;
+  const float* sigma;
+  const float* alpha;
+  const float* w;
+  float* out;
+  float* per_kernel;  // optional [n_pairs, K]
+  int64_t n_pairs;
+  int64_t ppq;
+  int Q, D, E, K;
+  int64_t pairs_per_wave;
+  // document addressing: document p starts at row p*d_doc_rows + d_row0 (TK: D, 0; TKL chunks: 50, 5)
+  int64_t d_doc_rows;
+  int d_row0;
+  // TKL mode (sigir20_tkl.py:180-199): "documents" are packed chunks, the query of chunk p is
+  // chunk_slot[p] / C, and instead of pooling over the document the kernel emits, per position pair
+  // u (positions 2u, 2u+1 of the chunk's 40 centre tokens), the K summed activations + the number of
+  // positions whose activation is non-zero: ps_out[p][20][Q][K+1].
+  const int32_t* chunk_slot;
+  int C;
+  float* ps_out;
+  // variants of the pooling block (same arithmetic family):
+  //   dw != nullptr: per document token gate >= 0 multiplying all its activations (TK-Sparse stop-word
+  //   vector, cikm20_tk_sparse.py:133-135), [n_pairs, D] float32;
+  //   clamp_min: floor inside the log (1e-10 TK :121; 1e-4 IDCM sampler, sigir21_idcm.py:185)
+  const float* dw;
+  float clamp_min;
+  //   pair_q != nullptr: the query of pair p is row pair_q[p] of q (ragged groups: IDCM's packed passages);
+  //   overrides ppq
+  const int32_t* pair_q;
+};
+
+__device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
+
+__device__ __forceinline__ uint32_t sload_u32(const void* base, int64_t idx) {
+  uint32_t v;
+  const uint32_t* p = (const uint32_t*)base + idx;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+
+// RBF constants in exp2 form: exp(-(c-mu)^2/(2 s^2)) = exp2((c-mu)^2 * c2), c2 = -log2(e)/(2 s^2)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+struct Rbf {
+  float mu[kMaxK];
+  float c2[kMaxK];
+  float alpha[kMaxK];
+  float w[kMaxK];
+  // packed form for v_pk_* math: exp(-(c-mu)^2/(2 s^2)) = exp2(-(c*sq - mu*sq)^2), sq = sqrt(log2(e)/(2 s^2));
+  // kernels are processed two at a time, an odd K gets a dummy partner (sq = 0) whose sum is ignored
+  f32x2 sq2[kMaxK / 2];
+  f32x2 msq2[kMaxK / 2];
+};
+
+template <int K>
+__device__ __forceinline__ void pack_rbf(Rbf& rbf) {
+#pragma unroll
+  for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+    float sq[2], msq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = 2 * kp + u;
+      sq[u] = k < K ? sqrtf(-rbf.c2[k]) : 0.0f;
+      msq[u] = k < K ? rbf.mu[k] * sq[u] : 1.0e3f;  // dummy partner: exp2(-(0*c - 1e3)^2) = 0 for every c
+    }
+    rbf.sq2[kp] = f32x2{sq[0], sq[1]};
+    rbf.msq2[kp] = f32x2{msq[0], msq[1]};
+  }
+}
+
+__device__ __forceinline__ float sload_f32(const float* base, int idx) {
+  return __builtin_bit_cast(float, sload_u32(base, idx));
+}
+
+// Kernel parameters are wave-uniform: fetch them through the scalar cache (SGPRs, no vmcnt traffic
+// that would make the compiler drain the LDS-DMA queue inside the block loop).
+template <int K>
+__device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, const float* alpha, const float* w, Rbf& rbf) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float sg = sload_f32(sigma, k);
+    rbf.mu[k] = sload_f32(mu, k);
+    rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
+    rbf.alpha[k] = alpha ? sload_f32(alpha, k) : 1.0f;
+    rbf.w[k] = w ? sload_f32(w, k) : 0.0f;
+  }
+  pack_rbf<K>(rbf);
+}
+
+// Epilogue of one 32-token document block: cosine scaling + K RBF kernels, summed into pk[k].
+// acc[i]: raw dot of document row rowof(i)+4h with this lane's query token; rdr[i]: 1/(|d|+tiny) of
+// that row; vbits (already shifted by 4h): bit rowof(i) set <=> the row is a real token.
+// Packed: per row one select (a masked row gets cosine 1e5, which underflows every kernel to exactly
+// 0, the same contribution as the reference's multiply by the 0 mask) and per kernel PAIR
+// v_pk_fma + v_pk_mul + 2 v_exp + v_pk_add.  The fp32 MFMA shares the SIMD's FMA lanes with the
+// VALU (measured: zero overlap, profiles/r01_kernel_pool_pmc.json), so every VALU op removed here
+// is wall time.
+// W: lw[i] = log2(gate of row i) rides in the exponent (exp2(x + log2 g) = g exp2(x); g = 0 -> -inf -> 0),
+// which turns the pk_mul of the square into a pk_fma: the gate costs no instruction.
+template <int K, bool W = false>
+__device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
+                                          uint32_t va, int h, const Rbf& rbf, const float* lw = nullptr) {
+  // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
+  // 4g..4g+3 hold rows 8g..8g+7 (both lane halves), so a group with no real row is skipped as a
+  // whole (the last block of a document: D = 200 -> 8 of 32 rows) and a group of 8 real rows needs
+  // no per-row select.
+  const uint32_t vbits = va >> (4 * h);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint32_t gm = (va >> (8 * g)) & 0xffu;
+    if (gm == 0) continue;
+    const bool full = gm == 0xffu;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = 4 * g + ii;
+      float c = (acc[i] * rq) * rdr[i];
+      if (!full) c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+      const f32x2 cc = {c, c};
+      const f32x2 lwv = W ? f32x2{lw[i], lw[i]} : f32x2{0.0f, 0.0f};
+#pragma unroll
+      for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+        const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+        const f32x2 av = W ? lwv - sv * sv : -(sv * sv);
+        const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+        pk2[kp] += e;
+      }
+    }
+  }
+}
+
+// log2 of a TK-Sparse gate (a ReLU output, so >= 0; anything below 0 is treated as 0)
+__device__ __forceinline__ float gate_log2(float g) { return __builtin_amdgcn_logf(fmaxf(g, 0.0f)); }
+
+
+// log-sum pooling of one pair: pk[k] (this lane's query token, both halves already combined).
+template <int K>
+__device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
+                                            int lane, const Rbf& rbf) {
+  float total = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
+    lg = (qvalid && lane < 32) ? lg : 0.0f;  // both halves hold the combined sums: count one
+    const float s = wave_sum(lg);
+    if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
+    total += rbf.w[k] * s;
+  }
+  if (lane == 0) a.out[pair] = total;
+}
+
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+  u32x4 hw, lw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4];
+    const float b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+    const uint32_t w = cvt_pk_bf16(a, b);
+    const float ha = __uint_as_float(w << 16), hb = __uint_as_float(w & 0xffff0000u);
+    hw[j] = w;
+    lw[j] = cvt_pk_bf16(a - ha, b - hb);
+  }
+  hi = __builtin_bit_cast(bf16x8, hw);
+  lo = __builtin_bit_cast(bf16x8, lw);
+}
+
+__device__ __forceinline__ float sumsq4(const f32x4& v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// kernel_pool128.hip: streaming kernels for E = 64n <= 384 (Q <= 32)
+bool kp128_supported(int Q, int D, int E, bool gated);
+int kp128_launch(const KpArgs& a, hipStream_t stream);
+
+}  // namespace mm

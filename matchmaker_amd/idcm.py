@@ -27,18 +27,22 @@ _SIGMA = [0.1] * 11                                                    # :107
 
 def sampler_scores(query_ctx: torch.Tensor, document_ctx: torch.Tensor, query_mask: torch.Tensor,
                    document_mask: torch.Tensor, mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor,
-                   binweights: nn.Linear) -> torch.Tensor:
+                   binweights: nn.Linear, pair_query: Optional[torch.Tensor] = None) -> torch.Tensor:
     """packed_patch_scores [P, 1] of sigir21_idcm.py:182-186 from the sampler's (un-normalised) token vectors
-    query_ctx [P, Q, E], document_ctx [P, D, E] and {0,1} masks."""
+    document_ctx [P, D, E] and {0,1} masks.  query_ctx is [P, Q, E] (one query copy per passage, as the
+    reference builds it, :143-144) or, with pair_query [P], [B, Q, E] + the document index of each passage."""
     q = query_ctx.float()
     d = document_ctx.float()
     w = binweights.weight
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (q, d, w, alpha))
     if needs_grad:
+        if pair_query is not None:                         # the native backward works pair per row
+            q, query_mask = q.index_select(0, pair_query), query_mask.index_select(0, pair_query)
         s = _KernelPoolFn.apply(q, d, query_mask.float(), document_mask.float(), mu.reshape(-1), sigma.reshape(-1),
                                 alpha.reshape(-1), w.reshape(-1), None, 1e-4)
     else:
-        s = ops.kernel_pool(q, d, query_mask, document_mask, mu, sigma, alpha, w, clamp_min=1e-4)
+        s = ops.kernel_pool(q, d, query_mask, document_mask, mu, sigma, alpha, w, clamp_min=1e-4,
+                            pair_query=pair_query)
     return (s + binweights.bias).unsqueeze(-1)
 
 
@@ -140,10 +144,14 @@ class IDCM(nn.Module):
         not_cached = isinstance(bert_part_cached, bool) and bert_part_cached is False
 
         if self.sample_n > -1:
-            query_ctx = self._sampler_vectors(packed_query_ids, packed_query_mask)
+            # the reference contextualises one query copy per passage (:167-178); the copies are identical, so
+            # each document's query goes through the sampler once and the passages index it
+            query_ctx = self._sampler_vectors(query["input_ids"], query["attention_mask"])
             document_ctx = self._sampler_vectors(ids_packed, mask_packed)
-            packed_patch_scores = sampler_scores(query_ctx, document_ctx, packed_query_mask, mask_packed, self.mu,
-                                                 self.sigma, self.kernel_alpha_scaler, self.sampling_binweights)   # :182-186
+            passage_doc = torch.div(packed_indices.nonzero().squeeze(-1), chunk_pieces, rounding_mode="floor")
+            packed_patch_scores = sampler_scores(query_ctx, document_ctx, query["attention_mask"], mask_packed, self.mu,
+                                                 self.sigma, self.kernel_alpha_scaler, self.sampling_binweights,
+                                                 pair_query=passage_doc)                                      # :182-186
             sampling_scores_per_doc = packed_patch_scores.new_zeros((total_chunks, 1))
             sampling_scores_per_doc[packed_indices] = packed_patch_scores
             sampling_scores_per_doc = sampling_scores_per_doc.reshape(batch_size, -1)

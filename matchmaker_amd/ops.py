@@ -199,14 +199,17 @@ def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Ten
 def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
                 mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor,
                 pairs_per_query: int = 1, return_per_kernel: bool = False,
-                d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10):
+                d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10,
+                pair_query: Optional[torch.Tensor] = None):
     """TK kernel pooling (matchmaker/models/published/ecai20_tk.py:105-124).
 
     q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings; mu/sigma/alpha/w [K].
     d_gate [n_pairs, D] >= 0 (optional): TK-Sparse's stop-word vector (cikm20_tk_sparse.py:133-135);
-    clamp_min: floor inside the log (1e-4: IDCM sampler, sigir21_idcm.py:185).
+    clamp_min: floor inside the log (1e-4: IDCM sampler, sigir21_idcm.py:185);
+    pair_query [n_pairs] int (optional): row of q each pair scores against (ragged groups; replaces
+    pairs_per_query; equal neighbours reuse the query tile).
     Returns float32 [n_pairs] (and per_kernel [n_pairs, K] when asked)."""
-    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate)
+    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate, pair_query)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != torch.float32 or d.dtype != torch.float32:
         raise NativeError("kernel_pool: float32 embeddings only (the reference cosine rejects bf16, "
@@ -215,8 +218,19 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     B, D, E2 = d.shape
     if E != E2:
         raise NativeError(f"embedding dims differ: {E} vs {E2}")
-    if pairs_per_query < 1 or nq != (B + pairs_per_query - 1) // pairs_per_query:
+    if pair_query is not None:
+        pq = pair_query.reshape(-1).to(torch.int32).contiguous()
+        if pq.numel() != B:
+            raise NativeError(f"pair_query has {pq.numel()} entries for {B} pairs")
+        if B and not torch.cuda.is_current_stream_capturing():
+            lo, hi = int(pq.min()), int(pq.max())
+            if lo < 0 or hi >= nq:
+                raise NativeError(f"pair_query values [{lo}, {hi}] outside the {nq} query rows")
+        pairs_per_query = 1
+    elif pairs_per_query < 1 or nq != (B + pairs_per_query - 1) // pairs_per_query:
         raise NativeError(f"q has {nq} rows but {B} pairs / {pairs_per_query} per query")
+    else:
+        pq = None
     K = mu.numel()
     f = lambda t: t.detach().reshape(-1).to(torch.float32).contiguous()
     mu, sigma, alpha, w = f(mu), f(sigma), f(alpha), f(w)
@@ -230,10 +244,11 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
     if B:
         with torch.cuda.device(dev):
-            wsb = L.mm_kernel_pool_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
+            wsb = L.mm_kernel_pool_workspace_bytes(max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
             rc = L.mm_kernel_pool_ex_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
-                                         gate.data_ptr() if gate is not None else None, mu.data_ptr(),
+                                         gate.data_ptr() if gate is not None else None,
+                                         pq.data_ptr() if pq is not None else None, nq, mu.data_ptr(),
                                          sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
                                          out.data_ptr(), pk.data_ptr() if pk is not None else None, B,
                                          pairs_per_query, Q, D, E, K, _lib.MM_F32,

@@ -63,8 +63,10 @@ def _tiny_distilbert():
     return DistilBertModel(cfg).eval()
 
 
-def _oracle_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, clamp_min=1e-10, **kw):
+def _oracle_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, clamp_min=1e-10, pair_query=None, **kw):
     assert clamp_min == 1e-4 and kw.get("d_gate") is None
+    if pair_query is not None:                             # ragged groups: the query row of each passage
+        q, q_mask = q[pair_query.long()], q_mask[pair_query.long()]
     n = lambda t: t.detach().cpu().numpy()
     s = O.idcm_sampler_scores(n(q), n(d), n(q_mask), n(d_mask), n(mu).reshape(-1), n(sigma).reshape(-1),
                               n(alpha).reshape(-1), n(w).reshape(-1), 0.0)

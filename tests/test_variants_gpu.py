@@ -182,6 +182,34 @@ def test_idcm_sampler_scores_vs_oracle_forward_and_backward(P, Q, D, E):
         np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), want, atol=2e-4 * scale, rtol=2e-3, err_msg=name)
 
 
+@pytest.mark.parametrize("E", [128, 384, 300, 60, 768])
+def test_pair_query_indexing_equals_one_query_copy_per_pair(E):
+    """Ragged groups (IDCM: a different number of passages per document): q [n_queries] + pair_query must
+    equal the pair-per-row layout the reference materialises (sigir21_idcm.py:143-144), on every kernel."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(E)
+    nq, Q, D = 7, 30, 64
+    groups = [5, 0, 1, 9, 3, 0, 4]
+    pq = torch.repeat_interleave(torch.arange(nq), torch.tensor(groups))
+    P = int(pq.numel())
+    q = torch.randn(nq, Q, E, generator=gen)
+    d = torch.randn(P, D, E, generator=gen)
+    d[2, 3] = q[pq[2], 4]
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (nq,), generator=gen)[:, None]).float()
+    dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (P,), generator=gen)[:, None]).float()
+    prm = [torch.tensor(MU), torch.tensor(SIGMA), torch.rand(11, generator=gen) + 0.5, torch.randn(11, generator=gen)]
+    prm = [t.to(dev) for t in prm]
+    a = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), *prm, clamp_min=1e-4, pair_query=pq.to(dev))
+    b = ops.kernel_pool(q[pq].to(dev), d.to(dev), qm[pq].to(dev), dm.to(dev), *prm, clamp_min=1e-4)
+    assert torch.equal(a, b)
+    ref = O.idcm_sampler_scores(q[pq].numpy(), d.numpy(), qm[pq].numpy(), dm.numpy(), MU, SIGMA, prm[2].cpu().numpy(),
+                                prm[3].cpu().numpy(), 0.0, dtype=np.float64)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+    with pytest.raises(ops.NativeError):
+        ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), *prm, pair_query=(pq + 1).to(dev))
+
+
 def _tiny_distilbert():
     from transformers import DistilBertConfig, DistilBertModel
     cfg = DistilBertConfig(vocab_size=200, dim=64, n_heads=4, hidden_dim=128, n_layers=2,
