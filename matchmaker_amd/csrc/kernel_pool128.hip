@@ -12,6 +12,13 @@
 //            LDS-DMA lane fetches from its own global address;
 //   K step p (0..3) of a slice: lane (r, h) feeds floats 16p + 8h .. +7 of row r (chunks 4p+2h, 4p+2h+1);
 //   query  tile as bf16 hi / lo B fragments in VGPRs: 4*NSL steps x 8 registers (192 at E = 384).
+//
+// E = 512 / 768 (IDCM's default "ck" sampler works on DistilBERT's 768-wide vectors): the query tile alone
+// is 96 KiB of bf16 hi + lo, more than one wavefront's registers can keep beside the accumulators.  KS = 2
+// wavefronts per workgroup therefore split the K axis: each streams its own half of every document row
+// (its own LDS-DMA ring, its half of the query tile in VGPRs), the two partial 32x32 dot tiles and row
+// norms meet in LDS once per block (4 KiB each way, two barriers), and the RBF epilogue is shared by
+// kernel pairs (wave 0: kernels 0-5, wave 1: 6-10) so that both matrix pipes and both VALUs stay busy.
 #include "mm_internal.h"
 #include "kp_device.h"
 
@@ -45,23 +52,39 @@ __device__ __forceinline__ void wait_slices8(int younger) {
   }
 }
 
-template <int NSL, int K, bool W>
-__global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a) {
+// LDS map of a workgroup of KS waves: [KS rings of NBUF slices][KS x rdbuf 128 B][exchange, KS == 2 only:
+// xacc 2 x 4 KiB | xss 2 x 128 B | xq 2 x 2 x 128 B | xtot 2 x 16 B][KS gate vectors]
+constexpr int kXchgBytes = 2 * 4096 + 2 * 128 + 4 * 128 + 32;
+__host__ __device__ constexpr int kp128_lds_fixed(int KS) {
+  return KS * (kS128Nbuf * kS128Bytes + 128) + (KS == 2 ? kXchgBytes : 0);
+}
+
+template <int NSL, int K, bool W, int KS>
+__global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a) {
+  static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = kS128Nbuf;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 31, h = lane >> 5;
   const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
   const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
   if (p0 >= p1) return;
-  constexpr int E = 64 * NSL;
+  constexpr int E = 64 * NSL * KS;
   constexpr int RB = E * 4;
   const int D = a.D, Q = a.Q;
   const int nblk_tot = (D + 31) >> 5;
   const int rows_last = D - 32 * (nblk_tot - 1);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  float* rdbuf = (float*)(smem + NBUF * kS128Bytes);
-  float* wbuf = rdbuf + 32;
+  char* ring = smem + wv * (NBUF * kS128Bytes);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  float* rdbuf = (float*)(smem + KS * (NBUF * kS128Bytes) + wv * 128);
+  char* xchg = smem + KS * (NBUF * kS128Bytes + 128);
+  float* xacc = (float*)xchg;                      // [2 waves][4 groups][64 lanes][4]
+  float* xss = (float*)(xchg + 8192);              // [2 waves][32 rows]
+  float* xq = (float*)(xchg + 8192 + 256);         // [2 toggles][2 waves][32 query tokens]
+  float* xtot = (float*)(xchg + 8192 + 256 + 512); // [2 toggles][4]
+  float* wbuf = (float*)(smem + kp128_lds_fixed(KS)) + wv * 32 * nblk_tot;
+  int q_toggle = 0, p_toggle = 0;
 
   // LDS-DMA source offsets: slot s = 64n + lane -> row s >> 4, stored chunk s & 15 <- global chunk (s & 15) ^ (row & 15)
   uint32_t voff[kS128Instr], voff_tail[kS128Instr];
@@ -95,7 +118,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
   int pbuf = 0, cbuf = 0, inflight = 0;
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
-      const char* g = dbase + (pp * (int64_t)D + (int64_t)pt * 32) * RB + ps * 256;
+      const char* g = dbase + (pp * (int64_t)D + (int64_t)pt * 32) * RB + (wv * NSL + ps) * 256;
       if (pt == nblk_tot - 1 && rows_last != 32)
         issue_slice8(g, voff_tail, lds0 + (uint32_t)pbuf * kS128Bytes);
       else
@@ -134,7 +157,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
     if (qi != cur_q) {
       cur_q = qi;
       const int qr = r < Q ? r : Q - 1;
-      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB + h * 32;
+      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB + wv * (NSL * 256) + h * 32;
       float ss = 0.0f;
 #pragma unroll
       for (int s = 0; s < NSL; ++s) {
@@ -147,6 +170,12 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
         }
       }
       ss += __shfl_xor(ss, 32, 64);
+      if constexpr (KS == 2) {  // the other wave holds the other half of the row
+        if (h == 0) xq[(q_toggle * 2 + wv) * 32 + r] = ss;
+        __syncthreads();
+        ss += xq[(q_toggle * 2 + (1 - wv)) * 32 + r];
+        q_toggle ^= 1;
+      }
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
       const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
       qvalid = r < Q && r < qlen;
@@ -169,7 +198,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
       for (int s = 0; s < NSL; ++s) {
         top_up();
         wait_slices8(inflight - 1);
-        const char* buf = smem + cbuf * kS128Bytes;
+        const char* buf = ring + cbuf * kS128Bytes;
         f32x4 x[2 * kS128Steps];
 #pragma unroll
         for (int p = 0; p < kS128Steps; ++p) {
@@ -211,6 +240,21 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
       ss += __shfl_xor(ss, 32, 64);
+      if constexpr (KS == 2) {
+        // partial dot tile + partial row norms of this wave's K half -> LDS; add the other wave's
+        __syncthreads();  // the other wave has finished reading the previous block's exchange
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(xacc + ((wv * 4 + g) * 64 + lane) * 4) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (h == 0) xss[wv * 32 + r] = ss;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = *(const f32x4*)(xacc + (((1 - wv) * 4 + g) * 64 + lane) * 4);
+          acc[4 * g] += o[0]; acc[4 * g + 1] += o[1]; acc[4 * g + 2] += o[2]; acc[4 * g + 3] += o[3];
+        }
+        ss += xss[(1 - wv) * 32 + r];
+      }
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
       float rdr[16];
 #pragma unroll
@@ -228,9 +272,13 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
           const f32x4 v = *(const f32x4*)(wbuf + 32 * t + 8 * g + 4 * h);
           lw[4 * g + 0] = v[0]; lw[4 * g + 1] = v[1]; lw[4 * g + 2] = v[2]; lw[4 * g + 3] = v[3];
         }
-        rbf_block<K, true>(pk2, acc, rdr, rq, va, h, rbf, lw);
+        if (KS == 1) rbf_block<K, true>(pk2, acc, rdr, rq, va, h, rbf, lw);
+        else if (wv == 0) rbf_block<K, true, 0, 3>(pk2, acc, rdr, rq, va, h, rbf, lw);
+        else rbf_block<K, true, 3, (K + 1) / 2>(pk2, acc, rdr, rq, va, h, rbf, lw);
       } else {
-        rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
+        if (KS == 1) rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
+        else if (wv == 0) rbf_block<K, false, 0, 3>(pk2, acc, rdr, rq, va, h, rbf);
+        else rbf_block<K, false, 3, (K + 1) / 2>(pk2, acc, rdr, rq, va, h, rbf);
       }
     }
     float pk[kMaxK];
@@ -239,39 +287,60 @@ __global__ void __launch_bounds__(64) kernel_pool_split128_kernel(const KpArgs a
       pk[k] = pk2[k >> 1][k & 1];
       pk[k] += __shfl_xor(pk[k], 32, 64);
     }
-    finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+    if constexpr (KS == 1) {
+      finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+    } else {
+      static_assert(K > 6, "wave 1 pools kernels 6..K-1");
+      // each wave pools the kernels it evaluated; wave 1 hands its weighted partial to wave 0
+      const float part = wv == 0 ? pool_partial<K, 0, 6>(a, pair, pk, qvalid, lane, rbf)
+                                 : pool_partial<K, 6, K>(a, pair, pk, qvalid, lane, rbf);
+      if (wv == 1 && lane == 0) xtot[p_toggle * 4] = part;
+      __syncthreads();
+      if (wv == 0 && lane == 0) a.out[pair] = part + xtot[p_toggle * 4];
+      p_toggle ^= 1;
+    }
   }
 }
 
 bool kp128_supported(int Q, int D, int E, bool gated) {
-  if (Q > 32 || E % 64 || E > 384) return false;
+  if (Q > 32 || E % 64) return false;
   const int nsl = E / 64;
-  if (nsl == 5) return false;  // not instantiated
-  return !gated || D <= 4096;
+  const bool ok = nsl == 1 || nsl == 2 || nsl == 3 || nsl == 4 || nsl == 6 || nsl == 8 || nsl == 12;  // instantiated
+  return ok && (!gated || D <= 4096);
 }
 
-template <int NSL, bool W>
+template <int NSL, bool W, int KS>
 static int launch128(const KpArgs& a, const dim3 grid, int lds, hipStream_t stream) {
-  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, W>), grid, dim3(64), lds, stream, a);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<NSL, 11, W, KS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, W, KS>), grid, dim3(64 * KS), lds, stream, a);
   return check_launch("kernel_pool_split128_kernel");
 }
 
 int kp128_launch(const KpArgs& a0, hipStream_t stream) {
   KpArgs a = a0;
   const bool gated = a.dw != nullptr;
-  const int lds = kS128Nbuf * kS128Bytes + 128 + (gated ? 128 * ((a.D + 31) >> 5) : 0);
-  int64_t waves = (int64_t)kCUs * 4;
-  if (waves > a.n_pairs) waves = a.n_pairs;
-  a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
-  waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  const dim3 grid((unsigned)waves);
-  switch (a.E / 64) {
-    case 1: return gated ? launch128<1, true>(a, grid, lds, stream) : launch128<1, false>(a, grid, lds, stream);
-    case 2: return gated ? launch128<2, true>(a, grid, lds, stream) : launch128<2, false>(a, grid, lds, stream);
-    case 3: return gated ? launch128<3, true>(a, grid, lds, stream) : launch128<3, false>(a, grid, lds, stream);
-    case 4: return gated ? launch128<4, true>(a, grid, lds, stream) : launch128<4, false>(a, grid, lds, stream);
-    case 6: return gated ? launch128<6, true>(a, grid, lds, stream) : launch128<6, false>(a, grid, lds, stream);
+  const int nsl = a.E / 64;
+  const int ks = nsl > 6 ? 2 : 1;
+  const int lds = kp128_lds_fixed(ks) + (gated ? ks * 128 * ((a.D + 31) >> 5) : 0);
+  int64_t groups = (int64_t)kCUs * 4 / ks;  // one wave per SIMD either way
+  if (groups > a.n_pairs) groups = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
+  groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  const dim3 grid((unsigned)groups);
+#define MM_KP128(NSL, KS) \
+  return gated ? launch128<NSL, true, KS>(a, grid, lds, stream) : launch128<NSL, false, KS>(a, grid, lds, stream)
+  switch (nsl) {
+    case 1: MM_KP128(1, 1);
+    case 2: MM_KP128(2, 1);
+    case 3: MM_KP128(3, 1);
+    case 4: MM_KP128(4, 1);
+    case 6: MM_KP128(6, 1);
+    case 8: MM_KP128(4, 2);
+    case 12: MM_KP128(6, 2);
   }
+#undef MM_KP128
   return set_error(MM_EUNSUPPORTED, "kernel_pool: E=%d has no 64-float streaming kernel", a.E);
 }
 

@@ -109,7 +109,8 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
 // is wall time.
 // W: lw[i] = log2(gate of row i) rides in the exponent (exp2(x + log2 g) = g exp2(x); g = 0 -> -inf -> 0),
 // which turns the pk_mul of the square into a pk_fma: the gate costs no instruction.
-template <int K, bool W = false>
+// KP0..KP1: the kernel pairs this call evaluates (a K-split workgroup shares the 6 pairs between its waves).
+template <int K, bool W = false, int KP0 = 0, int KP1 = (K + 1) / 2>
 __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
                                           uint32_t va, int h, const Rbf& rbf, const float* lw = nullptr) {
   // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
@@ -130,7 +131,7 @@ __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16&
       const f32x2 cc = {c, c};
       const f32x2 lwv = W ? f32x2{lw[i], lw[i]} : f32x2{0.0f, 0.0f};
 #pragma unroll
-      for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+      for (int kp = KP0; kp < KP1; ++kp) {
         const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
         const f32x2 av = W ? lwv - sv * sv : -(sv * sv);
         const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
@@ -144,22 +145,29 @@ __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16&
 __device__ __forceinline__ float gate_log2(float g) { return __builtin_amdgcn_logf(fmaxf(g, 0.0f)); }
 
 
-// log-sum pooling of one pair: pk[k] (this lane's query token, both halves already combined).
-template <int K>
-__device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
-                                            int lane, const Rbf& rbf) {
+// log-sum pooling of one pair over kernels K0..K1-1: pk[k] (this lane's query token, both halves already
+// combined); writes per_kernel, returns sum_k w_k * pooled_k (wave-uniform).
+template <int K, int K0 = 0, int K1 = K>
+__device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
+                                              int lane, const Rbf& rbf) {
   float total = 0.0f;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
+  for (int k = K0; k < K1; ++k) {
     float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
     lg = (qvalid && lane < 32) ? lg : 0.0f;  // both halves hold the combined sums: count one
     const float s = wave_sum(lg);
     if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
     total += rbf.w[k] * s;
   }
-  if (lane == 0) a.out[pair] = total;
+  return total;
 }
 
+template <int K>
+__device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
+                                            int lane, const Rbf& rbf) {
+  const float total = pool_partial<K>(a, pair, pk, qvalid, lane, rbf);
+  if (lane == 0) a.out[pair] = total;
+}
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
