@@ -5,6 +5,12 @@ Stays PyTorch, as in the reference: query contextualisation (:139), document chu
 50-token windows with 5 tokens of overlap on each side, dropping of all-padding chunks and the chunk
 Transformer (:142-175).  Everything after that — cosine match, RBF kernels, sliding-window pooling,
 saturation, dense layer, top-3 region scoring (:180-286) — runs in libmm_native.so (mm_tkl_fwd).
+
+Training (train.py:347-348, loss.backward() :503-524): the document score is a weighted sum of at most 15
+window scores (3 regions x 5 neighbours, :257-286) and the region choice is piecewise constant, so the
+exact gradient only involves those windows.  The forward value and the window scores come from the native
+kernels; the 15 selected windows per document (30 tokens each, out of up to 2,000) are then re-evaluated
+with differentiable torch ops on the device to carry the gradient (`_selected_window_scores`).
 """
 from typing import List
 
@@ -141,10 +147,6 @@ class TKL_sigir20(nn.Module):
         if not (self.use_embedding_sat or self.use_log_sat):
             raise NativeError(f"tk_saturation_type={self.saturation_type!r}: the reference's idf/linear branches read "
                               "`query_idfs`, which forward() does not receive (sigir20_tkl.py:130,214,236)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and \
-                (query_embeddings.requires_grad or document_embeddings.requires_grad or self.training):
-            raise NativeError("TKL_sigir20 (matchmaker_amd): the native scoring path is inference-only in this "
-                              "round; wrap evaluation in torch.no_grad() (eval.py:76 does)")
         B, Q = query_embeddings.shape[0], query_embeddings.shape[1]
         query_ctx, _ = self.forward_representation(query_embeddings, query_pad_oov_mask,
                                                    self.positional_features_q[:, :Q, :])
@@ -158,15 +160,82 @@ class TKL_sigir20(nn.Module):
         else:
             chunks_ctx = chunks
         K = self.mu.numel()
-        score, win = ops.tkl_score(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
-                                   self.pack_params(), B, C, K, "embedding" if self.use_embedding_sat else "log",
-                                   return_windows=True)
+        with torch.no_grad():
+            score, win = ops.tkl_score(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
+                                       self.pack_params(), B, C, K, "embedding" if self.use_embedding_sat else "log",
+                                       return_windows=True)
+        if torch.is_grad_enabled() and (query_ctx.requires_grad or chunks_ctx.requires_grad or
+                                        any(p.requires_grad for p in self._scoring_parameters())):
+            carrier = self._selected_window_scores(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot,
+                                                   query_pad_oov_mask, win, C)
+            score = score + (carrier - carrier.detach())     # the native value, the gradient of the selected windows
         if output_secondary_output:
             query_mean_vector = query_ctx.sum(dim=1) / query_pad_oov_mask.sum(dim=1).unsqueeze(-1)
             return score, {"score": score, "orig_score": win, "orig_doc_len": document_pad_oov_mask.sum(dim=-1),
                            "total_chunks": B * C, "packed_chunks": int(chunks.shape[0]),
                            "query_mean_vector": query_mean_vector}
         return score
+
+    # ------------------------------------------------------------------ gradient carrier (training)
+    def _scoring_parameters(self):
+        ps = [self.dense.weight, self.chunk_scoring]
+        if self.use_embedding_sat:
+            ps += [self.saturation_linear.weight, self.saturation_linear.bias, self.saturation_linear2.weight,
+                   self.saturation_linear2.bias, self.saturation_linear3.weight, self.saturation_linear3.bias,
+                   self.sat_normer.weight, self.sat_normer.bias, self.sat_emb_reduce1.weight]
+        else:
+            ps.append(self.kernel_mult)
+        return ps
+
+    def _selected_window_scores(self, query_ctx, chunks_ctx, chunk_mask, chunk_slot, query_mask, win, C):
+        """Differentiable re-evaluation of the document score from the windows the region search picks
+        (sigir20_tkl.py:184-286 restricted to those windows).  win [B, W]: the native window scores (0 = empty)."""
+        B, W = win.shape
+        dev = win.device
+        # region search on the native window scores: three arg-max rounds with +-15 suppression (:262-272)
+        s = torch.where(win == 0, win.new_full((), -9900.0), win)
+        r = torch.arange(W, device=dev)
+        picks = []
+        for c in range(TOP_K):
+            best = torch.argmax(s, dim=1)
+            picks.append(best)
+            s = torch.where((r.unsqueeze(0) - best.unsqueeze(1)).abs() < WINDOW / 2, s.new_full((), -10001.0 - c), s)
+        top = torch.stack(picks, dim=1)
+        idx = torch.cat([top, top - 1, top + 1, top - 2, top + 2], dim=1).clamp_(0, W - 1)          # :275-277 [B, 15]
+        # the 30 positions of every selected window -> (packed chunk, row) of the contextualised chunks
+        t = 2 * idx.unsqueeze(-1) + torch.arange(WINDOW, device=dev)                                # [B, 15, 30]
+        in_doc = t < C * CHUNK                                   # documents shorter than a window are padded (:203-204)
+        t = t.clamp(max=C * CHUNK - 1)
+        slot = torch.arange(B, device=dev).view(B, 1, 1) * C + t // CHUNK
+        slot2p = torch.full((B * C,), -1, dtype=torch.long, device=dev)
+        slot2p[chunk_slot.long()] = torch.arange(chunk_slot.numel(), device=dev)
+        p = slot2p[slot]
+        present = (p >= 0) & in_doc
+        p = p.clamp(min=0)
+        row = t % CHUNK + OVERLAP
+        if chunks_ctx.shape[0] == 0:
+            return (win.sum(1) * 0.0) + 0.0 * self.chunk_scoring.sum()
+        vec = chunks_ctx[p, row]                                                                     # [B, 15, 30, E]
+        m = chunk_mask.to(vec.dtype)[p, row] * present.to(vec.dtype)
+        qn = query_ctx / (query_ctx.norm(p=2, dim=-1, keepdim=True) + 1e-13)
+        dn = vec / (vec.norm(p=2, dim=-1, keepdim=True) + 1e-13)
+        cos = torch.einsum("bqe,bwte->bwqt", qn, dn)                                                 # :184
+        act = torch.exp(-torch.pow(cos.unsqueeze(-1) - self.mu.view(1, 1, 1, 1, -1), 2) /
+                        (2 * torch.pow(self.sigma.view(1, 1, 1, 1, -1), 2))) * m.unsqueeze(2).unsqueeze(-1)   # :192-194
+        lengths = (act.sum(dim=-1) != 0).sum(dim=-1)                                                 # :210 [B, 15, Q]
+        pkq = act.sum(dim=3)                                                                         # :211 [B, 15, Q, K]
+        if self.use_embedding_sat:                                                                   # :224-235
+            infl = torch.cat([self.sat_emb_reduce1(query_ctx).unsqueeze(1).expand(-1, idx.shape[1], -1, -1),
+                              lengths.to(pkq.dtype).unsqueeze(-1)], dim=-1)
+            infl = self.sat_normer(infl)
+            sat = self.saturation_linear(infl) * (torch.clamp(pkq, min=1e-10) ** (1 / self.saturation_linear2(infl))) - \
+                self.saturation_linear3(infl)
+        else:                                                                                        # :246
+            sat = torch.log(torch.clamp(pkq * self.kernel_mult[0].view(1, 1, 1, -1), min=1e-10))
+        sat = sat * query_mask.to(sat.dtype).view(B, 1, -1, 1) * (lengths > 0).to(sat.dtype).unsqueeze(-1)   # :248
+        wscore = self.dense(sat.sum(dim=2)).squeeze(-1)                                              # :249-252 [B, 15]
+        wscore = torch.where(wscore == 0, torch.zeros_like(wscore), wscore)     # :257, :280: exact zeros are constants
+        return (wscore * self.chunk_scoring).sum(dim=1)                                              # :284
 
     def forward_representation(self, sequence_embeddings: torch.Tensor, sequence_mask: torch.Tensor,
                                positional_features=None):

@@ -328,8 +328,49 @@ def gen_idcm():
                             packed_indices=sec["packed_indices"].numpy(), **sd)
 
 
+def gen_tkl_grad():
+    # gradients of the REAL TKL_sigir20.forward (contextualiser bypassed as in gen_tkl) w.r.t. its inputs and every
+    # trainable scoring parameter: what loss.backward() (train.py:503-524) sends through sigir20_tkl.py:180-286
+    for sat, seed in (("embedding", 3101), ("log", 3102)):
+        g = torch.Generator().manual_seed(seed)
+        B, Q, D, E = 3, 8, 333, 64
+        q = fp16_round(torch.randn(B, Q, E, generator=g))
+        d = fp16_round(torch.randn(B, D, E, generator=g))
+        d[0, 100:108] = q[0]                                       # a region that matches the query
+        d[1, 40:44] = q[1, :4]
+        qm = prefix_mask(torch.tensor([8, 5, 3]), Q, torch.float32)
+        dm = prefix_mask(torch.tensor([333, 200, 61]), D, torch.float32)
+        m = R.make_tkl(E, saturation_type=sat, att_heads=8, seed=seed)
+        with torch.no_grad():
+            m.chunk_scoring.uniform_(0.5, 1.5, generator=g)
+            m.kernel_mult.uniform_(0.5, 1.5, generator=g)
+            m.sat_normer.weight.uniform_(0.5, 1.5, generator=g)
+            m.sat_normer.bias.uniform_(-0.5, 0.5, generator=g)
+            m.dense.weight.uniform_(-0.5, 0.5, generator=g)
+            m.sat_emb_reduce1.weight.uniform_(-0.2, 0.2, generator=g)
+            for lin in (m.saturation_linear, m.saturation_linear2, m.saturation_linear3):
+                lin.weight.uniform_(-0.3, 0.3, generator=g)
+                lin.bias.uniform_(1.0, 3.0, generator=g)           # the init of 100 (:99-107) would hide every gradient
+        m.train()
+        q.requires_grad_(True)
+        d.requires_grad_(True)
+        go = torch.randn(B, generator=g)
+        score, sec = m.forward(q, d, qm, dm, True) if sat == "embedding" else (m.forward(q, d, qm, dm), None)
+        (score * go).sum().backward()
+        grads = {"grad." + k: p.grad.numpy() for k, p in m.named_parameters()
+                 if p.grad is not None and not k.startswith(("contextualizer", "positional"))}
+        extra = {"orig_score": sec["orig_score"].detach().numpy()} if sec is not None else {}
+        sd = {"param." + k: v.detach().numpy() for k, v in m.state_dict().items()
+              if not k.startswith("contextualizer") and not k.startswith("positional")}
+        np.savez_compressed(os.path.join(OUT, "grad_tkl_d333_e64_%s.npz" % sat),
+                            q_fp16=q.detach().to(torch.float16).numpy(), d_fp16=d.detach().to(torch.float16).numpy(),
+                            q_mask=qm.numpy(), d_mask=dm.numpy(), saturation=np.array(sat), grad_out=go.numpy(),
+                            score=score.detach().numpy(), grad_q=q.grad.numpy(), grad_d=d.grad.numpy(),
+                            **extra, **grads, **sd)
+
+
 GENERATORS = {"colbert": gen_colbert, "colbert_e2e": gen_colbert_e2e, "e2e_tk_tkl": gen_e2e_tk_tkl, "tk": gen_tk,
-              "knrm": gen_knrm, "conv_knrm": gen_conv_knrm, "tkl": gen_tkl, "tk_sparse": gen_tk_sparse, "idcm": gen_idcm}
+              "knrm": gen_knrm, "conv_knrm": gen_conv_knrm, "tkl": gen_tkl, "tk_sparse": gen_tk_sparse, "idcm": gen_idcm, "tkl_grad": gen_tkl_grad}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):      # python gen_golden.py [generator ...]

@@ -173,3 +173,47 @@ def test_full_tk_and_tkl_forward_match_the_real_classes_end_to_end():
     with torch.no_grad():
         s = m.forward(t("q"), t("d"), t("q_mask"), t("d_mask"))
     np.testing.assert_allclose(s.cpu().numpy(), g["score"], atol=5e-3, rtol=2e-4)
+
+
+@pytest.mark.parametrize("sat", ["embedding", "log"])
+def test_tkl_training_gradients_match_the_real_class(sat):
+    """grad_tkl_*.npz hold the gradients of the REAL TKL_sigir20.forward (contextualiser bypassed) w.r.t. inputs and
+    every trainable scoring parameter.  Drop-in: native forward (value + window scores), selected-window carrier."""
+    from tests.test_variants_cpu import _tkl_bypass, check_tkl_grads, _params
+    dev = util.require_gpu()
+    g = util.load("grad_tkl_d333_e64_%s.npz" % sat)
+    m = _tkl_bypass(64, sat, _params(g)).to(dev).train()
+    t = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).float().to(dev)
+    q, d = t("q").requires_grad_(True), t("d").requires_grad_(True)
+    score = m.forward(q, d, t("q_mask"), t("d_mask"))
+    np.testing.assert_allclose(score.detach().cpu().numpy(), g["score"], atol=util.TOL_FP32, rtol=1e-5)
+    (score * t("grad_out")).sum().backward()
+    check_tkl_grads(m, g, q, d, tol=5e-4)
+    # the value is the native one (the carrier only contributes its gradient)
+    with torch.no_grad():
+        plain = m.forward(q.detach(), d.detach(), t("q_mask"), t("d_mask"))
+    assert torch.equal(plain, score.detach())
+
+
+def test_tkl_full_model_trains_end_to_end():
+    """The whole drop-in (Transformer contextualiser included) takes an optimiser step in train mode."""
+    dev = util.require_gpu()
+    torch.manual_seed(11)
+    m = make_model(64, "embedding", dev, bypass=False).train()
+    with torch.no_grad():
+        for lin in (m.saturation_linear, m.saturation_linear2, m.saturation_linear3):
+            lin.bias.fill_(2.0)
+    B, Q, D = 3, 10, 700
+    q, d = torch.randn(B, Q, 64, device=dev), torch.randn(B, D, 64, device=dev)
+    qm = (torch.arange(Q, device=dev)[None] < torch.tensor([10, 4, 7], device=dev)[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < torch.tensor([700, 130, 41], device=dev)[:, None]).float()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    s0 = m.forward(q, d, qm, dm)
+    (-s0.sum()).backward()
+    for p in (m.dense.weight, m.chunk_scoring, m.mixer, m.sat_emb_reduce1.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in m.contextualizer.parameters())
+    opt.step()
+    with torch.no_grad():
+        s1 = m.forward(q, d, qm, dm)
+    assert torch.isfinite(s1).all() and not torch.equal(s0.detach(), s1)
