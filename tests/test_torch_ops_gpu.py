@@ -1,0 +1,85 @@
+"""GPU: torch.ops.mm_native.* — same numbers as matchmaker_amd.ops, autograd through the native backward kernels,
+and the autocast rules (fp16 MaxSim as under the reference's torch.cuda.amp.autocast, colbert.py:60; fp32 pooling)."""
+import numpy as np
+import pytest
+import torch
+
+import matchmaker_amd.torch_ops  # noqa: F401
+from matchmaker_amd import ops
+from oracle import np_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+
+
+def test_maxsim_op_autograd_and_autocast():
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(1)
+    B, Q, D, E = 6, 32, 180, 128
+    q = torch.randn(B, Q, E, generator=gen).to(dev)
+    d = torch.randn(B, D, E, generator=gen).to(dev)
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B,), generator=gen)[:, None]).long().to(dev)
+    dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (B,), generator=gen)[:, None]).long().to(dev)
+    s = torch.ops.mm_native.maxsim(q, d, qm, dm, 1)
+    assert torch.equal(s, ops.maxsim(q, d, qm, dm))
+    ref = O.maxsim_paired(q.cpu().numpy(), d.cpu().numpy(), qm.cpu().numpy(), dm.cpu().numpy(), dtype=np.float64)
+    np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+    # autocast: fp32 inputs run through the fp16 kernel (what the reference's autocast does to its bmm), fp32 scores
+    with torch.autocast("cuda", dtype=torch.float16):
+        sa = torch.ops.mm_native.maxsim(q, d, qm, dm, 1)
+    assert sa.dtype == torch.float32 and torch.equal(sa, ops.maxsim(q.half(), d.half(), qm, dm))
+    np.testing.assert_allclose(sa.cpu().numpy(), ref, atol=0.15, rtol=util.TOL_BF16)
+    # autograd through mm_maxsim_bwd
+    ql, dl = q.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    go = torch.randn(B, generator=gen).to(dev)
+    (torch.ops.mm_native.maxsim(ql, dl, qm, dm, 1) * go).sum().backward()
+    gq, gd = ops.maxsim_bwd(q, d, qm, dm, go)
+    assert torch.equal(ql.grad, gq) and torch.equal(dl.grad, gd)
+    ib = torch.ops.mm_native.maxsim_inbatch(q, qm, d, dm, False)
+    assert torch.equal(ib, ops.maxsim_inbatch(q, qm, d, dm))
+    np.testing.assert_allclose(torch.diagonal(ib).cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+def test_kernel_pool_op_autograd_and_autocast():
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(2)
+    B, Q, D, E = 5, 20, 200, 300
+    q = torch.randn(B, Q, E, generator=gen).to(dev)
+    d = torch.randn(B, D, E, generator=gen).to(dev)
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B,), generator=gen)[:, None]).float().to(dev)
+    dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (B,), generator=gen)[:, None]).float().to(dev)
+    mu, sigma = torch.tensor(MU).to(dev), torch.full((11,), 0.1).to(dev)
+    alpha, w = (torch.rand(11, generator=gen) + 0.5).to(dev), torch.randn(11, generator=gen).to(dev)
+    gate = torch.relu(torch.randn(B, D, generator=gen)).to(dev)
+    s = torch.ops.mm_native.kernel_pool(q, d, qm, dm, mu, sigma, alpha, w, 1, gate, 1e-10)
+    assert torch.equal(s, ops.kernel_pool(q, d, qm, dm, mu, sigma, alpha, w, d_gate=gate))
+    with torch.autocast("cuda", dtype=torch.float16):                # the pooling family stays fp32 under autocast
+        sa = torch.ops.mm_native.kernel_pool(q.half(), d.half(), qm, dm, mu, sigma, alpha, w, 1, gate, 1e-10)
+    assert torch.equal(sa, ops.kernel_pool(q.half().float(), d.half().float(), qm, dm, mu, sigma, alpha, w, d_gate=gate))
+    leaves = [t.clone().requires_grad_(True) for t in (q, d, alpha, w, gate)]
+    go = torch.randn(B, generator=gen).to(dev)
+    (torch.ops.mm_native.kernel_pool(leaves[0], leaves[1], qm, dm, mu, sigma, leaves[2], leaves[3], 1, leaves[4], 1e-10) * go).sum().backward()
+    want = ops.kernel_pool_bwd(q, d, qm, dm, mu, sigma, alpha, w, go, d_gate=gate)
+    for leaf, g in zip(leaves, want):
+        assert torch.equal(leaf.grad, g.view_as(leaf))
+
+
+def test_tkl_window_pool_op_equals_the_dropin_path():
+    from matchmaker_amd.tkl import chunk_documents
+    from tests.test_tkl_gpu import make_model
+    dev = util.require_gpu()
+    torch.manual_seed(3)
+    m = make_model(64, "embedding", dev)
+    B, Q, D = 3, 12, 500
+    q, d = torch.randn(B, Q, 64, device=dev), torch.randn(B, D, 64, device=dev)
+    qm = torch.ones(B, Q, device=dev)
+    dm = (torch.arange(D, device=dev)[None] < torch.tensor([500, 77, 300], device=dev)[:, None]).float()
+    with torch.no_grad():
+        want, sec = m.forward(q, d, qm, dm, output_secondary_output=True)
+        q_ctx, _ = m.forward_representation(q, qm)
+        chunks, cmask, slot, C = chunk_documents(d, dm)
+        chunks_ctx, _ = m.forward_representation(chunks, cmask)
+        score, win = torch.ops.mm_native.tkl_window_pool(q_ctx, chunks_ctx, cmask, slot, qm, m.pack_params(), B, C, 11, "embedding")
+    assert torch.equal(score, want) and torch.equal(win, sec["orig_score"])
