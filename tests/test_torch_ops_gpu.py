@@ -83,3 +83,38 @@ def test_tkl_window_pool_op_equals_the_dropin_path():
         chunks_ctx, _ = m.forward_representation(chunks, cmask)
         score, win = torch.ops.mm_native.tkl_window_pool(q_ctx, chunks_ctx, cmask, slot, qm, m.pack_params(), B, C, 11, "embedding")
     assert torch.equal(score, want) and torch.equal(win, sec["orig_score"])
+
+
+def test_operators_are_reentrant_across_threads_and_streams():
+    """nn.DataParallel drives forward() from one Python thread per replica (train.py:201): the operators must hold
+    no shared mutable state and honour the calling thread's current stream."""
+    import threading
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(4)
+    q = torch.randn(8, 32, 128, generator=gen).to(dev).to(torch.bfloat16)
+    d = torch.randn(8 * 50, 180, 128, generator=gen).to(dev).to(torch.bfloat16)
+    d_len = torch.randint(1, 181, (400,), generator=gen).to(torch.int32).to(dev)
+    qf, df = torch.randn(6, 20, 300, generator=gen).to(dev), torch.randn(6, 200, 300, generator=gen).to(dev)
+    prm = [torch.tensor(MU).to(dev), torch.full((11,), 0.1).to(dev), torch.ones(11).to(dev), torch.randn(11, generator=gen).to(dev)]
+    want_a = ops.maxsim(q, d, None, d_len, pairs_per_query=50)
+    want_b = ops.kernel_pool(qf, df, None, None, *prm)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    a = ops.maxsim(q, d, None, d_len, pairs_per_query=50)
+                    b = ops.kernel_pool(qf, df, None, None, *prm)
+                st.synchronize()
+            if not (torch.equal(a, want_a) and torch.equal(b, want_b)):
+                errors.append("thread %d: results differ" % i)
+        except Exception as e:           # noqa: BLE001
+            errors.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
