@@ -137,7 +137,8 @@ int mm_maxsim_bwd(const void* q, const void* d,
  *           (cosine = allennlp CosineMatrixAttention, call site ecai20_tk.py:105)
  *
  *   q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings
- *   mu, sigma, alpha, w: float32[K] device pointers, K <= 16
+ *   mu, sigma, alpha, w: float32[K] device pointers, K <= 32 (K = 11, the reference configs, takes the
+ *          streaming kernels; any other count the generic kernel)
  *   per_kernel: optional float32 [n_pairs, K] (the reference's secondary output), may be NULL
  *   masks: float {0,1} as the reference passes them (MM_MASK_F32) or any other mm mask kind;
  *          nonzero = real token.  workspace as for mm_maxsim_fwd.

@@ -1232,16 +1232,20 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
   const int qlen = a.qm.len ? a.qm.len[qi] : Q;
   const char* dbase = (const char*)a.d + (pair * a.d_doc_rows + a.d_row0) * rowb;
   const char* qbase = (const char*)a.q + qi * Q * rowb;
+  // K is the number of kernel slots this instantiation evaluates, a.K <= K the run-time kernel count
+  // (K = 11 = a.K for the reference's configs; the K = 32 instantiation serves every other count)
+  const int nk = a.K < K ? a.K : K;
   Rbf rbf;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const float sg = a.sigma[k];
-    rbf.mu[k] = a.mu[k];
+    const bool real = k < nk;
+    const float sg = real ? a.sigma[k] : 1.0f;
+    rbf.mu[k] = real ? a.mu[k] : 0.0f;
     rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
-    rbf.alpha[k] = a.alpha ? a.alpha[k] : 1.0f;
-    rbf.w[k] = a.w ? a.w[k] : 0.0f;
+    rbf.alpha[k] = (real && a.alpha) ? a.alpha[k] : 1.0f;
+    rbf.w[k] = (real && a.w) ? a.w[k] : 0.0f;
   }
-  pack_rbf<K>(rbf);
+  pack_rbf<K>(rbf, nk);
   float tot[kMaxK];
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) tot[k] = 0.0f;
@@ -1293,7 +1297,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (a.dm.bits[pair * nblk_tot + t] & ex) : ex;
-      if (TKL)
+      if constexpr (TKL)
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, qtok, h, acc, rdr, rq, va >> (4 * h), rbf);
       else
         rbf_block<K, W>(pk2, acc, rdr, rq, va, h, rbf, lw);
@@ -1301,18 +1305,22 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a)
     if (TKL) continue;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const float pkk = pk2[k >> 1][k & 1];
-      const float v = pkk + __shfl_xor(pkk, 32, 64);
-      float lg = __logf(fmaxf(v * rbf.alpha[k], a.clamp_min));
-      tot[k] += wave_sum((qvalid && h == 0) ? lg : 0.0f);
+      if (k < nk) {
+        const float pkk = pk2[k >> 1][k & 1];
+        const float v = pkk + __shfl_xor(pkk, 32, 64);
+        float lg = __logf(fmaxf(v * rbf.alpha[k], a.clamp_min));
+        tot[k] += wave_sum((qvalid && h == 0) ? lg : 0.0f);
+      }
     }
   }
   if (TKL) return;
   float total = 0.0f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = tot[k];
-    total += rbf.w[k] * tot[k];
+    if (k < nk) {
+      if (a.per_kernel && lane == 0) a.per_kernel[pair * (int64_t)nk + k] = tot[k];
+      total += rbf.w[k] * tot[k];
+    }
   }
   if (lane == 0) a.out[pair] = total;
 }
@@ -1431,7 +1439,7 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
   if (!(clamp_min > 0.0f)) return set_error(MM_EINVAL, "kernel_pool: clamp_min must be > 0 (it sits inside a log)");
   if (pair_query && n_queries <= 0) return set_error(MM_EINVAL, "kernel_pool: pair_query needs n_queries");
   const int64_t q_rows = pair_query ? n_queries : (n_pairs + pairs_per_query - 1) / pairs_per_query;
-  if (K != 11) return set_error(MM_EUNSUPPORTED, "kernel_pool: K=%d kernels (only the reference's 11 are instantiated)", K);
+  if (K <= 0 || K > kMaxK) return set_error(MM_EUNSUPPORTED, "kernel_pool: K=%d kernels (1..%d supported)", K, kMaxK);
   if (E % 4) return set_error(MM_EUNSUPPORTED, "kernel_pool: E=%d rows are not 16-byte multiples", E);
   if (((uintptr_t)q | (uintptr_t)d) & 15) return set_error(MM_EINVAL, "kernel_pool: q/d must be 16-byte aligned");
   if (n_pairs == 0) return MM_OK;
@@ -1445,7 +1453,15 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, q_rows, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-  return launch_k<11>(a, stream);
+  if (K == 11) return launch_k<11>(a, stream);
+  // any other kernel count (the lists in tk_kernels_mu / knrm_kernels are configuration): the generic kernel with
+  // run-time K
+  if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
+  if (a.dw)
+    hipLaunchKernelGGL((kernel_pool_generic_kernel<kMaxK, false, true>), dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((kernel_pool_generic_kernel<kMaxK, false, false>), dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
+  return check_launch("kernel_pool_generic_kernel<run-time K>");
 }
 
 extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,

@@ -24,7 +24,7 @@
 
 namespace mm {
 
-constexpr int kBK = 16;  // max kernels
+constexpr int kBK = 32;  // max kernels
 
 struct KpBwdArgs {
   const float* q;

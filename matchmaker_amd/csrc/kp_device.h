@@ -4,7 +4,7 @@
 
 namespace mm {
 
-constexpr int kMaxK = 16;
+constexpr int kMaxK = 32;  // array bound; the streaming kernels are instantiated for the reference's K = 11
 
 struct KpArgs {
   const float* q;
@@ -64,16 +64,17 @@ struct Rbf {
   f32x2 msq2[kMaxK / 2];
 };
 
+// nk <= K real kernels (nk < K: the generic kernel's run-time kernel count); the rest are dummies
 template <int K>
-__device__ __forceinline__ void pack_rbf(Rbf& rbf) {
+__device__ __forceinline__ void pack_rbf(Rbf& rbf, int nk = K) {
 #pragma unroll
   for (int kp = 0; kp < (K + 1) / 2; ++kp) {
     float sq[2], msq[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int k = 2 * kp + u;
-      sq[u] = k < K ? sqrtf(-rbf.c2[k]) : 0.0f;
-      msq[u] = k < K ? rbf.mu[k] * sq[u] : 1.0e3f;  // dummy partner: exp2(-(0*c - 1e3)^2) = 0 for every c
+      sq[u] = (k < K && k < nk) ? sqrtf(-rbf.c2[k]) : 0.0f;
+      msq[u] = (k < K && k < nk) ? rbf.mu[k] * sq[u] : 1.0e3f;  // dummy: exp2(-(0*c - 1e3)^2) = 0 for every c
     }
     rbf.sq2[kp] = f32x2{sq[0], sq[1]};
     rbf.msq2[kp] = f32x2{msq[0], msq[1]};

@@ -243,3 +243,60 @@ def test_idcm_dropin_matches_the_real_class_end_to_end(fname, ctx_kind):
     loss[0][0].backward()
     assert m.sampling_binweights.weight.grad.abs().sum() > 0 and torch.isfinite(m.kernel_alpha_scaler.grad).all()
     assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in m.sample_cnn3.parameters())
+
+
+@pytest.mark.parametrize("K,E", [(1, 300), (5, 64), (21, 300), (32, 128), (12, 100)])
+def test_kernel_counts_other_than_eleven(K, E):
+    """tk_kernels_mu / knrm_kernels are configuration: any K <= 32 runs (generic kernel with run-time K), forward
+    and backward; KNRM's own kernel table (knrm.py:100-130) at K = 21 goes through the drop-in."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(K * 10 + E)
+    B, Q, D = 4, 14, 70
+    q = torch.randn(B, Q, E, generator=gen)
+    d = torch.randn(B, D, E, generator=gen)
+    d[0, 3] = q[0, 1]
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B,), generator=gen)[:, None]).float()
+    dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (B,), generator=gen)[:, None]).float()
+    mu = torch.linspace(1.0, -0.9, K) if K > 1 else torch.tensor([0.3])
+    sigma = torch.full((K,), 0.1)
+    alpha, w = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen)
+    s, pk = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev), alpha.to(dev), w.to(dev),
+                            return_per_kernel=True)
+    ref, ref_pk = O.tk_kernel_pool(q.numpy(), d.numpy(), qm.numpy(), dm.numpy(), mu.numpy(), sigma.numpy(), alpha.numpy(),
+                                   w.numpy(), dtype=np.float64, return_per_kernel=True)
+    assert pk.shape == (B, K)
+    np.testing.assert_allclose(pk.cpu().numpy(), ref_pk, atol=5e-3, rtol=1e-4)
+    np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32 * max(1.0, K / 11), rtol=1e-5)
+    leaves = [t.double().clone().requires_grad_(True) for t in (q, d, alpha, w)]
+    go = torch.randn(B, generator=gen)
+    TP.tk_kernel_pool(leaves[0], leaves[1], qm.double(), dm.double(), mu.double().view(1, 1, 1, -1),
+                      sigma.double().view(1, 1, 1, -1), leaves[2].view(1, 1, -1), leaves[3].view(1, -1)).backward(go.double())
+    got = ops.kernel_pool_bwd(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev), alpha.to(dev),
+                              w.to(dev), go.to(dev))
+    for g_, leaf, name in zip(got, leaves, ("grad_q", "grad_d", "grad_alpha", "grad_w")):
+        want = leaf.grad.numpy()
+        np.testing.assert_allclose(g_.cpu().numpy().astype(np.float64), want, atol=2e-4 * max(1.0, np.abs(want).max()),
+                                   rtol=2e-3, err_msg=name)
+    with pytest.raises(ops.NativeError):
+        z = torch.zeros(33, device=dev)
+        ops.kernel_pool(q.to(dev), d.to(dev), None, None, z, z + 0.1, z + 1, z)
+
+
+def test_knrm_with_21_kernels():
+    from matchmaker_amd.knrm import KNRM
+    dev = util.require_gpu()
+    torch.manual_seed(21)
+    m = KNRM(21).to(dev).eval()
+    B, Q, D, E = 3, 10, 40, 300
+    q, d = torch.randn(B, Q, E), torch.randn(B, D, E)
+    d[0, 2] = q[0, 0]
+    qm = (torch.arange(Q)[None] < torch.tensor([10, 4, 1])[:, None]).float()
+    dm = (torch.arange(D)[None] < torch.tensor([40, 7, 22])[:, None]).float()
+    qi, di = q * qm[..., None], d * dm[..., None]
+    with torch.no_grad():
+        s = m.forward(qi.to(dev), di.to(dev), qm.to(dev), dm.to(dev))
+    ref = O.knrm_kernel_pool(qi.numpy(), di.numpy(), qm.numpy(), dm.numpy(), np.asarray(m.mu.cpu()).reshape(-1),
+                             np.asarray(m.sigma.cpu()).reshape(-1), m.dense.weight.detach().cpu().numpy().reshape(-1),
+                             dtype=np.float64)
+    np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
