@@ -190,7 +190,7 @@ def main():
         if tr is not None:
             out["roofline"]["traffic"] = tr[0]
             out["roofline"]["traffic_source"] = f"profiles/{tr[1]} (rocprofv3 PMC passes of this workload)"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is an N = 1 figure; ranks > 0 would idle through it
             nsamp = min(nq, 24)
             out["cpu_baseline"] = cpu_baseline(q[:nsamp].cpu(), d[:nsamp * CANDS].cpu(), q_len[:nsamp].cpu(),
                                                d_len[:nsamp * CANDS].cpu(), CANDS)
