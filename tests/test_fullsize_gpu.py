@@ -1,0 +1,80 @@
+"""GPU: the largest single-GPU workloads BASELINE.json names, checked through size-independent properties.
+
+* configs[3] (MSMARCO-dev re-ranking, 6,980 queries x 1000 candidates over 8 GPUs): ONE rank's shard — 873 queries,
+  873,000 pairs, 40 GB of bf16 token embeddings resident — determinism, exact power-of-two linearity, whole
+  queries against the oracle.
+* configs[4] (BERT_DOT brute force over 8.8 M passages on 8 GPUs): one rank's shard of 1,105,228 x 768 fp16 vectors
+  against all 6,980 queries — determinism, planted documents found at their ranks, a sample of queries against an
+  exact fp32 ranking (torch matmul + topk on the device as the checker; the numpy oracle covers the small cases).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maxsim_one_rank_shard_of_config4():
+    from matchmaker_amd import ops, sharding, synth
+    dev = util.require_gpu()
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 100e9:
+        pytest.skip("needs ~85 GB free HBM (40 GB shard + the generator's scratch)")
+    s0, s1 = sharding.shard_range(6980, 8, 0)
+    nq, C = s1 - s0, 1000
+    assert nq == 873
+    q, d, q_len, d_len = synth.colbert_batch(nq, C, dtype=torch.bfloat16, device=dev, lengths="msmarco", seed=44)
+    out = ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)
+    assert out.shape == (nq * C,) and torch.isfinite(out).all()
+    assert torch.equal(out, ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)), "non-deterministic"
+    half = ops.maxsim((q.float() * 0.5).to(torch.bfloat16), d, q_len, d_len, pairs_per_query=C)
+    assert torch.equal(half, out * 0.5)
+    for i in (0, 436, 872):                                # whole queries incl. the last one of the shard
+        dn = d[i * C:(i + 1) * C].float().cpu().numpy()
+        dm = synth.len_to_mask(d_len[i * C:(i + 1) * C], 180).cpu().numpy()
+        qm = np.repeat(synth.len_to_mask(q_len[i:i + 1], 32).cpu().numpy(), C, 0)
+        ref = O.maxsim_paired(np.repeat(q[i:i + 1].float().cpu().numpy(), C, 0), dn, qm, dm)
+        np.testing.assert_allclose(out[i * C:(i + 1) * C].cpu().numpy(), ref, atol=util.TOL_BF16)
+    # the ranking this rank contributes is a permutation of its candidates, best first
+    ranking = sharding.rank_candidates(out.view(nq, C))
+    assert ranking.shape == (nq, C)
+    top = torch.gather(out.view(nq, C), 1, ranking)
+    assert (top[:, :-1] >= top[:, 1:]).all()
+
+
+def test_dot_topk_one_rank_shard_of_config5():
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    N, E, nq, k = 1105228, 768, 6980, 1000
+    g = torch.Generator(device=dev).manual_seed(55)
+    c = torch.empty(N, E, dtype=torch.float16, device=dev)
+    for lo in range(0, N, 1 << 17):                        # chunked: no fp32 copy of the shard
+        hi = min(N, lo + (1 << 17))
+        c[lo:hi] = (torch.randn(hi - lo, E, generator=g, device=dev) * 0.05).half()
+    q = (torch.randn(nq, E, generator=g, device=dev) * 0.05).half()
+    planted = torch.tensor([5, 777777, N - 1], device=dev)
+    c[planted] = (q[123].float() * torch.tensor([3.0, 2.5, 2.0], device=dev)[:, None]).half()
+    s, idx = ops.dot_topk(q, c, k)
+    assert s.shape == (nq, k) and idx.shape == (nq, k)
+    assert idx[123, :3].tolist() == planted.tolist(), "planted near-duplicates must lead query 123's list"
+    assert (s[:, :-1] >= s[:, 1:]).all() and (idx >= 0).all() and (idx < N).all()
+    s2, idx2 = ops.dot_topk(q, c, k)
+    assert torch.equal(s, s2) and torch.equal(idx, idx2), "non-deterministic"
+    sel = torch.tensor([0, 123, 3490, 6979], device=dev)
+    full = q[sel].float() @ c.float().T if False else torch.cat(
+        [q[sel].float() @ c[lo:lo + (1 << 18)].float().T for lo in range(0, N, 1 << 18)], dim=1)
+    ref_s, ref_i = torch.topk(full, k, dim=1)
+    np.testing.assert_allclose(s[sel].cpu().numpy(), ref_s.cpu().numpy(), atol=2e-3, rtol=1e-3)
+    for r in range(sel.numel()):
+        got, want = set(idx[sel[r]].tolist()), set(ref_i[r].tolist())
+        # the sets agree except for candidates within accumulation noise of the k-th score
+        kth = float(ref_s[r, -1])
+        for j in got ^ want:
+            assert abs(float(full[r, j]) - kth) < 2e-3, (int(sel[r]), j)
+    # every returned score is the inner product of its row
+    rows = idx[sel]
+    chk = torch.stack([(c[rows[r]].float() @ q[sel[r]].float()) for r in range(sel.numel())])
+    np.testing.assert_allclose(s[sel].cpu().numpy(), chk.cpu().numpy(), atol=2e-3, rtol=1e-3)
