@@ -110,8 +110,9 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
 // is wall time.
 // W: lw[i] = log2(gate of row i) rides in the exponent (exp2(x + log2 g) = g exp2(x); g = 0 -> -inf -> 0),
 // which turns the pk_mul of the square into a pk_fma: the gate costs no instruction.
-// KP0..KP1: the kernel pairs this call evaluates (a K-split workgroup shares the 6 pairs between its waves).
-template <int K, bool W = false, int KP0 = 0, int KP1 = (K + 1) / 2>
+// KP0..KP1: the kernel pairs this call evaluates, G0..G1: the 8-row groups (a K-split workgroup shares the
+// epilogue between its two waves either by kernel pairs or by rows).
+template <int K, bool W = false, int KP0 = 0, int KP1 = (K + 1) / 2, int G0 = 0, int G1 = 4>
 __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
                                           uint32_t va, int h, const Rbf& rbf, const float* lw = nullptr) {
   // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
@@ -120,7 +121,7 @@ __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16&
   // no per-row select.
   const uint32_t vbits = va >> (4 * h);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int g = G0; g < G1; ++g) {
     const uint32_t gm = (va >> (8 * g)) & 0xffu;
     if (gm == 0) continue;
     const bool full = gm == 0xffu;
