@@ -1348,21 +1348,23 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
       hipLaunchKernelGGL((kernel_pool_stream_kernel<3, K, NBUF, true, TKL>), grid, block, lds, stream, a);
     return check_launch("kernel_pool_stream_kernel");
   }
+  // No non-temporal hint on these K-sliced streams: the 400-B row pieces of neighbouring slices share cache
+  // lines, and with `nt` the shared lines came from HBM twice (FETCH_SIZE 1.22 x the padded bytes, 1.08 x without).
   if constexpr (TKL) {  // grouped runs of chunks (tkl_stage1_run_kernel)
     if (a.E == 100)
-      hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, true>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, false>), grid, block, lds, stream, a);
     else if (a.E == 200)
-      hipLaunchKernelGGL((tkl_stage1_run_kernel<2, K, NBUF, true>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<2, K, NBUF, false>), grid, block, lds, stream, a);
     else
-      hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, true>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, false>), grid, block, lds, stream, a);
     return check_launch("tkl_stage1_run_kernel");
   } else {
     if (a.E == 100)
-      hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, true, false, W>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, false, false, W>), grid, block, lds, stream, a);
     else if (a.E == 200)
-      hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, true, false, W>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, false, false, W>), grid, block, lds, stream, a);
     else
-      hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, true, false, W>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, false, false, W>), grid, block, lds, stream, a);
     return check_launch("kernel_pool_split_kernel");
   }
 }
