@@ -19,7 +19,8 @@ namespace mm {
 
 constexpr int kU = 20;        // position pairs per chunk
 constexpr int kWinPairs = 15; // 30 positions, stride 2
-constexpr int kWT = 32;       // windows per workgroup in stage 2
+constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows staged: kWT + 14)
+constexpr int kWThreads = 512;
 
 
 // slot -> (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2); -1 = dropped
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) tkl_emb_kernel(const float* __restrict__ 
 
 // One workgroup = kWT consecutive windows of one document.
 template <int SAT>
-__global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
+__global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
                                                          const float* __restrict__ emb_g,
                                                          const float* __restrict__ q_mask,
                                                          const float* __restrict__ prm, float* __restrict__ win,
@@ -68,21 +69,29 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
   float* tile = (float*)smem;                         // [nu][Q][12]
   float* emb = tile + (size_t)nu * rowf;              // [Q]   sat_emb_reduce1(q_ctx)  (:224)
   float* red = emb + ((Q + 3) & ~3);                  // [kWT][Q] per-(window, query token) dense-weighted value
+  __shared__ int cinfo[8];                            // slot2p entries of the (<= 4) chunks this tile touches
+
+  // the chunk lookups first, once per tile, so that the row loads below are independent of each other
+  const int c0 = w0 / kU;
+  if (tid < 8) {
+    const int c = c0 + tid;
+    cinfo[tid] = c < C ? slot2p[(int64_t)b * C + c] : -1;
+  }
+  __syncthreads();
 
   // ---- stage the pair-sum rows (zeros for dropped chunks) --------------------------------------
-  // Two dependent global loads per element (slot -> packed chunk, then the row): all lookups of a
-  // batch of kStage elements are issued before the first row load, and all row loads before the
-  // first LDS store, so a thread pays ~2 memory latencies per batch instead of 2 per element
-  // (the kernel was 67 % s_waitcnt: profiles/r01_tkl_pmc.json).
+  // All row loads of a batch of kStage elements are issued before the first LDS store, so a thread pays
+  // one memory latency per batch (a tile of Q = 20 is ONE batch); the kernel was 67 % s_waitcnt when every
+  // element did its own dependent slot -> chunk -> row chain.
   const int row4 = rowf / 4;
   const int total4 = nu * row4;
   constexpr int kStage = 10;
-  for (int base = tid; base < total4; base += 256 * kStage) {
+  for (int base = tid; base < total4; base += kWThreads * kStage) {
     int pidx[kStage];
     int off[kStage];
 #pragma unroll
     for (int s = 0; s < kStage; ++s) {
-      const int idx = base + 256 * s;
+      const int idx = base + kWThreads * s;
       pidx[s] = -1;
       off[s] = 0;
       if (idx < total4) {
@@ -90,10 +99,8 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
         const int ug = w0 + j;
         const int c = ug / kU, uu = ug - c * kU;
         off[s] = uu * rowf + v * 4;
-        if (c < C) {
-          const int info = slot2p[(int64_t)b * C + c];
-          if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;  // rows of unwritten blocks are zeros
-        }
+        const int info = cinfo[c - c0];                                // c - c0 <= (19 + nu) / 20 < 8
+        if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;    // rows of unwritten blocks are zeros
       }
     }
     f32x4 val[kStage];
@@ -104,7 +111,7 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
     }
 #pragma unroll
     for (int s = 0; s < kStage; ++s) {
-      const int idx = base + 256 * s;
+      const int idx = base + kWThreads * s;
       if (idx < total4) *(f32x4*)(tile + (size_t)idx * 4) = val[s];
     }
   }
@@ -113,15 +120,16 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
 
   const float* sp = prm + TklParams::sat();
   typedef __attribute__((ext_vector_type(2))) float f32x2;
-  // One item = TWO adjacent windows of one query token: windows wl and wl + 1 share 14 of their 15 pair rows,
-  // so the shared rows are summed once (16 row reads and 15 row additions for two windows instead of 30 and
-  // 28).  Only additions of non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
-  for (int item = tid; item < (kWT / 2) * Q; item += 256) {
+  // One item = FOUR adjacent windows of one query token: windows wl .. wl + 3 share 12 of their 15 pair rows, so
+  // the shared rows are summed once (18 row reads for four windows instead of 60).  Only additions of
+  // non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
+  constexpr int kG = 4;
+  for (int item = tid; item < (kWT / kG) * Q; item += kWThreads) {
     const int wp = item / Q, i = item - wp * Q;
-    const int wl = 2 * wp;
+    const int wl = kG * wp;
     if (w0 + wl >= W) {
-      red[wl * Q + i] = 0.0f;
-      red[(wl + 1) * Q + i] = 0.0f;
+#pragma unroll
+      for (int which = 0; which < kG; ++which) red[(wl + which) * Q + i] = 0.0f;
       continue;
     }
     auto row = [&](int j, f32x2 (&dst)[kKC / 2]) {
@@ -133,23 +141,37 @@ __global__ void __launch_bounds__(256) tkl_window_kernel(const float* __restrict
         dst[2 * v + 1] = f32x2{x[2], x[3]};
       }
     };
-    f32x2 core[kKC / 2], first[kKC / 2], last[kKC / 2], tmp[kKC / 2];
-    row(0, first);
-    row(1, core);
+    // rows 0..2 and 15..17 are the edges, rows 3..14 the core every window of the item contains
+    f32x2 core[kKC / 2], edge[6][kKC / 2], tmp[kKC / 2];
+    row(0, edge[0]);
+    row(1, edge[1]);
+    row(2, edge[2]);
+    row(3, core);
 #pragma unroll
-    for (int j = 2; j < kWinPairs; ++j) {
+    for (int j = 4; j < kWinPairs; ++j) {
       row(j, tmp);
 #pragma unroll
       for (int k = 0; k < kKC / 2; ++k) core[k] += tmp[k];
     }
-    row(kWinPairs, last);
+    row(kWinPairs, edge[3]);
+    row(kWinPairs + 1, edge[4]);
+    row(kWinPairs + 2, edge[5]);
     const float qmv = q_mask[(int64_t)b * Q + i];
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < kG; ++which) {
+      // window wl + which = edges which..2 (head) + core + edges 3..2+which (tail)
+      f32x2 acc2[kKC / 2];
+#pragma unroll
+      for (int k = 0; k < kKC / 2; ++k) {
+        f32x2 v = core[k];
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+          if ((e < 3 && e >= which) || (e >= 3 && e < 3 + which)) v += edge[e][k];
+        acc2[k] = v;
+      }
       float pk[kKC];
 #pragma unroll
-      for (int k = 0; k < kKC; ++k)
-        pk[k] = which == 0 ? first[k >> 1][k & 1] + core[k >> 1][k & 1] : core[k >> 1][k & 1] + last[k >> 1][k & 1];
+      for (int k = 0; k < kKC; ++k) pk[k] = acc2[k >> 1][k & 1];
       float val = 0.0f;
       const float len = pk[kK];                                        // :210 (exact small integer)
       const float factor = qmv * (len > 0.0f ? 1.0f : 0.0f);          // :248
@@ -316,12 +338,12 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     if (saturation == MM_TKL_SAT_EMBEDDING) {
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(256), lds2, stream, ps, slot2p,
+      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
                          emb, q_mask, params, win, C, Q, W);
     } else {
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(256), lds2, stream, ps, slot2p,
+      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
                          emb, q_mask, params, win, C, Q, W);
     }
     if (int e = check_launch("tkl_window_kernel")) return e;
