@@ -220,3 +220,53 @@ def test_conv_knrm_block_decomposition_matches_the_real_class():
             score += O.knrm_kernel_pool(a, b, g["q_mask"], g["d_mask"], mu, sigma, w[blk * 11:(blk + 1) * 11])
             blk += 1
     np.testing.assert_allclose(score, g["score"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.skipif(not R.available(), reason="needs the reference tree (config files + real classes)")
+@pytest.mark.parametrize("model_name,model_yaml", [("TK", "tk.yaml"), ("TKL", "tkl.yaml"), ("TK_Sparse", "tk.yaml"),
+                                                   ("knrm", None), ("conv_knrm", None)])
+def test_from_config_on_the_reference_yaml_files_builds_the_same_parameters(model_name, model_yaml):
+    """models/all.py:141-152 builds these models with Model.from_config(config, word_embedding_dim) from the merged
+    YAML files under config/train/.  The drop-ins must accept the very same dictionaries and end up with the same
+    parameters / buffers (names and shapes) as the real classes: checkpoints and param-group routing by name
+    (train.py:119-137) keep working."""
+    import os
+    import yaml
+    R.install_shims()
+    cfg = {}
+    files = ["defaults.yaml", "non-bert-defaults.yaml"] + ([os.path.join("models", model_yaml)] if model_yaml else [])
+    for f in files:
+        with open(os.path.join(R.REFERENCE_ROOT, "config", "train", f)) as fh:
+            cfg.update(yaml.safe_load(fh) or {})
+    cfg.setdefault("tk_att_proj_dim", 32)               # read by CIKM20_TK_Sparse.from_config, absent from the YAML files
+    emb_dim = 300
+    if model_name == "TK":
+        from matchmaker.models.published.ecai20_tk import ECAI20_TK as Ref
+        from matchmaker_amd.tk import ECAI20_TK as Mine
+    elif model_name == "TKL":
+        from matchmaker.models.published.sigir20_tkl import TKL_sigir20 as Ref
+        from matchmaker_amd.tkl import TKL_sigir20 as Mine
+    elif model_name == "TK_Sparse":
+        from matchmaker.models.published.cikm20_tk_sparse import CIKM20_TK_Sparse as Ref
+        from matchmaker_amd.tk_sparse import CIKM20_TK_Sparse as Mine
+    elif model_name == "knrm":
+        from matchmaker.models.knrm import KNRM as Ref
+        from matchmaker_amd.knrm import KNRM as Mine
+    else:
+        from matchmaker.models.conv_knrm import Conv_KNRM as Ref
+        from matchmaker_amd.conv_knrm import Conv_KNRM as Mine
+
+    # the reference builds its range vectors with torch.cuda.LongTensor: use the CPU branch for the test
+    saved = Ref.__dict__.get("get_range_vector")
+    if saved is not None:
+        Ref.get_range_vector = lambda self, size, device: torch.arange(0, size, dtype=torch.long)
+    try:
+        ref = Ref.from_config(cfg, emb_dim)
+    finally:
+        if saved is not None:
+            Ref.get_range_vector = saved
+    mine = Mine.from_config(cfg, emb_dim)
+    shapes = lambda m: {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert shapes(ref) == shapes(mine)
+    assert {k for k, _ in ref.named_parameters()} == {k for k, _ in mine.named_parameters()}
+    mine.load_state_dict(ref.state_dict(), strict=True)
