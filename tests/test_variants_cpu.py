@@ -161,3 +161,35 @@ def test_tkl_gradient_carrier_matches_gradients_of_the_real_class():
     np.testing.assert_allclose(s.detach().numpy(), g["score"], atol=1e-4, rtol=1e-5)
     (s * t("grad_out")).sum().backward()
     check_tkl_grads(m, g, q, d)
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_harness", fromlist=["available"]).available(),
+                    reason="live comparison with the real class needs the reference tree")
+@pytest.mark.parametrize("ctx_kind", ["tk", "ck", "ck-small"])
+def test_idcm_dropin_equals_the_live_reference_class_for_every_sampler(monkeypatch, ctx_kind):
+    """No fixture for the "tk" sampler (its Transformer weights are 3.5 MB): here the REAL IDCM runs next to the
+    drop-in on the same state_dict and inputs (CPU, oracle in the native operator's place)."""
+    from oracle import ref_harness as R
+    from matchmaker_amd import idcm, ops
+    torch.manual_seed(7)
+    ref = R.make_idcm(_tiny_distilbert(), sample_n=3, sample_context=ctx_kind, top_k_chunks=3, seed=5)
+    with torch.no_grad():
+        ref.sampling_binweights.weight.uniform_(-0.5, 0.5)
+        ref.kernel_alpha_scaler.uniform_(0.5, 1.5)
+    mine = idcm.IDCM(_tiny_distilbert(), sample_n=3, sample_context=ctx_kind, top_k_chunks=3, chunk_size=50, overlap=7,
+                     padding_idx=0, sample_train_type="mseloss")
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.eval()
+    monkeypatch.setattr(ops, "kernel_pool", _oracle_kernel_pool)
+    g = torch.Generator().manual_seed(3)
+    B, LQ, LD = 3, 10, 260
+    q_mask = (torch.arange(LQ)[None] < torch.tensor([10, 4, 7])[:, None]).long()
+    d_mask = (torch.arange(LD)[None] < torch.tensor([260, 33, 150])[:, None]).long()
+    query = {"input_ids": torch.randint(1, 200, (B, LQ), generator=g) * q_mask, "attention_mask": q_mask}
+    doc = {"input_ids": torch.randint(1, 200, (B, LD), generator=g) * d_mask, "attention_mask": d_mask}
+    with torch.no_grad():
+        want = ref.forward(query, doc, use_fp16=False, output_secondary_output=True)
+        got = mine.forward(query, doc, use_fp16=False, output_secondary_output=True)
+    np.testing.assert_allclose(got[2]["sampling_scores"].numpy(), want[2]["sampling_scores"].numpy(), atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(got[1].numpy(), want[1].numpy(), atol=1e-5)
+    np.testing.assert_allclose(got[0].numpy(), want[0].numpy(), atol=1e-5)
