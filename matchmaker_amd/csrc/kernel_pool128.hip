@@ -59,9 +59,27 @@ __host__ __device__ constexpr int kp128_lds_fixed(int KS) {
   return KS * (kS128Nbuf * kS128Bytes + 128) + (KS == 2 ? kXchgBytes : 0);
 }
 
-template <int NSL, int K, bool W, int KS>
+// MaxSim epilogue (MX): running maximum per accumulator register with ColBERT's -1000 sentinel for masked rows
+// (colbert.py:68-75), as maxsim.hip's block_max / finish_pair
+__device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint32_t ex, uint32_t va, float fill, int h) {
+  if (va == 0xffffffffu) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], acc[i]);
+  } else {
+    const uint32_t exs = ex >> (4 * h), vas = va >> (4 * h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int bit = rowof(i);
+      const float v = ((vas >> bit) & 1u) ? acc[i] : (((exs >> bit) & 1u) ? -1000.0f : fill);
+      m[i] = fmaxf(m[i], v);
+    }
+  }
+}
+
+template <int NSL, int K, bool W, int KS, bool MX = false>
 __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
+  static_assert(!MX || (KS == 1 && !W), "the fp32 MaxSim mode runs one wave per pair stream, no gate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = kS128Nbuf;
   const int lane = threadIdx.x & 63;
@@ -104,7 +122,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
     for (int j = 0; j < 2; ++j) aoff[p][j] = (uint32_t)(r * 256 + (((4 * p + 2 * h + j) ^ (r & 15)) << 4));
 
   Rbf rbf;
-  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+  if constexpr (!MX) load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
 
   const char* dbase = (const char*)a.d;
   auto doc_len = [&](int64_t p) -> int {
@@ -190,6 +208,11 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       const float* gw = a.dw + pair * (int64_t)D;
       for (int j = lane; j < 32 * nb; j += 64) wbuf[j] = j < D ? gate_log2(gw[j]) : -INFINITY;
     }
+    // MX: rows outside the effective length are -1000 if the document has padding at all, else they do not exist
+    const float fill = len < D ? -1000.0f : neg_inf();
+    float mrun[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mrun[i] = fill;
 
     for (int t = 0; t < nb; ++t) {
       f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
@@ -239,6 +262,13 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+      if constexpr (MX) {
+        const int rem = len - 32 * t;
+        const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+        const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+        mx_block(mrun, acc, ex, va, fill, h);
+        continue;
+      }
       ss += __shfl_xor(ss, 32, 64);
       if constexpr (KS == 2) {
         // partial dot tile + partial row norms of this wave's K half -> LDS; add the other wave's
@@ -281,6 +311,15 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
         else rbf_block<K, false, 3, (K + 1) / 2>(pk2, acc, rdr, rq, va, h, rbf);
       }
     }
+    if constexpr (MX) {  // max over the 32 rows of every block, then the masked sum over query tokens
+      float mx = mrun[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, mrun[i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float s = wave_sum((qvalid && h == 0) ? mx : 0.0f);
+      if (lane == 0) a.out[pair] = s;
+      continue;
+    }
     float pk[kMaxK];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -316,6 +355,38 @@ static int launch128(const KpArgs& a, const dim3 grid, int lds, hipStream_t stre
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, W, KS>), grid, dim3(64 * KS), lds, stream, a);
   return check_launch("kernel_pool_split128_kernel");
+}
+
+// fp32 MaxSim (ColBERT with use_fp16 = False, colbert.py:68-75) on the same stream: E = 64n <= 384, Q <= 32
+bool kp128_maxsim_supported(int Q, int E) {
+  const int nsl = E / 64;
+  return Q <= 32 && E % 64 == 0 && (nsl == 1 || nsl == 2 || nsl == 3 || nsl == 4 || nsl == 6);
+}
+
+int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask dm, float* out, int64_t n_pairs,
+                     int64_t pairs_per_query, int Q, int D, int E, hipStream_t stream) {
+  KpArgs a{};
+  a.q = q; a.d = d; a.qm = qm; a.dm = dm; a.out = out; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
+  a.Q = Q; a.D = D; a.E = E; a.d_doc_rows = D; a.clamp_min = 1e-10f;
+  if (n_pairs > 0x7fffffffLL * 64) return set_error(MM_EUNSUPPORTED, "maxsim: too many pairs for one launch");
+  const int lds = kp128_lds_fixed(1);
+  int64_t groups = (int64_t)kCUs * 4;
+  if (groups > a.n_pairs) groups = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
+  groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  const dim3 grid((unsigned)groups);
+#define MM_MX(NSL) \
+  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, 1, true>), grid, dim3(64), lds, stream, a); break
+  switch (a.E / 64) {
+    case 1: MM_MX(1);
+    case 2: MM_MX(2);
+    case 3: MM_MX(3);
+    case 4: MM_MX(4);
+    case 6: MM_MX(6);
+    default: return set_error(MM_EUNSUPPORTED, "maxsim: E=%d has no fp32 streaming kernel", a.E);
+  }
+#undef MM_MX
+  return check_launch("kernel_pool_split128_kernel<maxsim>");
 }
 
 int kp128_launch(const KpArgs& a0, hipStream_t stream) {

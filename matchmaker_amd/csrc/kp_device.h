@@ -205,4 +205,5 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 bool kp128_supported(int Q, int D, int E, bool gated);
 int kp128_launch(const KpArgs& a, hipStream_t stream);
 
+
 }  // namespace mm

@@ -696,6 +696,11 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   const bool stream_ok = !g_force_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
+  // fp32 token vectors (ColBERT run with use_fp16 = False): the split-bf16 streaming kernel of kernel_pool128.hip
+  // with the MaxSim epilogue
+  if (!g_force_generic && dtype == MM_F32 && kp128_maxsim_supported(Q, E)) {
+    return kp128_maxsim_f32((const float*)q, (const float*)d, a.qm, a.dm, out, n_pairs, pairs_per_query, Q, D, E, stream);
+  }
   return launch_generic(a, dtype, stream);
 }
 

@@ -92,15 +92,17 @@ def test_shared_query_layout_random(dtype, tol, Q, D, E, ppq, nq):
     np.testing.assert_allclose(out, ref, atol=tol, rtol=1e-4)
 
 
-def test_padding_content_is_ignored_and_holes_are_sentinel():
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, util.TOL_BF16), (torch.float32, util.TOL_FP32)])
+def test_padding_content_is_ignored_and_holes_are_sentinel(dtype, tol):
     """Garbage (inf/nan) in padded document rows must not leak; a hole inside the document counts
-    as -1000 exactly like the reference's masked assignment (colbert.py:69)."""
+    as -1000 exactly like the reference's masked assignment (colbert.py:69).  bf16: the roofline kernel;
+    fp32: the split-bf16 streaming kernel (kernel_pool128.hip, MaxSim epilogue)."""
     from matchmaker_amd import ops
     dev = util.require_gpu()
     g = torch.Generator().manual_seed(5)
     B, Q, D, E = 6, 32, 180, 128
-    q = torch.nn.functional.normalize(torch.randn(1, Q, E, generator=g), dim=-1).to(torch.bfloat16)
-    d = torch.nn.functional.normalize(torch.randn(B, D, E, generator=g), dim=-1).to(torch.bfloat16)
+    q = torch.nn.functional.normalize(torch.randn(1, Q, E, generator=g), dim=-1).to(dtype)
+    d = torch.nn.functional.normalize(torch.randn(B, D, E, generator=g), dim=-1).to(dtype)
     dm = torch.ones(B, D, dtype=torch.int64)
     dm[0, 100:] = 0
     dm[1, 31:] = 0
@@ -114,7 +116,7 @@ def test_padding_content_is_ignored_and_holes_are_sentinel():
     out = ops.maxsim(q.to(dev), d2.to(dev), None, dm.to(dev), pairs_per_query=B).cpu().numpy()
     ref = O.maxsim_paired(np.repeat(q.float().numpy(), B, 0), d.float().numpy(), np.ones((B, Q)), dm.numpy())
     assert np.isfinite(out).all()
-    np.testing.assert_allclose(out, ref, atol=util.TOL_BF16)
+    np.testing.assert_allclose(out, ref, atol=tol)
     assert out[4] == -1000.0 * Q
 
 

@@ -54,7 +54,7 @@ if "fp16" in which:
 if "fp32" in which:
     n = B // 4
     qf, df = q[: nq // 4].float(), d[:n].float()
-    report("fp32 shared-Q (generic kernel)", timeit(lambda: ops.maxsim(qf, df, q_len[: nq // 4], d_len[:n], C)), n, n * D * E * 4)
+    report("fp32 shared-Q (split-bf16 streaming kernel)", timeit(lambda: ops.maxsim(qf, df, q_len[: nq // 4], d_len[:n], C)), n, n * D * E * 4)
     del qf, df
 if "e768" in which:
     n = 8000
