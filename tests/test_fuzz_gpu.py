@@ -148,3 +148,71 @@ def test_dot_topk_random_shapes(seed):
     np.testing.assert_allclose(s[:, :kk], got, atol=5e-2, rtol=2e-3)
     if kk < k:
         assert (idx[:, kk:] == -1).all()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fp32_maxsim_streaming_widths(seed):
+    """fp32 MaxSim at the widths the split-bf16 streaming kernel serves (E = 64n <= 384, Q <= 32) and just outside
+    them: arbitrary masks, shared-query layout with a short last group."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    rng = np.random.default_rng(5000 + seed)
+    E = int(rng.choice([64, 128, 192, 256, 384, 320, 512]))
+    Q = int(rng.integers(1, 36))
+    D = int(rng.integers(1, 300))
+    ppq = int(rng.integers(1, 9))
+    nq = int(rng.integers(1, 6))
+    B = nq * ppq - (int(rng.integers(0, ppq)) if nq > 1 else 0)
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(nq, Q, E, generator=g) / E ** 0.5
+    d = torch.randn(B, D, E, generator=g) / E ** 0.5
+    qm = (torch.rand(nq, Q, generator=g) > 0.2).long()
+    dm = (torch.rand(B, D, generator=g) > 0.3).long()
+    if seed % 2:
+        dm = (torch.arange(D)[None] < torch.randint(0, D + 1, (B,), generator=g)[:, None]).long()   # prefix masks
+    dm[0] = 1
+    out = ops.maxsim(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), pairs_per_query=ppq).cpu().numpy()
+    qi = np.arange(B) // ppq
+    ref = O.maxsim_paired(q.numpy()[qi], d.numpy(), qm.numpy()[qi], dm.numpy(), dtype=np.float64)
+    np.testing.assert_allclose(out, ref, atol=util.TOL_FP32, rtol=1e-5, err_msg=f"E={E} Q={Q} D={D} ppq={ppq} B={B}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pooling_variants_random(seed):
+    """Random combinations of the pooling variants — gate, floor, ragged query groups, kernel count — over the
+    widths of all three kernel families (100n, 64n incl. the two-wave 512/768, generic)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    rng = np.random.default_rng(6000 + seed)
+    E = int(rng.choice([100, 300, 64, 128, 384, 512, 768, 36]))
+    K = 11 if seed % 3 else int(rng.integers(1, 33))
+    Q = int(rng.integers(1, 33))
+    D = int(rng.integers(1, 150))
+    nq = int(rng.integers(1, 6))
+    groups = rng.integers(0, 5, nq)
+    groups[0] = max(groups[0], 1)
+    pq = np.repeat(np.arange(nq), groups)
+    P = int(pq.size)
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(nq, Q, E, generator=g)
+    d = torch.randn(P, D, E, generator=g)
+    d[0, 0] = q[pq[0], 0]
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (nq,), generator=g)[:, None]).float()
+    dm = (torch.rand(P, D, generator=g) > 0.25).float()
+    use_gate = bool(seed % 2)
+    gate = torch.relu(torch.randn(P, D, generator=g)) if use_gate else None
+    clamp = [1e-10, 1e-4, 1e-7][seed % 3]
+    mu = torch.linspace(1.0, -0.9, K) if K > 1 else torch.tensor([0.5])
+    sigma = torch.full((K,), 0.1)
+    alpha, w = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    t = lambda x: None if x is None else x.to(dev)
+    out = ops.kernel_pool(t(q), t(d), t(qm), t(dm), t(mu), t(sigma), t(alpha), t(w), d_gate=t(gate), clamp_min=clamp,
+                          pair_query=torch.from_numpy(pq).to(dev)).cpu().numpy()
+    # oracle: TK pooling with the gate folded into the document mask and the floor as given
+    eff = dm.numpy() * (gate.numpy() if use_gate else 1.0)
+    cos = O.cosine_matrix(q.numpy()[pq], d.numpy(), np.float64)
+    act = np.exp(-(cos[..., None] - mu.numpy().reshape(1, 1, 1, -1)) ** 2 / (2 * 0.1 ** 2)) * eff[:, None, :, None]
+    lg = np.log(np.maximum(act.sum(2) * alpha.numpy().reshape(1, 1, -1), clamp)) * qm.numpy()[pq][..., None]
+    ref = lg.sum(1) @ w.numpy().astype(np.float64)
+    np.testing.assert_allclose(out, ref, atol=util.TOL_FP32 * max(1.0, K / 11), rtol=1e-5,
+                               err_msg=f"E={E} K={K} Q={Q} D={D} gate={use_gate} clamp={clamp}")
