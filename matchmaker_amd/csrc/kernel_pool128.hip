@@ -79,7 +79,7 @@ __device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint
 template <int NSL, int K, bool W, int KS, bool MX = false>
 __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
-  static_assert(!MX || (KS == 1 && !W), "the fp32 MaxSim mode runs one wave per pair stream, no gate");
+  static_assert(!MX || !W, "the fp32 MaxSim mode has no gate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = kS128Nbuf;
   const int lane = threadIdx.x & 63;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
-      if constexpr (MX) {
+      if constexpr (MX && KS == 1) {
         const int rem = len - 32 * t;
         const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
         const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
@@ -284,6 +284,15 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
           acc[4 * g] += o[0]; acc[4 * g + 1] += o[1]; acc[4 * g + 2] += o[2]; acc[4 * g + 3] += o[3];
         }
         ss += xss[(1 - wv) * 32 + r];
+      }
+      if constexpr (MX) {  // KS == 2: both waves now hold the full dot tile; wave 0 keeps the running maximum
+        if (wv == 0) {
+          const int rem = len - 32 * t;
+          const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+          const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+          mx_block(mrun, acc, ex, va, fill, h);
+        }
+        continue;
       }
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
       float rdr[16];
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, mrun[i]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float s = wave_sum((qvalid && h == 0) ? mx : 0.0f);
-      if (lane == 0) a.out[pair] = s;
+      if (lane == 0 && wv == 0) a.out[pair] = s;
       continue;
     }
     float pk[kMaxK];
@@ -357,10 +366,18 @@ static int launch128(const KpArgs& a, const dim3 grid, int lds, hipStream_t stre
   return check_launch("kernel_pool_split128_kernel");
 }
 
-// fp32 MaxSim (ColBERT with use_fp16 = False, colbert.py:68-75) on the same stream: E = 64n <= 384, Q <= 32
+// fp32 MaxSim (ColBERT with use_fp16 = False, colbert.py:68-75) on the same stream: E = 64n <= 384 (one wave) or 512 / 768 (two waves), Q <= 32
 bool kp128_maxsim_supported(int Q, int E) {
   const int nsl = E / 64;
-  return Q <= 32 && E % 64 == 0 && (nsl == 1 || nsl == 2 || nsl == 3 || nsl == 4 || nsl == 6);
+  return Q <= 32 && E % 64 == 0 && (nsl == 1 || nsl == 2 || nsl == 3 || nsl == 4 || nsl == 6 || nsl == 8 || nsl == 12);
+}
+
+template <int NSL, int KS>
+static void launch_mx(const KpArgs& a, const dim3 grid, int lds, hipStream_t stream) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<NSL, 11, false, KS, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, KS, true>), grid, dim3(64 * KS), lds, stream, a);
 }
 
 int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask dm, float* out, int64_t n_pairs,
@@ -368,24 +385,24 @@ int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask d
   KpArgs a{};
   a.q = q; a.d = d; a.qm = qm; a.dm = dm; a.out = out; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
   a.Q = Q; a.D = D; a.E = E; a.d_doc_rows = D; a.clamp_min = 1e-10f;
-  if (n_pairs > 0x7fffffffLL * 64) return set_error(MM_EUNSUPPORTED, "maxsim: too many pairs for one launch");
-  const int lds = kp128_lds_fixed(1);
-  int64_t groups = (int64_t)kCUs * 4;
+  const int nsl = E / 64;
+  const int ks = nsl > 6 ? 2 : 1;  // 512 / 768: two waves split the K axis (the query tile does not fit one wave)
+  const int lds = kp128_lds_fixed(ks);
+  int64_t groups = (int64_t)kCUs * 4 / ks;
   if (groups > a.n_pairs) groups = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
   groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
   const dim3 grid((unsigned)groups);
-#define MM_MX(NSL) \
-  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, 1, true>), grid, dim3(64), lds, stream, a); break
-  switch (a.E / 64) {
-    case 1: MM_MX(1);
-    case 2: MM_MX(2);
-    case 3: MM_MX(3);
-    case 4: MM_MX(4);
-    case 6: MM_MX(6);
+  switch (nsl) {
+    case 1: launch_mx<1, 1>(a, grid, lds, stream); break;
+    case 2: launch_mx<2, 1>(a, grid, lds, stream); break;
+    case 3: launch_mx<3, 1>(a, grid, lds, stream); break;
+    case 4: launch_mx<4, 1>(a, grid, lds, stream); break;
+    case 6: launch_mx<6, 1>(a, grid, lds, stream); break;
+    case 8: launch_mx<4, 2>(a, grid, lds, stream); break;
+    case 12: launch_mx<6, 2>(a, grid, lds, stream); break;
     default: return set_error(MM_EUNSUPPORTED, "maxsim: E=%d has no fp32 streaming kernel", a.E);
   }
-#undef MM_MX
   return check_launch("kernel_pool_split128_kernel<maxsim>");
 }
 

@@ -67,7 +67,7 @@ int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int3
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
                       const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream);
 
-// kernel_pool128.hip: fp32 MaxSim on the split-bf16 streaming kernel (E = 64n <= 384, Q <= 32), called from maxsim.hip
+// kernel_pool128.hip: fp32 MaxSim on the split-bf16 streaming kernel (E = 64n <= 384, 512, 768; Q <= 32), called from maxsim.hip
 bool kp128_maxsim_supported(int Q, int E);
 int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask dm, float* out, int64_t n_pairs,
                      int64_t pairs_per_query, int Q, int D, int E, hipStream_t stream);

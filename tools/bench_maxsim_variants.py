@@ -66,3 +66,8 @@ if "inbatch" in which:
     qb, db = q[:32].contiguous(), d[:32].contiguous()
     qm = torch.ones(32, Q, dtype=torch.int64, device=dev); dm = torch.ones(32, D, dtype=torch.int64, device=dev)
     report("all-pairs 32x32 (dynamic teacher shape)", timeit(lambda: ops.maxsim_inbatch(qb, qm, db, dm, True)), 1024, 32 * D * E * 2)
+if "fp32e768" in which:
+    n = (nq // 8) * C
+    q7 = torch.randn(max(nq // 8, 1), Q, 768, device=dev)
+    d7 = torch.randn(n, D, 768, device=dev)
+    report("fp32 E=768 (two-wave split-bf16 streaming kernel)", timeit(lambda: ops.maxsim(q7, d7, None, None, C)), n, n * D * 768 * 4)
