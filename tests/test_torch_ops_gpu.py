@@ -118,3 +118,47 @@ def test_operators_are_reentrant_across_threads_and_streams():
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
+
+
+def test_operators_are_graph_capturable():
+    """Fixed-shape re-ranking loops are launch-bound at small batches (TKL's scoring alone is seven launches): the
+    operators neither synchronise nor touch the host, so a scoring step can be captured in a HIP graph
+    (torch.cuda.graph) and replayed on new data in the same buffers.  (TKL's chunk PACKING is data dependent —
+    `nonzero`, as in the reference — so the graph starts at the packed chunks.)"""
+    from matchmaker_amd.tkl import chunk_documents
+    from tests.test_tkl_gpu import make_model
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(9)
+    q = torch.randn(4, 32, 128, generator=gen).to(dev).to(torch.bfloat16)
+    d = torch.randn(4 * 25, 180, 128, generator=gen).to(dev).to(torch.bfloat16)
+    d_len = torch.randint(1, 181, (100,), generator=gen).to(torch.int32).to(dev)
+    qf, df = torch.randn(6, 20, 300, generator=gen).to(dev), torch.randn(6, 200, 300, generator=gen).to(dev)
+    dm = (torch.arange(200)[None] < torch.randint(1, 201, (6,), generator=gen)[:, None]).float().to(dev)
+    prm = [torch.tensor(MU).to(dev), torch.full((11,), 0.1).to(dev), torch.ones(11).to(dev), torch.randn(11, generator=gen).to(dev)]
+    torch.manual_seed(5)
+    tkl = make_model(64, "embedding", dev)
+    ql, dl = torch.randn(3, 12, 64, device=dev), torch.randn(3, 500, 64, device=dev)
+    qml = torch.ones(3, 12, device=dev)
+    dml = (torch.arange(500, device=dev)[None] < torch.tensor([500, 77, 300], device=dev)[:, None]).float()
+    chunks, cmask, slot, C = chunk_documents(dl, dml)
+    params = tkl.pack_params()
+
+    def step():
+        with torch.no_grad():
+            return (ops.maxsim(q, d, None, d_len, pairs_per_query=25), ops.kernel_pool(qf, df, None, dm, *prm),
+                    ops.tkl_score(ql, chunks, cmask, slot, qml, params, 3, C, 11, "embedding"))
+
+    step()                                               # warm-up outside the capture (lazy library / attribute state)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step()
+    # new contents in the captured input buffers
+    d.copy_(torch.randn(100, 180, 128, generator=gen).to(dev).to(torch.bfloat16))
+    df.copy_(torch.randn(6, 200, 300, generator=gen).to(dev))
+    chunks.copy_(torch.randn(chunks.shape, generator=gen).to(dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    want = step()
+    for got, ref in zip(outs, want):
+        assert torch.equal(got, ref)
