@@ -593,8 +593,9 @@ __device__ __forceinline__ void sload4_u32(const void* base, int64_t idx, uint32
 // Epilogue of block t of a run: pairs of virtual rows (i0, i0 + 1), i0 = 32t + rowof(2ip) + 4h, belong
 // to chunk i0 / 40, pair (i0 % 40) / 2.  rows_blk = rows of this block that exist (multiple of 8).
 template <int K>
-__device__ __forceinline__ void tkl_block_run(float* ps_run, int Q, int t, int rows_blk, int r, int h, const f32x16& acc,
-                                              const float (&rdr)[16], float rq, uint32_t vbits, const Rbf& rbf) {
+__device__ __forceinline__ void tkl_block_run(float* ps_run, int Q, int qlim, int t, int rows_blk, int r, int h,
+                                              const f32x16& acc, const float (&rdr)[16], float rq, uint32_t vbits,
+                                              const Rbf& rbf) {
   constexpr int KC = K + 1;
   constexpr int KP = (K + 1) / 2;
   static_assert(KC % 4 == 0 && K % 2 == 1, "K kernels + the count channel must fill whole float4s");
@@ -625,7 +626,7 @@ __device__ __forceinline__ void tkl_block_run(float* ps_run, int Q, int t, int r
       const int i0 = 32 * t + rowof(2 * ip) + 4 * h;
       const int ci = (i0 * 205) >> 13;  // i0 / 40 for i0 < 400
       const int u = (i0 - 40 * ci) >> 1;
-      if (r < Q) {
+      if (r < qlim) {  // query tokens past the query's effective length are masked in stage 2 (:248): never written, never read
         f32x4* dst = (f32x4*)(ps_run + (int64_t)ci * (20 * Q * KC) + ((int64_t)u * Q + r) * KC);
 #pragma unroll
         for (int v = 0; v < KC / 4 - 1; ++v) dst[v] = f32x4{o2[2 * v][0], o2[2 * v][1], o2[2 * v + 1][0], o2[2 * v + 1][1]};
@@ -722,6 +723,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
   bf16x8 qhi[NS][kSplitSteps], qlo[NS][kSplitSteps], qhiL, qloL;
   float rq = 0.0f;
   int64_t cur_q = -1;
+  int qlim = Q;  // effective length of the current query (a.qm.len, when the caller resolved the query mask)
 
   for (int64_t pair = p0; pair < p1;) {
     const int crun = run_len(pair);
@@ -748,6 +750,10 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       split8(park[0], park[1], qhiL, qloL);
       ss += __shfl_xor(ss, 32, 64);
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
+      if (a.qm.len) {
+        const int ql = (int)sload_u32(a.qm.len, qi);
+        qlim = ql < 0 ? 0 : (ql > Q ? Q : ql);
+      }
     }
     float* ps_run = a.ps_out + pair * (20 * (int64_t)Q * (K + 1));
 
@@ -833,7 +839,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       }
       const int rows_blk = 40 * crun - i0 < 32 ? 40 * crun - i0 : 32;
       if (rows_blk < 32) va &= (1u << rows_blk) - 1u;
-      tkl_block_run<K>(ps_run, Q, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+      tkl_block_run<K>(ps_run, Q, qlim, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
     }
     pair += crun;
   }
@@ -1379,10 +1385,12 @@ bool tkl_stage1_writes_all_pairs(int Q, int E) {
 }
 
 // TKL stage 1 entry (called from tkl.hip): chunks [P,50,E] -> ps_out [P,20,Q,12]
-int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
-                      const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream) {
+int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* q_len,
+                      const int32_t* chunk_slot, int C, const float* mu, const float* sigma, float* ps_out, int64_t P,
+                      int Q, int E, hipStream_t stream) {
   KpArgs a{};
   a.q = q_ctx; a.d = chunks; a.dm = dm; a.mu = mu; a.sigma = sigma; a.alpha = nullptr; a.w = nullptr;
+  a.qm.len = q_len;  // effective query lengths [B] (may be null): pair rows of later tokens are not written
   a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;
   a.d_doc_rows = 50; a.d_row0 = 5; a.chunk_slot = chunk_slot; a.C = C; a.ps_out = ps_out;
   static int force_generic = -1;

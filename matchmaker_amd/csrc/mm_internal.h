@@ -64,8 +64,9 @@ bool tkl_fused_supported(int C, int Q, int E);
 int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* slot2p, const float* q_mask,
               const float* prm, const float* emb, float* win, int64_t B, int C, int Q, int E, int W, int saturation,
               hipStream_t stream);
-int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* chunk_slot, int C,
-                      const float* mu, const float* sigma, float* ps_out, int64_t P, int Q, int E, hipStream_t stream);
+int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* q_len,
+                      const int32_t* chunk_slot, int C, const float* mu, const float* sigma, float* ps_out, int64_t P,
+                      int Q, int E, hipStream_t stream);
 
 // kernel_pool128.hip: fp32 MaxSim on the split-bf16 streaming kernel (E = 64n <= 384, 512, 768; Q <= 32), called from maxsim.hip
 bool kp128_maxsim_supported(int Q, int E);

@@ -58,6 +58,7 @@ template <int SAT>
 __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
                                                          const float* __restrict__ emb_g,
                                                          const float* __restrict__ q_mask,
+                                                         const int32_t* __restrict__ q_len,
                                                          const float* __restrict__ prm, float* __restrict__ win,
                                                          int C, int Q, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,6 +73,8 @@ __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __re
   __shared__ int cinfo[8];                            // slot2p entries of the (<= 4) chunks this tile touches
 
   // the chunk lookups first, once per tile, so that the row loads below are independent of each other
+  int ql = q_len ? q_len[b] : Q;                      // effective query length (rows of later tokens do not exist)
+  ql = ql < 0 ? 0 : (ql > Q ? Q : ql);
   const int c0 = w0 / kU;
   if (tid < 8) {
     const int c = c0 + tid;
@@ -100,7 +103,8 @@ __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __re
         const int c = ug / kU, uu = ug - c * kU;
         off[s] = uu * rowf + v * 4;
         const int info = cinfo[c - c0];                                // c - c0 <= (19 + nu) / 20 < 8
-        if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;    // rows of unwritten blocks are zeros
+        // rows of unwritten blocks and of query tokens past the effective length are zeros
+        if (info >= 0 && uu < 16 * (info & 3) && v < 3 * ql) pidx[s] = info >> 2;
       }
     }
     f32x4 val[kStage];
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __re
   __syncthreads();
   if (tid < kWT && w0 + tid < W) {                                     // :249 sum over query tokens, :251 dense
     float s = 0.0f;
-    for (int i = 0; i < Q; ++i) s += red[tid * Q + i];
+    for (int i = 0; i < ql; ++i) s += red[tid * Q + i];
     win[(int64_t)b * W + w0 + tid] = s;
   }
 }
@@ -284,7 +288,8 @@ extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int
   if (B <= 0 || P < 0 || C <= 0 || Q <= 0 || K != kK) return 0;
   const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
   return align256((size_t)B * C * 4) + align256((size_t)P * kU * Q * kKC * 4) +
-         packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4);
+         packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4) +
+         packed_mask_bytes(MM_MASK_F32, B, Q);  // + the packed query mask (effective lengths)
 }
 
 extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
@@ -322,6 +327,14 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
                        emb, B * (int64_t)Q, E);
     if (int e = check_launch("tkl_emb_kernel")) return e;
   }
+  // effective query lengths (last real token + 1): query tokens past them are masked in :248, so stage 1 does not
+  // write their pair rows and stage 2 does not read or evaluate them
+  PackedMask qmk;
+  {
+    char* qws = (char*)emb + align256((size_t)B * Q * 4);
+    size_t qleft = packed_mask_bytes(MM_MASK_F32, B, Q);
+    if (int e = resolve_mask(q_mask, MM_MASK_F32, B, Q, &qws, &qleft, stream, &qmk)) return e;
+  }
   // Stages 1 + 2 fused per document (pair sums stay in LDS) when the shape fits; otherwise stage 1 writes the
   // pair sums to the workspace and the window kernel reads them back.
   const bool fused = tkl_fused_supported(C, Q, E);
@@ -333,7 +346,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
                        B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, slot2p);
     if (int e = check_launch("tkl_slot_map_kernel")) return e;
     if (!fused) {
-      if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, chunk_slot, C,
+      if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, qmk.len, chunk_slot, C,
                                     params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
         return e;
     }
@@ -351,12 +364,12 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
-                         emb, q_mask, params, win, C, Q, W);
+                         emb, q_mask, qmk.len, params, win, C, Q, W);
     } else {
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
-                         emb, q_mask, params, win, C, Q, W);
+                         emb, q_mask, qmk.len, params, win, C, Q, W);
     }
     if (int e = check_launch("tkl_window_kernel")) return e;
   }
