@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
         pk[k] = pk2[k >> 1][k & 1];
         pk[k] += __shfl_xor(pk[k], 32, 64);
       }
-      finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+      finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
     }
   }
 }
@@ -413,6 +413,8 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
   bf16x8 qhi[NS][kSplitSteps], qlo[NS][kSplitSteps], qhiL, qloL;
   float rq = 0.0f;
   bool qvalid = false;
+  uint32_t qbits = 0xffffffffu;
+  int qn = Q, np = 2;  // effective query length; lanes sharing one query token in the epilogue (2 = the MFMA layout)
   int64_t cur_q = -1;
   int64_t qi = TKL ? 0 : p0 / a.ppq;
   int64_t q_left = TKL ? 0 : a.ppq - (p0 - qi * a.ppq);
@@ -452,7 +454,11 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
       const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
       qvalid = r < Q && r < qlen;
-      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+      qbits = a.qm.bits ? sload_u32(a.qm.bits, qi) : 0xffffffffu;
+      if (a.qm.bits) qvalid = qvalid && ((qbits >> r) & 1u);
+      // short queries: share each query token's epilogue between np = 4 .. 32 lanes (see rbf_redistributed)
+      qn = qlen < Q ? (qlen < 0 ? 0 : qlen) : Q;
+      np = TKL ? 2 : (qn == 0 || qn > 16) ? 2 : (qn > 8 ? 4 : (qn > 4 ? 8 : (qn > 2 ? 16 : 32)));
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
@@ -543,6 +549,19 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
       const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
       if constexpr (TKL) {
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+      } else if (np > 2) {
+        // transpose the scaled tile through the ring slot just consumed (free until the next top_up()):
+        // T[query token][32 rows]; then np lanes per token evaluate 32 / np rows each
+        float* T = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(T + r * 32 + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
+                                                       (acc[4 * g + 2] * rq) * rdr[4 * g + 2], (acc[4 * g + 3] * rq) * rdr[4 * g + 3]};
+        const float* lwrow = W ? wbuf + 32 * t : nullptr;
+        if (np == 4) rbf_redistributed<K, W, 8>(pk2, T, lwrow, lane, va, rbf);
+        else if (np == 8) rbf_redistributed<K, W, 4>(pk2, T, lwrow, lane, va, rbf);
+        else if (np == 16) rbf_redistributed<K, W, 2>(pk2, T, lwrow, lane, va, rbf);
+        else rbf_redistributed<K, W, 1>(pk2, T, lwrow, lane, va, rbf);
       } else if constexpr (W) {
         float lw[16];
 #pragma unroll
@@ -557,12 +576,24 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
     }
     if (!TKL) {
       float pk[kMaxK];
+      if (np > 2) {  // np consecutive lanes hold the partial sums of one query token
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        pk[k] = pk2[k >> 1][k & 1];
-        pk[k] += __shfl_xor(pk[k], 32, 64);
+        for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
+        for (int o = np >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+          for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], o, 64);
+        }
+        const int tk = lane / np;
+        const bool count = (lane & (np - 1)) == 0 && tk < qn && ((qbits >> tk) & 1u);
+        finish_pool<K>(a, pair, pk, count, lane, rbf);
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          pk[k] = pk2[k >> 1][k & 1];
+          pk[k] += __shfl_xor(pk[k], 32, 64);
+        }
+        finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
       }
-      finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
     }
   }
 }

@@ -336,12 +336,12 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       pk[k] += __shfl_xor(pk[k], 32, 64);
     }
     if constexpr (KS == 1) {
-      finish_pool<K>(a, pair, pk, qvalid, lane, rbf);
+      finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
     } else {
       static_assert(K > 6, "wave 1 pools kernels 6..K-1");
       // each wave pools the kernels it evaluated; wave 1 hands its weighted partial to wave 0
-      const float part = wv == 0 ? pool_partial<K, 0, 6>(a, pair, pk, qvalid, lane, rbf)
-                                 : pool_partial<K, 6, K>(a, pair, pk, qvalid, lane, rbf);
+      const float part = wv == 0 ? pool_partial<K, 0, 6>(a, pair, pk, qvalid && lane < 32, lane, rbf)
+                                 : pool_partial<K, 6, K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
       if (wv == 1 && lane == 0) xtot[p_toggle * 4] = part;
       __syncthreads();
       if (wv == 0 && lane == 0) a.out[pair] = part + xtot[p_toggle * 4];

@@ -146,17 +146,72 @@ __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16&
 // log2 of a TK-Sparse gate (a ReLU output, so >= 0; anything below 0 is treated as 0)
 __device__ __forceinline__ float gate_log2(float g) { return __builtin_amdgcn_logf(fmaxf(g, 0.0f)); }
 
+// The same epilogue on a REDISTRIBUTED tile: this lane evaluates ROWS consecutive document rows of ONE query token
+// (c[j]: scaled cosines; bit j of `bits`: row j is a real token; lw: log2 gates of those rows when W).
+// Used when the query is short: a Q-token tile keeps only Q of 32 lanes busy in rbf_block, so the tile is
+// transposed through LDS and NP = 32 / ROWS lanes share each query token.
+template <int K, bool W, int ROWS>
+__device__ __forceinline__ void rbf_rows(f32x2 (&pk2)[kMaxK / 2], const float (&c)[ROWS], uint32_t bits, const Rbf& rbf,
+                                         const float (&lw)[ROWS]) {
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) {
+    const float cj = ((bits >> j) & 1u) ? c[j] : 1.0e5f;
+    const f32x2 cc = {cj, cj};
+    const f32x2 lwv = W ? f32x2{lw[j], lw[j]} : f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int kp = 0; kp < (K + 1) / 2; ++kp) {
+      const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+      const f32x2 av = W ? lwv - sv * sv : -(sv * sv);
+      const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+      pk2[kp] += e;
+    }
+  }
+}
+
+// read this lane's ROWS values of the transposed tile T[token][32 rows] (and of the gate vector) and evaluate them
+template <int K, bool W, int ROWS>
+__device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow, int lane,
+                                                  uint32_t va, const Rbf& rbf) {
+  constexpr int NP = 32 / ROWS;                 // lanes per query token
+  const int t = lane / NP, s = lane % NP;       // token, row group
+  const float* src = T + t * 32 + s * ROWS;
+  float c[ROWS], lw[ROWS];
+  if constexpr (ROWS >= 4) {
+#pragma unroll
+    for (int v = 0; v < ROWS / 4; ++v) {
+      const f32x4 x = *(const f32x4*)(src + 4 * v);
+      c[4 * v] = x[0]; c[4 * v + 1] = x[1]; c[4 * v + 2] = x[2]; c[4 * v + 3] = x[3];
+      if (W) {
+        const f32x4 y = *(const f32x4*)(lwrow + s * ROWS + 4 * v);
+        lw[4 * v] = y[0]; lw[4 * v + 1] = y[1]; lw[4 * v + 2] = y[2]; lw[4 * v + 3] = y[3];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+      c[j] = src[j];
+      if (W) lw[j] = lwrow[s * ROWS + j];
+    }
+  }
+  if (!W) {
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) lw[j] = 0.0f;
+  }
+  const uint32_t bits = (va >> (s * ROWS)) & ((ROWS == 32) ? 0xffffffffu : ((1u << ROWS) - 1u));
+  rbf_rows<K, W, ROWS>(pk2, c, bits, rbf, lw);
+}
+
 
 // log-sum pooling of one pair over kernels K0..K1-1: pk[k] (this lane's query token, both halves already
 // combined); writes per_kernel, returns sum_k w_k * pooled_k (wave-uniform).
 template <int K, int K0 = 0, int K1 = K>
-__device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
+__device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool count_lane,
                                               int lane, const Rbf& rbf) {
   float total = 0.0f;
 #pragma unroll
   for (int k = K0; k < K1; ++k) {
     float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
-    lg = (qvalid && lane < 32) ? lg : 0.0f;  // both halves hold the combined sums: count one
+    lg = count_lane ? lg : 0.0f;  // exactly one lane per real query token counts (the others hold copies)
     const float s = wave_sum(lg);
     if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
     total += rbf.w[k] * s;
@@ -165,9 +220,9 @@ __device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, con
 }
 
 template <int K>
-__device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool qvalid,
+__device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool count_lane,
                                             int lane, const Rbf& rbf) {
-  const float total = pool_partial<K>(a, pair, pk, qvalid, lane, rbf);
+  const float total = pool_partial<K>(a, pair, pk, count_lane, lane, rbf);
   if (lane == 0) a.out[pair] = total;
 }
 
