@@ -203,3 +203,34 @@ def test_conv_knrm_dropin_matches_reference_golden():
     assert m.dense.weight.grad is not None and float(m.dense.weight.grad.abs().sum()) > 0
     assert all(c[1].weight.grad is not None and torch.isfinite(c[1].weight.grad).all() for c in m.convolutions)
     np.testing.assert_allclose(out.detach().cpu().numpy(), g["score"], atol=5e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("qlen", [1, 2, 3, 4, 5, 8, 9, 16, 17, 20])
+@pytest.mark.parametrize("E,gated", [(300, False), (100, True)])
+def test_short_queries_take_the_redistributed_epilogue(qlen, E, gated):
+    """Effective query lengths on both sides of every lanes-per-token switch (2 / 4 / 8 / 16 / 32), a hole inside
+    the query, prefix-masked and hole-masked documents, with and without the TK-Sparse gate."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(100 * qlen + E)
+    nq, C, Q, D = 3, 5, 20, 130
+    B = nq * C
+    q = torch.randn(nq, Q, E, generator=gen)
+    d = torch.randn(B, D, E, generator=gen)
+    d[0, 3] = q[0, 0]
+    qm = (torch.arange(Q)[None] < torch.tensor([qlen, max(1, qlen - 1), Q])[:, None]).float()
+    if qlen > 2:
+        qm[0, 1] = 0.0                                     # a hole: effective length stays qlen
+    dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (B,), generator=gen)[:, None]).float()
+    dm[1, ::3] = 0.0
+    gate = torch.relu(torch.randn(B, D, generator=gen)) if gated else None
+    alpha, w = torch.rand(11, generator=gen) + 0.5, torch.randn(11, generator=gen) * 0.3
+    t = lambda x: None if x is None else x.to(dev)
+    s, pk = ops.kernel_pool(t(q), t(d), t(qm), t(dm), t(torch.tensor(MU)), t(torch.tensor(SIGMA)), t(alpha), t(w),
+                            pairs_per_query=C, return_per_kernel=True, d_gate=t(gate))
+    qi = np.arange(B) // C
+    eff = dm.numpy() * (gate.numpy() if gated else 1.0)
+    ref, ref_pk = O.tk_kernel_pool(q.numpy()[qi], d.numpy(), qm.numpy()[qi], eff, MU, SIGMA, alpha.numpy(), w.numpy(),
+                                   dtype=np.float64, return_per_kernel=True)
+    np.testing.assert_allclose(pk.cpu().numpy(), ref_pk, atol=5e-3, rtol=1e-4)
+    np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
