@@ -158,6 +158,8 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
   bf16x8 qhi[NSL][kS128Steps], qlo[NSL][kS128Steps];
   float rq = 0.0f;
   bool qvalid = false;
+  uint32_t qbits = 0xffffffffu;
+  int qn = Q, np = 2;  // effective query length; lanes sharing one query token in the epilogue (kernel_pool.hip, 3.3)
   int64_t cur_q = -1;
   int64_t qi = p0 / a.ppq;
   int64_t q_left = a.ppq - (p0 - qi * a.ppq);
@@ -197,7 +199,11 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
       const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
       qvalid = r < Q && r < qlen;
-      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+      qbits = a.qm.bits ? sload_u32(a.qm.bits, qi) : 0xffffffffu;
+      if (a.qm.bits) qvalid = qvalid && ((qbits >> r) & 1u);
+      qn = qlen < Q ? (qlen < 0 ? 0 : qlen) : Q;
+      constexpr bool kRedist = KS == 1 && !MX && !(W && NSL == 6);  // (gated E = 384 would spill registers)
+      np = (!kRedist || qn == 0 || qn > 16) ? 2 : (qn > 8 ? 4 : (qn > 4 ? 8 : (qn > 2 ? 16 : 32)));
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
@@ -304,7 +310,20 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
-      if constexpr (W) {
+      if (KS == 1 && np > 2) {
+        // short query: transpose the scaled tile through the ring slot just consumed (free until the next top_up())
+        // and let np lanes share each query token (kp_device.h rbf_redistributed)
+        float* T = (float*)(ring + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kS128Bytes);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4*)(T + r * 32 + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
+                                                       (acc[4 * g + 2] * rq) * rdr[4 * g + 2], (acc[4 * g + 3] * rq) * rdr[4 * g + 3]};
+        const float* lwrow = W ? wbuf + 32 * t : nullptr;
+        if (np == 4) rbf_redistributed<K, W, 8>(pk2, T, lwrow, lane, va, rbf);
+        else if (np == 8) rbf_redistributed<K, W, 4>(pk2, T, lwrow, lane, va, rbf);
+        else if (np == 16) rbf_redistributed<K, W, 2>(pk2, T, lwrow, lane, va, rbf);
+        else rbf_redistributed<K, W, 1>(pk2, T, lwrow, lane, va, rbf);
+      } else if constexpr (W) {
         float lw[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -330,6 +349,17 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       continue;
     }
     float pk[kMaxK];
+    if (KS == 1 && np > 2) {  // np consecutive lanes hold the partial sums of one query token
+#pragma unroll
+      for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
+      for (int o = np >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], o, 64);
+      }
+      const int tk = lane / np;
+      finish_pool<K>(a, pair, pk, (lane & (np - 1)) == 0 && tk < qn && ((qbits >> tk) & 1u), lane, rbf);
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       pk[k] = pk2[k >> 1][k & 1];
