@@ -270,3 +270,31 @@ def test_from_config_on_the_reference_yaml_files_builds_the_same_parameters(mode
     assert shapes(ref) == shapes(mine)
     assert {k for k, _ in ref.named_parameters()} == {k for k, _ in mine.named_parameters()}
     mine.load_state_dict(ref.state_dict(), strict=True)
+
+
+@pytest.mark.skipif(not R.available(), reason="needs the reference tree")
+def test_patch_matchmaker_rebinds_the_model_classes():
+    from matchmaker_amd import patch
+    R.install_shims()
+    import importlib
+    saved = {}
+    for ref_mod, ref_attr, _, _ in patch._TABLE:
+        try:
+            saved[(ref_mod, ref_attr)] = getattr(importlib.import_module(ref_mod), ref_attr)
+        except Exception:
+            pass
+    try:
+        done = patch.patch_matchmaker()
+        assert "matchmaker.models.published.ecai20_tk.ECAI20_TK" in done and "matchmaker.models.colbert.ColBERT" in done
+        import matchmaker.models.published.ecai20_tk as ref_tk
+        import matchmaker.models.published.sigir20_tkl as ref_tkl
+        from matchmaker_amd.tk import ECAI20_TK
+        from matchmaker_amd.tkl import TKL_sigir20
+        assert ref_tk.ECAI20_TK is ECAI20_TK and ref_tkl.TKL_sigir20 is TKL_sigir20
+        m = ref_tk.ECAI20_TK.from_config({"tk_kernels_mu": MU, "tk_kernels_sigma": SIGMA, "tk_att_heads": 10, "tk_att_layer": 2,
+                                          "tk_att_ff_dim": 100, "max_doc_length": 200, "tk_use_diff_posencoding": True,
+                                          "tk_mix_hybrid_context": True}, 300)
+        assert type(m).__module__ == "matchmaker_amd.tk"
+    finally:                                             # other tests drive the real classes
+        for (ref_mod, ref_attr), obj in saved.items():
+            setattr(importlib.import_module(ref_mod), ref_attr, obj)
