@@ -78,3 +78,52 @@ def test_dot_topk_one_rank_shard_of_config5():
     rows = idx[sel]
     chk = torch.stack([(c[rows[r]].float() @ q[sel[r]].float()) for r in range(sel.numel())])
     np.testing.assert_allclose(s[sel].cpu().numpy(), chk.cpu().numpy(), atol=2e-3, rtol=1e-3)
+
+
+def test_fp32_maxsim_config2_variant_full_size():
+    """The fp32 variant of configs[1] (64 queries x 1000 candidates, Q32/D180/E128) on the split-bf16 streaming
+    kernel: determinism, permutation equivariance, power-of-two linearity, whole queries against the oracle."""
+    from matchmaker_amd import ops, synth
+    dev = util.require_gpu()
+    nq, C = 64, 1000
+    q, d, q_len, d_len = synth.colbert_batch(nq, C, dtype=torch.float32, device=dev, lengths="msmarco", seed=77)
+    out = ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)
+    assert torch.equal(out, ops.maxsim(q, d, q_len, d_len, pairs_per_query=C))
+    perm = torch.stack([torch.randperm(C, device=dev) + i * C for i in range(nq)]).reshape(-1)
+    assert torch.equal(ops.maxsim(q, d[perm].contiguous(), q_len, d_len[perm].contiguous(), pairs_per_query=C), out[perm])
+    assert torch.equal(ops.maxsim(q * 4.0, d, q_len, d_len, pairs_per_query=C), out * 4.0)
+    for i in (0, 31, 63):
+        dn = d[i * C:(i + 1) * C].cpu().numpy()
+        dm = synth.len_to_mask(d_len[i * C:(i + 1) * C], 180).cpu().numpy()
+        qm = np.repeat(synth.len_to_mask(q_len[i:i + 1], 32).cpu().numpy(), C, 0)
+        ref = O.maxsim_paired(np.repeat(q[i:i + 1].cpu().numpy(), C, 0), dn, qm, dm, dtype=np.float64)
+        np.testing.assert_allclose(out[i * C:(i + 1) * C].cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-6)
+
+
+def test_idcm_sampler_shape_full_size():
+    """IDCM's default sampler shape at scale: 2,000 documents x (up to) 41 passages of 64 tokens, 768-wide vectors,
+    one query row per document (pair_query), floor 1e-4 — determinism, invariance to a power-of-two rescaling of
+    the vectors (cosines are scale free), sampled passages against the oracle."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator(device=dev).manual_seed(88)
+    B, Q, D, E = 2000, 30, 64, 768
+    n_pass = torch.randint(1, 42, (B,), generator=g, device=dev)
+    pq = torch.repeat_interleave(torch.arange(B, device=dev), n_pass)
+    P = int(pq.numel())
+    q = torch.relu(torch.randn(B, Q, E, generator=g, device=dev))
+    d = torch.relu(torch.randn(P, D, E, generator=g, device=dev))
+    qm = (torch.arange(Q, device=dev)[None] < torch.randint(2, 13, (B,), generator=g, device=dev)[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < torch.randint(8, D + 1, (P,), generator=g, device=dev)[:, None]).float()
+    prm = [torch.tensor([1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9], device=dev), torch.full((11,), 0.1, device=dev),
+           torch.rand(11, generator=g, device=dev) + 0.5, torch.randn(11, generator=g, device=dev)]
+    s = ops.kernel_pool(q, d, qm, dm, *prm, clamp_min=1e-4, pair_query=pq)
+    assert s.shape == (P,) and torch.isfinite(s).all()
+    assert torch.equal(s, ops.kernel_pool(q, d, qm, dm, *prm, clamp_min=1e-4, pair_query=pq))
+    s2 = ops.kernel_pool(q * 2.0, d * 0.5, qm, dm, *prm, clamp_min=1e-4, pair_query=pq)
+    torch.testing.assert_close(s2, s, rtol=0, atol=1e-4)
+    sel = torch.tensor([0, P // 3, P - 1], device=dev)
+    ref = O.idcm_sampler_scores(q[pq[sel]].cpu().numpy(), d[sel].cpu().numpy(), qm[pq[sel]].cpu().numpy(), dm[sel].cpu().numpy(),
+                                prm[0].cpu().numpy(), prm[1].cpu().numpy(), prm[2].cpu().numpy(), prm[3].cpu().numpy(), 0.0,
+                                dtype=np.float64)
+    np.testing.assert_allclose(s[sel].cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
