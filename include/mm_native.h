@@ -167,7 +167,9 @@ int mm_kernel_pool_fwd(const void* q, const void* d,
  *              different number of passages per document against the document's query (the reference
  *              materialises one query copy per passage, sigir21_idcm.py:143-144).  With it q / q_mask have
  *              n_queries rows and pairs_per_query is ignored; NULL = the uniform pairs_per_query layout.
- *              Consecutive equal entries reuse the query tile already in registers.
+ *              Consecutive equal entries reuse the query tile already in registers.  The workspace then packs
+ *              n_queries query-mask rows: size it with
+ *              mm_kernel_pool_workspace_bytes(max(n_pairs, n_queries), 1, Q, D, kinds).
  * Everything else as mm_kernel_pool_fwd (which calls this with NULL, NULL, 0, ..., 1e-10). */
 int mm_kernel_pool_ex_fwd(const void* q, const void* d,
                           const void* q_mask, int q_mask_kind,
