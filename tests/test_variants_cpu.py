@@ -193,3 +193,34 @@ def test_idcm_dropin_equals_the_live_reference_class_for_every_sampler(monkeypat
     np.testing.assert_allclose(got[2]["sampling_scores"].numpy(), want[2]["sampling_scores"].numpy(), atol=1e-4, rtol=1e-5)
     np.testing.assert_allclose(got[1].numpy(), want[1].numpy(), atol=1e-5)
     np.testing.assert_allclose(got[0].numpy(), want[0].numpy(), atol=1e-5)
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_harness", fromlist=["available"]).available(),
+                    reason="live comparison with the real class needs the reference tree")
+def test_idcm_without_sampling_equals_the_live_reference_class():
+    """idcm.yaml's default is idcm_sample_n: -1 — no passage selection, BERT reads every packed passage
+    (sigir21_idcm.py:209-252); the branch never touches the native operator, so it runs on the CPU as is."""
+    from oracle import ref_harness as R
+    from matchmaker_amd import idcm
+    ref = R.make_idcm(_tiny_distilbert(), sample_n=-1, sample_context="ck", top_k_chunks=3, seed=6)
+    mine = idcm.IDCM(_tiny_distilbert(), sample_n=-1, sample_context="ck", top_k_chunks=3, chunk_size=50, overlap=7,
+                     padding_idx=0)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.eval()
+    g = torch.Generator().manual_seed(4)
+    B, LQ, LD = 3, 9, 190
+    q_mask = (torch.arange(LQ)[None] < torch.tensor([9, 4, 6])[:, None]).long()
+    d_mask = (torch.arange(LD)[None] < torch.tensor([190, 20, 101])[:, None]).long()
+    query = {"input_ids": torch.randint(1, 200, (B, LQ), generator=g) * q_mask, "attention_mask": q_mask}
+    doc = {"input_ids": torch.randint(1, 200, (B, LD), generator=g) * d_mask, "attention_mask": d_mask}
+    with torch.no_grad():
+        want, wsec = ref.forward(query, doc, use_fp16=False, output_secondary_output=True)
+        got, gsec = mine.forward(query, doc, use_fp16=False, output_secondary_output=True)
+        plain = mine.forward(query, doc, use_fp16=False)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-5)
+    np.testing.assert_allclose(gsec["bert_scores"].numpy(), wsec["bert_scores"].numpy(), atol=1e-5)
+    assert (gsec["packed_indices"] == wsec["packed_indices"]).all() and torch.equal(plain, got)
+    # training: gradients reach BERT (the grad-enabled branch of :213)
+    mine.train()
+    mine.forward(query, doc, use_fp16=False).sum().backward()
+    assert mine._classification_layer.weight.grad.abs().sum() > 0
