@@ -76,7 +76,9 @@ __device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint
   }
 }
 
-template <int NSL, int K, bool W, int KS, bool MX = false>
+// MX: 0 = kernel pooling; 1 = fp32 MaxSim with the two-term split (4 MFMAs per K step); 2 = fp32 MaxSim with the
+// three-term split x = hi + lo + c (6 MFMAs: + c.hi and hi.c; operand error 2^-25, i.e. fp32-class scores)
+template <int NSL, int K, bool W, int KS, int MX = 0>
 __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
   static_assert(!MX || !W, "the fp32 MaxSim mode has no gate");
@@ -156,6 +158,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
   top_up();
 
   bf16x8 qhi[NSL][kS128Steps], qlo[NSL][kS128Steps];
+  bf16x8 qc[MX == 2 ? NSL : 1][kS128Steps];
   float rq = 0.0f;
   bool qvalid = false;
   uint32_t qbits = 0xffffffffu;
@@ -185,7 +188,8 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
         for (int p = 0; p < kS128Steps; ++p) {
           const f32x4 x0 = *(const f32x4*)(qrow + s * 256 + p * 64);
           const f32x4 x1 = *(const f32x4*)(qrow + s * 256 + p * 64 + 16);
-          split8(x0, x1, qhi[s][p], qlo[s][p]);
+          if constexpr (MX == 2) split8x3(x0, x1, qhi[s][p], qlo[s][p], qc[s][p]);
+          else split8(x0, x1, qhi[s][p], qlo[s][p]);
           ss += sumsq4(x0) + sumsq4(x1);
         }
       }
@@ -235,17 +239,30 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
           x[2 * p + 1] = *(const f32x4*)(buf + aoff[p][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 ah, al;
-        split8(x[0], x[1], ah, al);
+        bf16x8 ah, al, ac;
+        if constexpr (MX == 2) split8x3(x[0], x[1], ah, al, ac);
+        else split8(x[0], x[1], ah, al);
 #pragma unroll
         for (int p = 0; p < kS128Steps; ++p) {
-          bf16x8 nh = ah, nl = al;
-          if (p + 1 < kS128Steps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
-          acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
-          acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
-          acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
-          acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
-          {
+          bf16x8 nh = ah, nl = al, nc = ac;
+          if (p + 1 < kS128Steps) {
+            if constexpr (MX == 2) split8x3(x[2 * p + 2], x[2 * p + 3], nh, nl, nc);
+            else split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
+          }
+          if constexpr (MX == 2) {  // every accumulator is reused only after two other MFMAs
+            acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
+            acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
+            acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
+            acc_hh = mfma_bf16(ah, qc[s][p], acc_hh);
+            acc_lh = mfma_bf16(ac, qhi[s][p], acc_lh);
+            acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
+          } else {
+            acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
+            acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
+            acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
+            acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
+          }
+          if constexpr (!MX) {
             const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
             const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
             ss2 += a0 * a0;
@@ -254,12 +271,13 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
             ss2 += b1 * b1;
           }
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
+          for (int g = 0; g < (MX == 2 ? 6 : 4); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 VALU in its shadow
           }
           ah = nh;
           al = nl;
+          ac = nc;
         }
         cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
         --inflight;
@@ -402,12 +420,21 @@ bool kp128_maxsim_supported(int Q, int E) {
   return Q <= 32 && E % 64 == 0 && (nsl == 1 || nsl == 2 || nsl == 3 || nsl == 4 || nsl == 6 || nsl == 8 || nsl == 12);
 }
 
-template <int NSL, int KS>
+template <int NSL, int KS, int MX>
 static void launch_mx(const KpArgs& a, const dim3 grid, int lds, hipStream_t stream) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<NSL, 11, false, KS, true>,
+    (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<NSL, 11, false, KS, MX>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, KS, true>), grid, dim3(64 * KS), lds, stream, a);
+  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, KS, MX>), grid, dim3(64 * KS), lds, stream, a);
+}
+
+// MM_MAXSIM_F32_TERMS = 2 selects the two-term split (operand error 2^-17) for A/B runs; default: three terms
+static int maxsim_f32_terms() {
+  static const int terms = [] {
+    const char* s = getenv("MM_MAXSIM_F32_TERMS");
+    return (s && atoi(s) == 2) ? 2 : 3;
+  }();
+  return terms;
 }
 
 int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask dm, float* out, int64_t n_pairs,
@@ -423,16 +450,19 @@ int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask d
   a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
   groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
   const dim3 grid((unsigned)groups);
+  const bool x3 = maxsim_f32_terms() == 3;
+#define MM_MX(NSL, KS) (x3 ? launch_mx<NSL, KS, 2>(a, grid, lds, stream) : launch_mx<NSL, KS, 1>(a, grid, lds, stream))
   switch (nsl) {
-    case 1: launch_mx<1, 1>(a, grid, lds, stream); break;
-    case 2: launch_mx<2, 1>(a, grid, lds, stream); break;
-    case 3: launch_mx<3, 1>(a, grid, lds, stream); break;
-    case 4: launch_mx<4, 1>(a, grid, lds, stream); break;
-    case 6: launch_mx<6, 1>(a, grid, lds, stream); break;
-    case 8: launch_mx<4, 2>(a, grid, lds, stream); break;
-    case 12: launch_mx<6, 2>(a, grid, lds, stream); break;
+    case 1: MM_MX(1, 1); break;
+    case 2: MM_MX(2, 1); break;
+    case 3: MM_MX(3, 1); break;
+    case 4: MM_MX(4, 1); break;
+    case 6: MM_MX(6, 1); break;
+    case 8: MM_MX(4, 2); break;
+    case 12: MM_MX(6, 2); break;
     default: return set_error(MM_EUNSUPPORTED, "maxsim: E=%d has no fp32 streaming kernel", a.E);
   }
+#undef MM_MX
   return check_launch("kernel_pool_split128_kernel<maxsim>");
 }
 

@@ -249,6 +249,26 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, bf16x8&
   lo = __builtin_bit_cast(bf16x8, lw);
 }
 
+// Three-term split x = hi + lo + c (3 x 8 significand bits = fp32's 24): the fp32 MaxSim path ranks candidates, and
+// the two-term split's 2^-17 operand error moves ~10x more near-ties than a true fp32 evaluation would.
+__device__ __forceinline__ void split8x3(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo, bf16x8& c) {
+  u32x4 hw, lw, cw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = j < 2 ? x0[2 * j] : x1[2 * j - 4];
+    const float b = j < 2 ? x0[2 * j + 1] : x1[2 * j - 3];
+    const uint32_t w = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(w << 16), rb = b - __uint_as_float(w & 0xffff0000u);
+    const uint32_t l = cvt_pk_bf16(ra, rb);
+    hw[j] = w;
+    lw[j] = l;
+    cw[j] = cvt_pk_bf16(ra - __uint_as_float(l << 16), rb - __uint_as_float(l & 0xffff0000u));
+  }
+  hi = __builtin_bit_cast(bf16x8, hw);
+  lo = __builtin_bit_cast(bf16x8, lw);
+  c = __builtin_bit_cast(bf16x8, cw);
+}
+
 __device__ __forceinline__ float sumsq4(const f32x4& v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
 
 

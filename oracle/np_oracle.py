@@ -115,6 +115,24 @@ def cosine_matrix_split_bf16(a, b):
     return (dot * ra) * np.swapaxes(rb, -1, -2)
 
 
+def maxsim_paired_split_bf16(q, d, q_mask, d_mask):
+    """Emulation of the DEVICE arithmetic of the fp32 MaxSim path (kernel_pool128.hip, MX = true): every fp32
+    operand x = hi + lo (two bf16), dot = hi.hi + lo.hi + hi.lo + lo.lo with exact products and fp32-class
+    accumulation; masking / max / sum as colbert.py:69-75.  Not a reference restatement: it measures the
+    rounding noise of the split scheme against `maxsim_paired(..., float64)` for the rank-order checks."""
+    q = np.asarray(q, dtype=np.float32)
+    d = np.asarray(d, dtype=np.float32)
+    qh, dh = _bf16_rne(q), _bf16_rne(d)
+    ql, dl = _bf16_rne(q - qh), _bf16_rne(d - dh)
+    f = np.float64
+    t = lambda x: np.swapaxes(x.astype(f), 1, 2)
+    s = (np.matmul(qh.astype(f), t(dh)) + np.matmul(ql.astype(f), t(dh)) + np.matmul(qh.astype(f), t(dl))
+         + np.matmul(ql.astype(f), t(dl))).astype(np.float32)
+    s = np.where((np.asarray(d_mask) != 0)[:, None, :], s, np.float32(-1000))
+    m = np.where(np.asarray(q_mask) != 0, s.max(-1), np.float32(0))
+    return m.sum(-1, dtype=np.float32)
+
+
 # ----------------------------------------------------------------------------- TK
 
 

@@ -32,12 +32,18 @@ def test_maxsim_one_rank_shard_of_config4():
     assert torch.equal(out, ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)), "non-deterministic"
     half = ops.maxsim((q.float() * 0.5).to(torch.bfloat16), d, q_len, d_len, pairs_per_query=C)
     assert torch.equal(half, out * 0.5)
-    for i in (0, 436, 872):                                # whole queries incl. the last one of the shard
+    rows = []
+    for i in range(nq):                                    # EVERY query of the shard: scores and rank order
         dn = d[i * C:(i + 1) * C].float().cpu().numpy()
         dm = synth.len_to_mask(d_len[i * C:(i + 1) * C], 180).cpu().numpy()
         qm = np.repeat(synth.len_to_mask(q_len[i:i + 1], 32).cpu().numpy(), C, 0)
-        ref = O.maxsim_paired(np.repeat(q[i:i + 1].float().cpu().numpy(), C, 0), dn, qm, dm)
-        np.testing.assert_allclose(out[i * C:(i + 1) * C].cpu().numpy(), ref, atol=util.TOL_BF16)
+        qr = np.repeat(q[i:i + 1].float().cpu().numpy(), C, 0)
+        ref = O.maxsim_paired(qr, dn, qm, dm)
+        ref64 = O.maxsim_paired(qr, dn, qm, dm, dtype=np.float64)
+        got = out[i * C:(i + 1) * C].cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=util.TOL_BF16)
+        rows.append(util.rank_parity(got, ref, ref64, (1, 10, 100, 1000), label=f"shard query {i}"))
+    assert util.rank_report("config4_one_rank_shard", rows) >= 0.99
     # the ranking this rank contributes is a permutation of its candidates, best first
     ranking = sharding.rank_candidates(out.view(nq, C))
     assert ranking.shape == (nq, C)

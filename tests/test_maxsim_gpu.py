@@ -150,16 +150,8 @@ def test_config2_full_size_properties_and_rank_order():
         ref64 = O.maxsim_paired(np.repeat(qn[i:i + 1], C, 0), dn, qm, dm, dtype=np.float64)
         got = out[i * C:(i + 1) * C].cpu().numpy()
         np.testing.assert_allclose(got, ref32, atol=util.TOL_BF16)
-        # rank order: identical wherever the fp64 gap between neighbours exceeds the fp32 noise bound
-        order_ref = O.rank_order(ref64)
-        order_got = O.rank_order(got)
-        noise = 4 * 32 * 128 * np.finfo(np.float32).eps        # 4 x (Q sums of E-long fp32 dots of unit vectors)
-        gaps = np.abs(np.diff(ref64[order_ref]))
-        decided = np.concatenate([[True], gaps > noise]) & np.concatenate([gaps > noise, [True]])
-        assert (order_ref[decided] == order_got[decided]).all()
-        for k in (10, 20, 100):
-            if gaps[k - 1] > noise:
-                assert set(order_ref[:k]) == set(order_got[:k])
+        # rank order under the measured-noise tie policy (tests/util.rank_parity; every query: test_rank_order_gpu.py)
+        util.rank_parity(got, ref32, ref64, (1, 10, 100, 1000), label=f"query {i}")
 
 
 def test_errors_are_loud():

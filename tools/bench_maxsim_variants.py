@@ -42,6 +42,17 @@ if "paired" in which:
     qp = q.repeat_interleave(C, 0)[: B // 4].contiguous()
     report("bf16 pair-per-row layout (reference batch layout, Q replicated)",
            timeit(lambda: ops.maxsim(qp, d[: B // 4], None, d_len[: B // 4], 1)), B // 4, (B // 4) * (D + Q) * E * 2)
+if "dropin" in which:
+    # exactly what ColBERT.forward hands over (eval.py:108 -> colbert.py:68-75): Q replicated per pair, int64 HF masks
+    qp = q.repeat_interleave(C, 0).contiguous()
+    dm = synth.len_to_mask(d_len, D, torch.int64)
+    qm = synth.len_to_mask(q_len, Q, torch.int64).repeat_interleave(C, 0).contiguous()
+    by = B * ((D + Q) * E * 2 + 8 * (D + Q) + 4)
+    report("bf16 drop-in layout: pair-per-row Q + int64 masks (bytes incl. masks)",
+           timeit(lambda: ops.maxsim(qp, d, qm, dm, 1)), B, by)
+    report("bf16 pair-per-row Q + int32 lengths",
+           timeit(lambda: ops.maxsim(qp, d, q_len.repeat_interleave(C), d_len, 1)), B, B * ((D + Q) * E * 2 + 12))
+    del qp, dm, qm
 if "i64mask" in which:
     dm = synth.len_to_mask(d_len, D, torch.int64)
     qm = synth.len_to_mask(q_len, Q, torch.int64)
