@@ -1,23 +1,35 @@
 #!/usr/bin/env python
 """bench.py — query-doc pairs scored / second, ColBERT MaxSim (Q32 / D180 / dim128, bf16,
-1000 candidates per query; BASELINE.json config 2), on N MI355X GPUs of one node.
+1000 candidates per query; BASELINE.json configs[1]), on N MI355X GPUs of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path (mm_maxsim_fwd) over one resident batch of
-`--queries` x 1000 synthetic (query, candidate) pairs per GPU.  Inputs are generated on the device
-before the timed region (resident in HBM).  Every rank scores its own shard of queries (weak
-scaling, no data-path collective); with N > 1 one RCCL all-gather of the fp32 scores per step is
-part of the timed region (the ranking merge of SURVEY.md §8e).
+`--gpus N` with N > 1 starts itself: when no torch.distributed environment is present the script re-executes
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one process
+per GPU over RCCL), the way the reference starts all GPUs from one `python train.py`
+(matchmaker/train.py:194-202); launched under torchrun by someone else it just joins the group.
 
-Prints ONE JSON line (rank 0).  `roofline`: algorithmic bytes per launch / average
-kernel time measured with HIP events on the launch stream; `cpu_baseline`: the torch CPU port of the
-reference's ops (oracle/torch_port.py) timed on this host's cores on a bounded sample of the same workload.
+A "step" = one pass of the hot path (mm_maxsim_fwd) over one resident batch of `--queries` x 1000 synthetic
+(query, candidate) pairs per GPU.  Inputs are generated on the device before the timed region (resident in
+HBM).  Every rank scores its own shard of queries (weak scaling, no data-path collective); with N > 1 one
+RCCL all-gather of the fp32 scores per step is part of the timed region (the ranking merge of SURVEY.md §8e).
+
+Prints ONE JSON line (rank 0).  `roofline`: algorithmic bytes per launch / average kernel
+time measured with HIP events on the launch stream; `cpu_baseline`: the torch CPU port of the reference's ops
+(oracle/torch_port.py) timed on this host's cores on a bounded sample of the same workload.  At N = 1 the line
+also carries `extra`: the reference's own batch layout through the same operator (`dropin_forward`: query
+replicated per pair, HF int64 masks — what eval.py:108 hands to ColBERT.forward), and the other BASELINE.json
+configs on this GPU (`tk` configs[0] shapes at scale, `tkl` configs[2], `dot_topk` one rank's shard of
+configs[4]), each with its own roofline fraction, CPU leg and the rocprof summary it can be checked against.
+
+`--dry` (with `--backend gloo --device cpu`) exercises ONLY the launch + collective plumbing on a machine
+without GPUs (tests/test_bench_launch_cpu.py): scores are fabricated, `value` is null — never a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,13 +38,64 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 Q, D, E, CANDS = 32, 180, 128, 1000
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_16BIT = 2.5e15     # dense bf16 / fp16 MFMA peak, FLOP/s (MI355X_MICROARCH.md; no sparsity)
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
 
 
 def algorithmic_bytes(n_queries: int, cands: int) -> int:
     """B*D*E*s + Nq*Q*E*s + 4*(B + Nq) + 4*B  (shared-Q layout, int32 lengths)."""
     B = n_queries * cands
     return B * D * E * 2 + n_queries * Q * E * 2 + 4 * (B + n_queries) + 4 * B
+
+
+def dropin_bytes(B: int) -> int:
+    """The reference's pair-per-row layout (54,280 B/pair) + its int64 HF masks as they are read."""
+    return B * ((D + Q) * E * 2 + 8 * (D + Q) + 4)
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """One command starts all ranks (train.py:194-202 starts its GPUs from one process too)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL / cross-process device memory)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def timed_cpu(fn, budget_s, unit_per_call):
+    """2 warm-ups, then whole calls until ~budget_s seconds -> (units/s, calls, seconds)."""
+    fn(); fn()
+    t_total, n = 0.0, 0
+    while t_total < budget_s or n < 5:
+        t0 = time.perf_counter()
+        fn()
+        t_total += time.perf_counter() - t0
+        n += 1
+        if n >= 5 and t_total >= budget_s:
+            break
+    return unit_per_call * n / t_total, n, t_total
+
+
+def both_thread_settings(make_fn, budget_s, unit_per_call):
+    """(all-threads rate, single-thread rate, threads): BASELINE.md §2 asks for torch.set_num_threads(1) — what
+    the reference's scripts run with (train.py:12 exports OMP_NUM_THREADS=1) — and the host's best case."""
+    import torch
+    threads = torch.get_num_threads()
+    r_all = timed_cpu(make_fn(), budget_s, unit_per_call)
+    torch.set_num_threads(1)
+    try:
+        r_one = timed_cpu(make_fn(), budget_s / 2, unit_per_call)
+    finally:
+        torch.set_num_threads(threads)
+    return r_all, r_one, threads
 
 
 def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
@@ -81,25 +144,231 @@ def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
                       f"(OMP_NUM_THREADS=1 as in train.py:12): {pairs1} pairs in {t1:.1f} s"}
 
 
-def measured_traffic(nq, cands, lengths):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/*_maxsim_pmc.json, written by tools/profile_maxsim.sh + tools/summarize_rocprof.py:
-    separate --pmc passes, FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024)."""
+def profile_summary(pattern, kernel_substr, key):
+    """A figure from the committed rocprofv3 summaries (profiles/*.json, tools/summarize_rocprof.py):
+    returns (value, file) of the newest matching profile, or None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*maxsim*pmc*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             j = json.load(open(f))
         except Exception:
             continue
-        wl = j.get("workload", {})
-        if wl.get("queries") == nq and wl.get("cands") == cands and wl.get("lengths") == lengths:
-            for k, c in j.get("pmc", {}).items():
-                if "maxsim_stream_kernel" in k and "_hbm_traffic_bytes_per_dispatch" in c:
-                    best = (c["_hbm_traffic_bytes_per_dispatch"]["total"], os.path.basename(f))
+        for k, c in j.get("pmc", {}).items():
+            if kernel_substr in k and key in c:
+                v = c[key]
+                best = (v["total"] if isinstance(v, dict) and "total" in v else v, os.path.basename(f), j.get("workload", {}))
     return best
 
 
+def gpu_time_ms(fn, steps, warmup=2):
+    """Median of per-call HIP-event times on the current stream (the stream the operators launch on)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+
+
+# ------------------------------------------------------------------------------------------ extras (N = 1)
+def extra_dropin_forward(q, d, q_len, d_len, steps):
+    """eval.py:108 -> ColBERT.forward -> colbert.py:68-75 exactly as the reference batches it: the query
+    replicated per pair, HF int64 attention masks, pairs_per_query = 1 — on the SAME pairs as the headline."""
+    import torch
+    from matchmaker_amd import ops, synth
+    from matchmaker_amd.colbert import ColBERT
+    nq, B = q.shape[0], d.shape[0]
+    qp = q.repeat_interleave(CANDS, 0).contiguous()
+    qm = synth.len_to_mask(q_len, Q, torch.int64).repeat_interleave(CANDS, 0).contiguous()
+    dm = synth.len_to_mask(d_len, D, torch.int64)
+    ref = ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
+    got = ColBERT._score(qp, d, qm, dm)                   # the drop-in's scoring entry (no_grad: native forward)
+    same = bool(torch.equal(ref, got))
+    ms = gpu_time_ms(lambda: ColBERT._score(qp, d, qm, dm), steps)
+    by = dropin_bytes(B)
+    gbs = by / (ms * 1e-3) / 1e9
+    return {"workload": f"the headline's {nq} x {CANDS} pairs in the reference's batch layout: Q replicated per pair "
+                        f"[{B},{Q},{E}] bf16, int64 HF masks [{B},{Q}] / [{B},{D}], pairs_per_query = 1 (ColBERT._score)",
+            "dtype": "bf16", "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
+            "bytes_per_pair": by // B, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "frac": gbs / HBM_PEAK_GBS},
+            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r02_dropin_pmc.json"}
+
+
+def extra_tk(steps, cpu_budget):
+    """BASELINE.json configs[0] shapes (TK kernel pooling, Q=20 / D=200 / dim=300, fp32) at GPU scale:
+    64 queries x 1000 candidates, every position real (the padded figure of DESIGN.md §3.3)."""
+    import torch
+    from matchmaker_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nq, C, Qt, Dt, Et = 64, 1000, 20, 200, 300
+    B = nq * C
+    g = torch.Generator(device=dev).manual_seed(1001)
+    q = torch.randn(nq, Qt, Et, generator=g, device=dev)
+    d = torch.randn(B, Dt, Et, generator=g, device=dev)
+    q_len = torch.full((nq,), Qt, dtype=torch.int32, device=dev)
+    d_len = torch.full((B,), Dt, dtype=torch.int32, device=dev)
+    prm = [torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev), torch.ones(11, device=dev),
+           torch.linspace(-0.014, 0.014, 11, device=dev)]
+    fn = lambda: ops.kernel_pool(q, d, q_len, d_len, *prm, pairs_per_query=C)
+    ms = gpu_time_ms(fn, steps)
+    by = B * Dt * Et * 4 + nq * Qt * Et * 4 + 4 * (B + nq) + 4 * B
+    gbs = by / (ms * 1e-3) / 1e9
+    out = {"workload": f"TK kernel pooling (ecai20_tk.py:105-124), {nq} queries x {C} candidates, Q={Qt}/D={Dt}/dim={Et}, "
+                       f"all positions real, shared query tile, int32 lengths",
+           "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms,
+           "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by, "flop": B * (2 * Qt * Dt * Et + 2 * (Qt + Dt) * Et),
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r02_tk_pmc.json"}
+    # --- CPU legs: scoring only (torch port of :105-124) and full forward (+ the 2-layer Transformer contextualiser)
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        from matchmaker_amd.tk import ECAI20_TK
+        n = 200
+        qc, dc = q[:1].cpu().expand(n, -1, -1).contiguous(), d[:n].cpu()
+        qm, dm = torch.ones(n, Qt), torch.ones(n, Dt)
+        mu, sg = prm[0].cpu().view(1, 1, 1, -1), prm[1].cpu().view(1, 1, 1, -1)
+        al, w = prm[2].cpu().view(1, 1, -1), prm[3].cpu().view(1, -1)
+        model = ECAI20_TK(Et, MU, [0.1] * 11, att_heads=10, att_layer=2, att_ff_dim=300, max_length=Dt,
+                          use_diff_posencoding=True, mix_hybrid_context=True).eval()      # tk.yaml
+
+        def scoring():
+            with torch.no_grad():
+                TP.tk_kernel_pool(qc, dc, qm, dm, mu, sg, al, w)
+
+        def full():
+            with torch.no_grad():
+                qx = model.forward_representation(qc, qm, model.positional_features_q[:, :Qt])
+                dx = model.forward_representation(dc, dm, model.positional_features_d[:, :Dt])
+                TP.tk_kernel_pool(qx, dx, qm, dm, mu, sg, al, w)
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: scoring, cpu_budget, n)
+        (fa, _, _), (f1, _, _), _ = both_thread_settings(lambda: full, cpu_budget, n)
+        out["cpu_baseline"] = {"value": ra, "unit": "pairs/s", "cores": threads, "kind": "port", "single_thread_value": r1,
+                               "full_forward_value": fa, "full_forward_single_thread_value": f1,
+                               "sample": f"{n}-pair forward calls, {na} timed calls in {ta:.1f} s ({threads} threads) / {n1} in "
+                                         f"{t1:.1f} s (1 thread); scoring only = oracle/torch_port.tk_kernel_pool; full forward = "
+                                         f"the drop-in's own PyTorch contextualiser (2 layers, 10 heads, tk.yaml) + that block"}
+    return out
+
+
+def extra_tkl(steps, cpu_budget):
+    """BASELINE.json configs[2]: TKL, D = 2048, dim = 300, Q = 20, fp32; 256 documents of U{50..2048} tokens and
+    queries of U{3..20} tokens, pre-contextualised packed chunks resident in HBM -> scores."""
+    import torch
+    from matchmaker_amd import ops
+    from matchmaker_amd.tkl import TKL_sigir20, chunk_documents
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, Qt, Dt, Et = 256, 20, 2048, 300
+    g = torch.Generator(device=dev).manual_seed(3003)
+    m = TKL_sigir20(Et, MU, [0.1] * 11, 10, 2, 300, 2000, True, True, "embedding").to(dev).eval()     # tkl.yaml
+    q = torch.randn(B, Qt, Et, generator=g, device=dev)
+    d = torch.randn(B, Dt, Et, generator=g, device=dev)
+    d_len = torch.randint(50, Dt + 1, (B,), generator=g, device=dev)
+    q_len = torch.randint(3, Qt + 1, (B,), generator=g, device=dev)
+    qm = (torch.arange(Qt, device=dev)[None] < q_len[:, None]).float()
+    dm = (torch.arange(Dt, device=dev)[None] < d_len[:, None]).float()
+    q_ctx = q * qm.unsqueeze(-1)
+    chunks, cmask, slot, C = chunk_documents(d * dm.unsqueeze(-1), dm)       # stands in for the contextualised chunks
+    params = m.pack_params()
+    P = chunks.shape[0]
+    fn = lambda: ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, "embedding")
+    ms = gpu_time_ms(fn, steps)
+    by = P * 50 * Et * 4 + B * Qt * Et * 4 + P * 50 * 4 + 4 * B
+    gbs = by / (ms * 1e-3) / 1e9
+    out = {"workload": f"TKL scoring (sigir20_tkl.py:180-286), {B} documents x D={Dt} (lengths U{{50..{Dt}}}: {P} packed chunks "
+                       f"of 50 tokens), dim={Et}, Q={Qt} (lengths U{{3..{Qt}}}), embedding saturation",
+           "dtype": "fp32 (split-bf16 operands)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+           "kernel": "tkl_stage1_run_kernel + tkl_window_kernel + tkl_region_kernel (whole mm_tkl_fwd call)",
+           "profile": "profiles/r02_tkl_pmc.json"}
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        n = 4
+        keep = (slot.long() // C) < n
+        packed = torch.zeros(n * C, dtype=torch.bool)
+        packed[slot[keep].long().cpu()] = True
+        centre, cm = chunks[keep][:, 5:-5].cpu().contiguous(), cmask[keep][:, 5:-5].cpu().float().contiguous()
+        prm = {"mu": m.mu, "sigma": m.sigma, "dense_w": m.dense.weight, "sat_w1": m.saturation_linear.weight,
+               "sat_b1": m.saturation_linear.bias, "sat_w2": m.saturation_linear2.weight, "sat_b2": m.saturation_linear2.bias,
+               "sat_w3": m.saturation_linear3.weight, "sat_b3": m.saturation_linear3.bias, "ln_w": m.sat_normer.weight,
+               "ln_b": m.sat_normer.bias, "emb_reduce_w": m.sat_emb_reduce1.weight, "kernel_mult0": m.kernel_mult[0],
+               "chunk_scoring": m.chunk_scoring}
+        prm = {k: v.detach().float().cpu().reshape(-1) for k, v in prm.items()}
+        qc, qmc = q_ctx[:n].cpu(), qm[:n].cpu()
+        mc = TKL_sigir20(Et, MU, [0.1] * 11, 10, 2, 300, 2000, True, True, "embedding").eval()
+        dc, dmc = d[:n].cpu() * dm[:n].cpu().unsqueeze(-1), dm[:n].cpu()
+
+        def scoring():
+            with torch.no_grad():
+                TP.tkl_scoring(qc, centre, cm, packed, n, qmc, prm, "embedding")
+
+        def full():
+            with torch.no_grad():
+                qx, _ = mc.forward_representation(qc, qmc, mc.positional_features_q[:, :Qt])
+                ch, chm, sl, Cc = chunk_documents(dc, dmc)
+                cx, _ = mc.forward_representation(ch, chm, mc.positional_features_d[:, :50])
+                pk = torch.zeros(n * Cc, dtype=torch.bool)
+                pk[sl.long()] = True
+                TP.tkl_scoring(qx, cx[:, 5:-5].contiguous(), chm[:, 5:-5].float().contiguous(), pk, n, qmc, prm, "embedding")
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: scoring, cpu_budget, n)
+        (fa, _, _), (f1, _, _), _ = both_thread_settings(lambda: full, cpu_budget, n)
+        out["cpu_baseline"] = {"value": ra, "unit": "docs/s", "cores": threads, "kind": "port", "single_thread_value": r1,
+                               "full_forward_value": fa, "full_forward_single_thread_value": f1,
+                               "sample": f"the first {n} documents of the workload per call, {na} timed calls in {ta:.1f} s "
+                                         f"({threads} threads) / {n1} in {t1:.1f} s (1 thread); scoring only = "
+                                         f"oracle/torch_port.tkl_scoring (sigir20_tkl.py:180-286); full forward adds chunking + the "
+                                         f"drop-in's PyTorch chunk Transformer (tkl.yaml)"}
+    return out
+
+
+def extra_dot_topk(steps, cpu_budget):
+    """BASELINE.json configs[4], ONE rank's shard: 8,841,823 / 8 passages x dim 768 fp16 against all 6,980 queries,
+    exact top-1000 (faiss IndexFlatIP semantics)."""
+    import torch
+    from matchmaker_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    N, Ed, nq, k = 1105228, 768, 6980, 1000
+    g = torch.Generator(device=dev).manual_seed(5005)
+    c = torch.empty((N, Ed), dtype=torch.float16, device=dev)
+    for s in range(0, N, 1 << 18):
+        n = min(1 << 18, N - s)
+        c[s:s + n] = torch.randn(n, Ed, generator=g, device=dev).half()
+    q = torch.randn(nq, Ed, generator=g, device=dev).half()
+    ops.dot_topk(q, c, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ops.dot_topk(q, c, k)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    flop = 2.0 * nq * N * Ed
+    out = {"workload": f"brute-force inner-product top-{k} (faiss_indices.py:49-74, dense_retrieval.py:391): one rank's shard "
+                       f"of configs[4] = {N} passages x dim {Ed} fp16, {nq} queries",
+           "dtype": "fp16 (fp32 accumulation)", "ms": t * 1e3, "queries_per_s": nq / t, "flop": flop,
+           "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
+                        "frac": flop / t / MFMA_PEAK_16BIT},
+           "kernel": "dot_stream_kernel (sample + filter) + sample_tau_kernel + topk_rows_kernel (whole mm_dot_topk_fwd call, wall clock)",
+           "profile": "profiles/r02_dot_pmc.json"}
+    if cpu_budget > 0:
+        nqc, nc = 64, 1 << 16
+        qc, cc = q[:nqc].float().cpu(), c[:nc].float().cpu()
+
+        def search():
+            with torch.no_grad():
+                torch.topk(qc @ cc.T, k, dim=1)
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: search, cpu_budget, nqc * nc)
+        out["cpu_baseline"] = {"value": ra, "unit": "query-passage inner products/s", "cores": threads, "kind": "port",
+                               "single_thread_value": r1, "gpu_value_same_unit": nq * N / t,
+                               "sample": f"{nqc} queries x {nc} passages per call (fp32 torch matmul + topk = IndexFlatIP.search's "
+                                         f"definition; faiss is absent here), {na} calls in {ta:.1f} s ({threads} threads) / {n1} in "
+                                         f"{t1:.1f} s (1 thread)"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,33 +378,53 @@ def main():
                     help="queries per GPU per step (x1000 candidates; 256 -> 11.8 GB of bf16 token embeddings resident)")
     ap.add_argument("--lengths", default="full", choices=["full", "msmarco"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the drop-in-layout / TK / TKL / dot-top-k legs (N = 1 only)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"])
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
+    ap.add_argument("--dry", action="store_true",
+                    help="launch + collective plumbing only (fabricated scores, value = null); for GPU-less machines")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
-    from matchmaker_amd import ops, synth, _lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
+    if args.device == "cpu" and not args.dry:
+        raise SystemExit("--device cpu is only valid with --dry: there is no CPU scoring path")
+    backend = args.backend or ("gloo" if args.device == "cpu" else "nccl")
+    if args.device == "cuda":
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    _lib.lib()   # fail loudly here if the HIP library is missing
+        kw = {"device_id": dev} if dev.type == "cuda" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
 
-    nq = args.queries
-    q, d, q_len, d_len = synth.colbert_batch(nq, CANDS, Q, D, E, torch.bfloat16, dev, seed=4004 + rank,
-                                             lengths=args.lengths)
+    nq = args.queries if not args.dry else min(args.queries, 2)
     B = nq * CANDS
+    if args.dry:
+        score_shard = lambda: torch.arange(B, dtype=torch.float32, device=dev) + rank * B     # rank-tagged, checkable
+    else:
+        from matchmaker_amd import ops, synth, _lib
+        _lib.lib()   # fail loudly here if the HIP library is missing
+        q, d, q_len, d_len = synth.colbert_batch(nq, CANDS, Q, D, E, torch.bfloat16, dev, seed=4004 + rank,
+                                                 lengths=args.lengths)
+        score_shard = lambda: ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
     gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
-        s = ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
+        s = score_shard()
         if world > 1:
             dist.all_gather_into_tensor(gathered, s)     # RCCL over xGMI: the ranking merge
         return s
@@ -144,56 +433,105 @@ def main():
         step()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
 
     # kernel-only timing with HIP events on the launch stream (roofline numerator)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    use_ev = dev.type == "cuda"
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_ev else []
     barrier()
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        s = ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
-        b.record()
+    for i in range(args.steps):
+        if use_ev:
+            ev[i][0].record()
+        s = score_shard()
+        if use_ev:
+            ev[i][1].record()
         if world > 1:
             dist.all_gather_into_tensor(gathered, s)
     barrier()
     t = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if use_ev else None
 
     tt = torch.tensor([t], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t = float(tt.item())
+    gather_ok = None
+    if world > 1 and args.dry:
+        want = torch.arange(world * B, dtype=torch.float32, device=dev)
+        gather_ok = bool(torch.equal(gathered, want))
 
     if rank == 0:
         total_pairs = world * B * args.steps
-        ab = algorithmic_bytes(nq, CANDS)
-        achieved = ab / (kern_ms * 1e-3) / 1e9
+        coll = None
+        if world > 1:
+            ver = None
+            if backend == "nccl":
+                try:
+                    ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+                except Exception:
+                    ver = "unknown"
+            coll = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "version": ver, "world_size": world,
+                    "op": "all_gather_into_tensor of fp32 scores, once per step, inside the timed region",
+                    "bytes_per_rank": 4 * B, "bytes_total": 4 * B * world}
         out = {
             "metric": "query-doc pairs scored/sec (ColBERT MaxSim, Q32/D180/dim128)",
-            "value": total_pairs / t, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "value": None if args.dry else total_pairs / t, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "world_size": world, "collective": coll,
             "config": {"workload": f"BASELINE.json configs[1]: ColBERT MaxSim re-rank, dim=128, Q=32/D=180, "
                                    f"1000 candidates/query, bf16; {nq} queries x 1000 candidates resident per GPU "
                                    f"per step; doc lengths = {args.lengths}",
                        "queries_per_gpu": nq, "cands_per_query": CANDS, "Q": Q, "D": D, "E": E,
-                       "parallelism": f"query-sharded x{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "maxsim_stream_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": ab},
+                       "parallelism": f"query-sharded x{world}" + (f", {backend} all-gather of scores" if world > 1 else "")},
         }
-        tr = measured_traffic(nq, CANDS, args.lengths)
-        if tr is not None:
-            out["roofline"]["traffic"] = tr[0]
-            out["roofline"]["traffic_source"] = f"profiles/{tr[1]} (rocprofv3 PMC passes of this workload)"
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg is an N = 1 figure; ranks > 0 would idle through it
-            nsamp = min(nq, 24)
-            out["cpu_baseline"] = cpu_baseline(q[:nsamp].cpu(), d[:nsamp * CANDS].cpu(), q_len[:nsamp].cpu(),
-                                               d_len[:nsamp * CANDS].cpu(), CANDS)
+        if args.dry:
+            out["dry"] = True
+            out["note"] = "launch/collective plumbing check only: scores fabricated, nothing measured"
+            out["all_gather_verified"] = gather_ok
+        else:
+            ab = algorithmic_bytes(nq, CANDS)
+            achieved = ab / (kern_ms * 1e-3) / 1e9
+            flop = 2.0 * B * Q * D * E
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "maxsim_stream_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": ab,
+                               "mfma_util": {"flop_per_launch": flop, "tflops": flop / (kern_ms * 1e-3) / 1e12,
+                                             "frac_of_dense_bf16_peak": flop / (kern_ms * 1e-3) / MFMA_PEAK_16BIT,
+                                             "peak_tflops": MFMA_PEAK_16BIT / 1e12}}
+            tr = profile_summary("*maxsim*pmc*.json", "maxsim_stream_kernel", "_hbm_traffic_bytes_per_dispatch")
+            if tr is not None and tr[2].get("queries") == nq and tr[2].get("cands") == CANDS and tr[2].get("lengths") == args.lengths:
+                out["roofline"]["traffic"] = tr[0]
+                out["roofline"]["traffic_source"] = f"profiles/{tr[1]} (rocprofv3 PMC passes of this workload)"
+            busy = profile_summary("*maxsim*pmc*.json", "maxsim_stream_kernel", "_mfma_busy_frac")
+            if busy is not None:
+                out["roofline"]["mfma_util"]["pmc_busy_frac"] = busy[0]
+                out["roofline"]["mfma_util"]["pmc_source"] = f"profiles/{busy[1]} (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x SQ_BUSY_CYCLES-derived kernel cycles))"
+            if world == 1:      # CPU leg and extras are N = 1 figures; ranks > 0 would idle through them
+                if not args.no_cpu_baseline:
+                    nsamp = min(nq, 24)
+                    out["cpu_baseline"] = cpu_baseline(q[:nsamp].cpu(), d[:nsamp * CANDS].cpu(), q_len[:nsamp].cpu(),
+                                                       d_len[:nsamp * CANDS].cpu(), CANDS)
+                if not args.no_extras:
+                    extra = {}
+                    cpu_b = 0.0 if args.no_cpu_baseline else 3.0
+                    try:
+                        extra["dropin_forward"] = extra_dropin_forward(q, d, q_len, d_len, max(5, args.steps // 2))
+                    except Exception as e:      # an extra must never take the headline line down with it
+                        extra["dropin_forward"] = {"error": repr(e)}
+                    del q, d
+                    torch.cuda.empty_cache()
+                    for name, fn in (("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk)):
+                        try:
+                            extra[name] = fn(3 if name == "dot_topk" else 10, cpu_b)
+                        except Exception as e:
+                            extra[name] = {"error": repr(e)}
+                        torch.cuda.empty_cache()
+                    out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

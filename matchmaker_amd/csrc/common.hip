@@ -1,5 +1,6 @@
 // Error reporting + mask packing for libmm_native.so.
 #include "mm_internal.h"
+#include <stdlib.h>
 
 namespace mm {
 
@@ -11,6 +12,30 @@ int set_error(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+const EnvCfg& env() {
+  static const EnvCfg cfg = [] {
+    EnvCfg c;
+    c.maxsim_nbuf = env_int("MM_MAXSIM_NBUF", c.maxsim_nbuf);
+    if (c.maxsim_nbuf < 2) c.maxsim_nbuf = 2;
+    if (c.maxsim_nbuf > 4) c.maxsim_nbuf = 4;
+    c.maxsim_wpc = env_int("MM_MAXSIM_WPC", c.maxsim_wpc);
+    c.maxsim_nt = env_int("MM_MAXSIM_NT", c.maxsim_nt);
+    c.maxsim_generic = env_int("MM_MAXSIM_GENERIC", 0);
+    c.maxsim_f32_terms = env_int("MM_MAXSIM_F32_TERMS", 3) == 2 ? 2 : 3;
+    c.kp_generic = env_int("MM_KP_GENERIC", 0);
+    c.kp_f32mfma = env_int("MM_KP_F32MFMA", 0);
+    c.tkl_fused = env_int("MM_TKL_FUSED", 0);
+    c.dot_prof = env_int("MM_DOT_PROF", 0);
+    return c;
+  }();
+  return cfg;
 }
 
 // One wave per mask row.  Lanes sweep the row 64 positions at a time; __ballot gives the 64

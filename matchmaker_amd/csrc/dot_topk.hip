@@ -583,11 +583,13 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   // phase 2: full product + threshold filter
   if (hipMemsetAsync(count, 0, (size_t)nq * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "dot_topk: memset failed");
   a.ndocs = n_docs; a.stride = 1;
-  static unsigned long long* prof_buf = nullptr;  // MM_DOT_PROF=1: per-wavefront phase cycle counters (tools/dot_prof.py)
-  static int prof_on = -1;
-  if (prof_on < 0) prof_on = getenv("MM_DOT_PROF") ? atoi(getenv("MM_DOT_PROF")) : 0;
-  if (prof_on) {
-    if (!prof_buf && hipMalloc((void**)&prof_buf, 8 * 32 * 32 * 4 * 6 * 8) != hipSuccess) prof_buf = nullptr;
+  if (env().dot_prof) {  // MM_DOT_PROF=1: per-wavefront phase cycle counters (single-GPU profiling runs only:
+                         // the buffer lives on the device that was current at the first call)
+    static unsigned long long* const prof_buf = [] {
+      void* p = nullptr;
+      if (hipMalloc(&p, 8 * 32 * 32 * 4 * 6 * 8) != hipSuccess) p = nullptr;
+      return (unsigned long long*)p;
+    }();
     a.prof = prof_buf;
   }
   {
@@ -600,10 +602,10 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), (size_t)cap * 8, stream, cand_score, cand_idx, count, cap, k,
                      n_docs, out_scores, out_idx, status);
   if (int e = check_launch("topk_rows_kernel")) return e;
-  if (prof_on && prof_buf) {  // tools only: synchronous dump of the phase counters
+  if (a.prof) {  // tools only: synchronous dump of the phase counters
     static unsigned long long host[8 * 32 * 32 * 4 * 6];
     (void)hipStreamSynchronize(stream);
-    (void)hipMemcpy(host, prof_buf, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host, a.prof, sizeof(host), hipMemcpyDeviceToHost);
     const int nw = 8 * 32 * 4;  // first launch's workgroups x 4 wavefronts at most
     double sum[6] = {0, 0, 0, 0, 0, 0};
     int cntw = 0;

@@ -1214,8 +1214,7 @@ bool tkl_fused_supported(int C, int Q, int E) {
   // — 0.47 ms vs 0.39 ms per 256 full documents, 0.44 vs 0.27 ms on ragged lengths: three wavefronts per CU with a
   // 2-slot ring expose the HBM latency, the window phase runs on the same three SIMDs, and one workgroup per
   // document serialises long documents.  Kept as the base for a version with a dedicated window wavefront.
-  const char* on = getenv("MM_TKL_FUSED");
-  if (!(on && atoi(on))) return false;
+  if (!env().tkl_fused) return false;
   if (!kp_stream_supported(Q, E)) return false;
   if (C > 1024) return false;
   const size_t lds = (size_t)kFW * kFNBUF * kSliceBytes + kFW * 128 + ((size_t)kFRing * Q * 12 + (size_t)kFRound * Q + ((Q + 3) & ~3)) * 4 +
@@ -1374,9 +1373,7 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   const dim3 grid((unsigned)waves), block(64);
   // MM_KP_F32MFMA=1 selects the exact-f32 MFMA kernel (A/B runs, tools/bench_kernel_pool.py);
   // the default is the split-bf16 kernel (same numerics class, 4x less matrix-pipe time)
-  static int f32mfma = -1;
-  if (f32mfma < 0) f32mfma = getenv("MM_KP_F32MFMA") ? atoi(getenv("MM_KP_F32MFMA")) : 0;
-  if (f32mfma && !W && !a.pair_q) {
+  if (env().kp_f32mfma && !W && !a.pair_q) {
     if (a.E == 100)
       hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
     else if (a.E == 200)
@@ -1410,9 +1407,7 @@ bool kp_stream_supported(int Q, int E) { return Q <= 32 && (E == 100 || E == 200
 
 // true when TKL stage 1 runs the grouped kernel, which writes every pair of every packed chunk
 bool tkl_stage1_writes_all_pairs(int Q, int E) {
-  const char* g = getenv("MM_KP_GENERIC");
-  const char* f = getenv("MM_KP_F32MFMA");
-  return kp_stream_supported(Q, E) && !(g && atoi(g)) && !(f && atoi(f));
+  return kp_stream_supported(Q, E) && !env().kp_generic && !env().kp_f32mfma;
 }
 
 // TKL stage 1 entry (called from tkl.hip): chunks [P,50,E] -> ps_out [P,20,Q,12]
@@ -1424,9 +1419,7 @@ int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, co
   a.qm.len = q_len;  // effective query lengths [B] (may be null): pair rows of later tokens are not written
   a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;
   a.d_doc_rows = 50; a.d_row0 = 5; a.chunk_slot = chunk_slot; a.C = C; a.ps_out = ps_out;
-  static int force_generic = -1;
-  if (force_generic < 0) force_generic = getenv("MM_KP_GENERIC") ? atoi(getenv("MM_KP_GENERIC")) : 0;
-  if (!force_generic && kp_stream_supported(Q, E)) return launch_stream<11, true>(a, stream);
+  if (!env().kp_generic && kp_stream_supported(Q, E)) return launch_stream<11, true>(a, stream);
   if (P > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "tkl: too many chunks for one launch");
   hipLaunchKernelGGL((kernel_pool_generic_kernel<11, true>), dim3((unsigned)P), dim3(64), 0, stream, a);
   return check_launch("kernel_pool_generic_kernel<TKL>");
@@ -1435,13 +1428,8 @@ int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, co
 template <int K>
 static int launch_k(const KpArgs& a0, hipStream_t stream) {
   KpArgs a = a0;
-  static int force_generic = -1, nbuf_env = 0;
-  if (force_generic < 0) {
-    force_generic = getenv("MM_KP_GENERIC") ? atoi(getenv("MM_KP_GENERIC")) : 0;
-    nbuf_env = getenv("MM_KP_NBUF") ? atoi(getenv("MM_KP_NBUF")) : 3;
-  }
+  const bool force_generic = env().kp_generic != 0;
   const bool stream_ok = !force_generic && a.Q <= 32 && (a.E == 100 || a.E == 200 || a.E == 300);
-  (void)nbuf_env;
   if (!force_generic && !stream_ok && kp128_supported(a.Q, a.D, a.E, a.dw != nullptr)) return kp128_launch(a, stream);
   if (a.dw) {  // gated (TK-Sparse); the gate vector of a document sits in LDS: D <= 4096 on the streaming path (LDS stays under 64 KB)
     if (stream_ok && a.D <= 4096) return launch_stream<K, false, true>(a, stream);

@@ -428,15 +428,6 @@ static void launch_mx(const KpArgs& a, const dim3 grid, int lds, hipStream_t str
   hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, KS, MX>), grid, dim3(64 * KS), lds, stream, a);
 }
 
-// MM_MAXSIM_F32_TERMS = 2 selects the two-term split (operand error 2^-17) for A/B runs; default: three terms
-static int maxsim_f32_terms() {
-  static const int terms = [] {
-    const char* s = getenv("MM_MAXSIM_F32_TERMS");
-    return (s && atoi(s) == 2) ? 2 : 3;
-  }();
-  return terms;
-}
-
 int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask dm, float* out, int64_t n_pairs,
                      int64_t pairs_per_query, int Q, int D, int E, hipStream_t stream) {
   KpArgs a{};
@@ -450,7 +441,7 @@ int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask d
   a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
   groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
   const dim3 grid((unsigned)groups);
-  const bool x3 = maxsim_f32_terms() == 3;
+  const bool x3 = env().maxsim_f32_terms == 3;  // MM_MAXSIM_F32_TERMS=2: two-term split (operand error 2^-17) for A/B runs
 #define MM_MX(NSL, KS) (x3 ? launch_mx<NSL, KS, 2>(a, grid, lds, stream) : launch_mx<NSL, KS, 1>(a, grid, lds, stream))
   switch (nsl) {
     case 1: MM_MX(1, 1); break;

@@ -596,27 +596,12 @@ static int validate(const void* q, const void* d, float* out, int64_t n_pairs, i
 
 // Measured on MI355X (profiles/r01_sweep_nbuf_wpc.log): one wavefront per SIMD (4 / CU) with a
 // 2-slot ring is the fastest point (6.9 TB/s); more wavefronts or deeper rings only add contention.
-static int g_stream_nbuf = 2;  // LDS ring depth of the roofline kernel (env MM_MAXSIM_NBUF)
-static int g_stream_wpc = 4;   // wavefronts per CU to launch (env MM_MAXSIM_WPC; 0 = what LDS allows)
-static int g_stream_nt = 1;    // non-temporal LDS-DMA (env MM_MAXSIM_NT)
-static int g_force_generic = 0;
-static bool g_env_read = false;
-static void read_env() {
-  if (g_env_read) return;
-  g_env_read = true;
-  if (const char* s = getenv("MM_MAXSIM_NBUF")) g_stream_nbuf = atoi(s);
-  if (const char* s = getenv("MM_MAXSIM_WPC")) g_stream_wpc = atoi(s);
-  if (const char* s = getenv("MM_MAXSIM_NT")) g_stream_nt = atoi(s);
-  if (const char* s = getenv("MM_MAXSIM_GENERIC")) g_force_generic = atoi(s);
-  if (g_stream_nbuf < 2) g_stream_nbuf = 2;
-  if (g_stream_nbuf > 4) g_stream_nbuf = 4;
-}
-
+// (defaults and their environment overrides: EnvCfg in mm_internal.h)
 template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT = 1>
 static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   MaxsimArgs a = a0;
   const int lds = NBUF * kBlkBytes;
-  int wpc = g_stream_wpc > 0 ? g_stream_wpc : (160 * 1024) / lds;
+  int wpc = env().maxsim_wpc > 0 ? env().maxsim_wpc : (160 * 1024) / lds;
   if (wpc > 16) wpc = 16;
   int64_t waves = (int64_t)kCUs * wpc;
   if (waves > a.n_pairs) waves = a.n_pairs;
@@ -628,12 +613,12 @@ static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
 
 template <int DT, int NSL, bool RAG>
 static int launch_stream_nsl(const MaxsimArgs& a, hipStream_t stream) {
-  const bool nt = g_stream_nt != 0;
+  const bool nt = env().maxsim_nt != 0;
   if constexpr (NSL <= 4) {
     if (a.Q > 32) return launch_stream<DT, 2, true, NSL, RAG, 2>(a, stream);  // two query tiles in registers
   }
   if (NSL == 1 && !RAG) {  // the tuning knobs are only instantiated for the headline shape
-    switch (g_stream_nbuf) {
+    switch (env().maxsim_nbuf) {
       case 3: return nt ? launch_stream<DT, 3, true, NSL, false>(a, stream) : launch_stream<DT, 3, false, NSL, false>(a, stream);
       case 4: return nt ? launch_stream<DT, 4, true, NSL, false>(a, stream) : launch_stream<DT, 4, false, NSL, false>(a, stream);
       default: return nt ? launch_stream<DT, 2, true, NSL, false>(a, stream) : launch_stream<DT, 2, false, NSL, false>(a, stream);
@@ -680,7 +665,6 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
                              const void* d_mask, int d_mask_kind, float* out, int64_t n_pairs,
                              int64_t pairs_per_query, int Q, int D, int E, int dtype, void* workspace,
                              size_t workspace_bytes, void* stream_) {
-  read_env();
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = validate(q, d, out, n_pairs, Q, D, E, dtype)) return e;
   if (pairs_per_query <= 0) return set_error(MM_EINVAL, "maxsim: pairs_per_query must be >= 1");
@@ -693,12 +677,12 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-  const bool stream_ok = !g_force_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
+  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
   // fp32 token vectors (ColBERT run with use_fp16 = False): the split-bf16 streaming kernel of kernel_pool128.hip
   // with the MaxSim epilogue
-  if (!g_force_generic && dtype == MM_F32 && kp128_maxsim_supported(Q, E)) {
+  if (!env().maxsim_generic && dtype == MM_F32 && kp128_maxsim_supported(Q, E)) {
     return kp128_maxsim_f32((const float*)q, (const float*)d, a.qm, a.dm, out, n_pairs, pairs_per_query, Q, D, E, stream);
   }
   return launch_generic(a, dtype, stream);
@@ -713,7 +697,6 @@ extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q
                                      const void* d_mask, int d_mask_kind, float* out, int64_t Bq, int64_t Bd,
                                      int Q, int D, int E, int dtype, int bug_compatible, void* workspace,
                                      size_t workspace_bytes, void* stream_) {
-  read_env();
   hipStream_t stream = (hipStream_t)stream_;
   if (Bq < 0 || Bd < 0) return set_error(MM_EINVAL, "maxsim_inbatch: negative batch");
   if (int e = validate(q, d, out, Bq * Bd, Q, D, E, dtype)) return e;
@@ -740,7 +723,6 @@ extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int
                                     const void* q_mask, int q_mask_kind, float* out, int64_t n_pairs,
                                     int64_t pairs_per_query, int Q, int E, int dtype, void* workspace,
                                     size_t workspace_bytes, void* stream_) {
-  read_env();
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = validate(q, tokens, out, n_pairs, Q, 1, E, dtype)) return e;
   if (!doc_begin || !doc_end) return set_error(MM_EINVAL, "maxsim_ragged: null document range pointer");
@@ -753,7 +735,7 @@ extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
-  const bool stream_ok = !g_force_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
+  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, true>(a, stream) : launch_stream_cfg<MM_F16, true>(a, stream);
   return launch_generic(a, dtype, stream);

@@ -20,6 +20,22 @@ constexpr int kCUs = 256;  // MI355X
 
 int set_error(int code, const char* fmt, ...);
 
+// Tuning / A-B knobs read from the environment ONCE per process.  env() returns a function-local static const
+// (C++11 guarantees thread-safe initialisation), so the library holds no unsynchronised mutable state: the
+// operators are called concurrently from nn.DataParallel's per-GPU threads (matchmaker/train.py:201).
+struct EnvCfg {
+  int maxsim_nbuf = 2;      // MM_MAXSIM_NBUF: LDS ring depth of the MaxSim roofline kernel (2..4)
+  int maxsim_wpc = 4;       // MM_MAXSIM_WPC: wavefronts per CU to launch (0 = what LDS allows)
+  int maxsim_nt = 1;        // MM_MAXSIM_NT: non-temporal LDS-DMA
+  int maxsim_generic = 0;   // MM_MAXSIM_GENERIC: force the generic MaxSim kernel
+  int maxsim_f32_terms = 3; // MM_MAXSIM_F32_TERMS: 2 = two-term split for fp32 MaxSim (A/B), default three terms
+  int kp_generic = 0;       // MM_KP_GENERIC: force the generic pooling kernel
+  int kp_f32mfma = 0;       // MM_KP_F32MFMA: exact-f32 MFMA pooling kernel instead of split-bf16
+  int tkl_fused = 0;        // MM_TKL_FUSED: fused TKL stages 1 + 2
+  int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
+};
+const EnvCfg& env();
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(MM_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

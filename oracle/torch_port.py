@@ -83,3 +83,56 @@ def idcm_sampler_scores(query_ctx, document_ctx, query_mask, document_mask, mu, 
     kernel_res = torch.log(torch.clamp(torch.sum(kernel_activations, 2) * alpha, min=1e-4)) * \
         query_mask.unsqueeze(-1)                                                                # :185
     return torch.nn.functional.linear(torch.sum(kernel_res, 1), weight, bias)                   # :186  [P,1]
+
+
+def tkl_scoring(query_ctx, centre, centre_mask, packed_indices, batch_size, query_mask, p, saturation="embedding"):
+    """TKL_sigir20.forward after the contextualiser — matchmaker/models/published/sigir20_tkl.py:180-286, the same
+    torch ops on CPU tensors (bench.py's CPU leg for BASELINE configs[2]; pinned on tests/golden/tkl_*.npz).
+
+    query_ctx [B,Q,E] (contextualised, times its mask, :306); centre [P,40,E] / centre_mask [P,40] = the packed chunks'
+    centre tokens (:174-175); packed_indices [B*C] bool (:159); p: float tensors mu, sigma, dense_w [K], sat_w1..3 [2],
+    sat_b1..3, ln_w, ln_b [2], emb_reduce_w [E], kernel_mult0 [K], chunk_scoring [15] (np_oracle.tkl_params_from_state).
+    Returns (score [B], window scores [B,W] with 0 for empty windows)."""
+    Q, K = query_ctx.shape[1], p["mu"].numel()
+    chunk_pieces = packed_indices.shape[0] // batch_size
+    packed_query = query_ctx.unsqueeze(1).expand(-1, chunk_pieces, -1, -1).reshape(-1, Q, query_ctx.shape[-1])[packed_indices]  # :180
+    cos = cosine_matrix(packed_query, centre).unsqueeze(-1)                                                   # :184, :192
+    raw = torch.exp(- torch.pow(cos - p["mu"].view(1, 1, 1, -1), 2) / (2 * torch.pow(p["sigma"].view(1, 1, 1, -1), 2)))  # :193
+    masked = raw * centre_mask.unsqueeze(1).unsqueeze(-1)                                                     # :194
+    act = torch.zeros((packed_indices.shape[0], Q, centre.shape[1], K), dtype=centre.dtype)                   # :196
+    act[packed_indices] = masked                                                                              # :197
+    act = act.transpose(1, 2).reshape(batch_size, -1, Q, K).transpose(2, 1)                                   # :199
+    if act.shape[2] < 30:                                                                                     # :206-207
+        act = torch.nn.functional.pad(act, (0, 0, 0, 30 - act.shape[2]))
+    unrolled = act.unfold(2, 30, 2).transpose(-1, -2)                                                         # :209
+    lengths = torch.sum(unrolled.sum(dim=-1) != 0, dim=-1)                                                    # :210
+    per_kernel_query = torch.sum(unrolled, -2)                                                                # :211
+    lin = lambda x, w, b: torch.nn.functional.linear(x, w.view(1, 2), b.view(1))
+    if saturation == "embedding":                                                                             # :224-234
+        infl = torch.cat([torch.nn.functional.linear(query_ctx, p["emb_reduce_w"].view(1, -1)).expand_as(lengths).unsqueeze(-1),
+                          lengths.float().unsqueeze(-1)], dim=-1)
+        infl = torch.nn.functional.layer_norm(infl, (2,), p["ln_w"], p["ln_b"], 1e-5)
+        sat = lin(infl, p["sat_w1"], p["sat_b1"]) * (torch.clamp(per_kernel_query, min=1e-10) ** (1 / lin(infl, p["sat_w2"], p["sat_b2"]))) \
+            - lin(infl, p["sat_w3"], p["sat_b3"])
+    else:                                                                                                     # :245-246
+        sat = torch.log(torch.clamp(per_kernel_query * p["kernel_mult0"].view(1, 1, 1, -1), min=1e-10))
+    sat = sat * query_mask.unsqueeze(-1).unsqueeze(-1) * (lengths > 0).float().unsqueeze(-1)                  # :248
+    score = torch.nn.functional.linear(torch.sum(sat, 1), p["dense_w"].view(1, -1)).squeeze(-1)               # :249-252
+    if score.shape[1] < 3:                                                                                    # :254-255
+        score = torch.nn.functional.pad(score, (0, 3 - score.shape[1]))
+    score[score == 0] = -9900                                                                                 # :257
+    orig = score
+    top = torch.zeros((orig.shape[0], 3), dtype=torch.long)
+    work = orig.clone()
+    r = torch.arange(work.shape[1])
+    for c in range(3):                                                                                        # :268-273
+        best = torch.argmax(work, dim=1)
+        top[:, c] = best
+        work[torch.abs(r - best.unsqueeze(-1)) < 30 / 2] = -10001 - c
+    nb = torch.cat([top, top - 1, top + 1, top - 2, top + 2], dim=1)                                          # :276
+    nb[nb < 0] = 0
+    nb[nb >= orig.shape[1]] = orig.shape[1] - 1
+    vals = torch.gather(orig, 1, nb)                                                                          # :280-281
+    vals[vals <= -9900] = 0                                                                                   # :282
+    orig[orig <= -9900] = 0                                                                                   # :284
+    return (vals * p["chunk_scoring"].view(1, -1)).sum(dim=1), orig                                           # :286

@@ -53,6 +53,12 @@ def main():
             wr = c.get("WRITE_SIZE", {}).get("avg_per_dispatch", 0.0) * 1024
             c["_hbm_traffic_bytes_per_dispatch"] = {"read_corrected": rd, "write": wr, "total": rd + wr,
                                                     "note": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024"}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]["avg_per_dispatch"] > 0:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a busy cycle is counted per SIMD (4 x 256 of them)
+            cyc = c["GRBM_GUI_ACTIVE"]["avg_per_dispatch"] / 8.0
+            c["_mfma_busy_frac"] = {"total": c["SQ_VALU_MFMA_BUSY_CYCLES"]["avg_per_dispatch"] / (1024.0 * cyc),
+                                    "kernel_cycles": cyc,
+                                    "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1)[:3000])
