@@ -19,7 +19,8 @@
 //
 // One workgroup (256 threads) per pair, fp32 VALU throughout: training batches are tens of pairs, so
 // this is a correctness path — what matters is that loss.backward() stays on the device without a
-// [B,Q,D,K] tensor.  Pair-per-row layout (the one train.py feeds: neuralIR_encoder.py:86-87).
+// [B,Q,D,K] tensor, for ANY document length (the [Q,D] tiles are swept DT positions at a time).
+// Pair-per-row layout (the one train.py feeds: neuralIR_encoder.py:86-87).
 #include "mm_internal.h"
 
 namespace mm {
@@ -53,67 +54,106 @@ __device__ __forceinline__ bool mask_bit(const PackedMask& m, int64_t row, int w
   return true;
 }
 
-__global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a) {
+// LDS: cosine + gradient tiles [Q][DT] (DT document positions at a time) + per-pair vectors.  Documents longer than
+// one tile (max_doc_length 2000 in tk.yaml-style training configs) take two sweeps over their tiles: the first pools
+// the kernels (pkq needs every position), the second recomputes each tile's cosines and finishes the gradients.
+__host__ __device__ inline size_t kp_bwd_lds_bytes(int Q, int DT) {
+  return ((size_t)2 * Q * DT + (size_t)4 * Q * kBK + 5 * (size_t)Q + 5 * (size_t)DT) * 4;
+}
+
+__global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a, const int DT) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t pair = blockIdx.x;
   const int Q = a.Q, D = a.D, E = a.E, K = a.K;
-  float* C = (float*)smem;            // [Q][D] cosines
-  float* G = C + Q * D;               // [Q][D] d loss / d c
-  float* A = G + Q * D;               // [Q][K]
-  float* rq = A + Q * kBK;            // [Q] 1/(|q|+tiny)
-  float* nq = rq + Q;                 // [Q] |q|
-  float* rd = nq + Q;                 // [D]
-  float* nd = rd + D;                 // [D]
-  float* sq = nd + D;                 // [Q] sum_j G c
-  float* td = sq + Q;                 // [D] sum_i G c
-  float* qmf = td + D;                // [Q] 0/1
-  float* dmf = qmf + Q;               // [D] 0/1
-  float* pw = dmf + D;                // [Q][K] per-(i,k) term of grad_w
+  float* C = (float*)smem;            // [Q][DT] cosines of the current tile
+  float* G = C + Q * DT;              // [Q][DT] d loss / d c
+  float* A = G + Q * DT;              // [Q][K]
+  float* PK = A + Q * kBK;            // [Q][K] pooled kernels, accumulated over the tiles
+  float* pw = PK + Q * kBK;           // [Q][K] per-(i,k) term of grad_w
   float* pa = pw + Q * kBK;           // [Q][K] per-(i,k) term of grad_alpha
+  float* rq = pa + Q * kBK;           // [Q] 1/(|q|+tiny)
+  float* nq = rq + Q;                 // [Q] |q|
+  float* sq = nq + Q;                 // [Q] sum_j G c (over all tiles)
+  float* qmf = sq + Q;                // [Q] 0/1
+  float* rd = qmf + Q;                // [DT]
+  float* nd = rd + DT;                // [DT]
+  float* td = nd + DT;                // [DT] sum_i G c
+  float* dmf = td + DT;               // [DT] mask x gate
+  float* dmb = dmf + DT;              // [DT] mask alone (0/1)
   const float* qb = a.q + pair * Q * (int64_t)E;
   const float* db = a.d + pair * D * (int64_t)E;
+  float* gq = a.gq + pair * Q * (int64_t)E;
+  float* gd = a.gd + pair * D * (int64_t)E;
   const float g = a.go[pair];
   const int qwords = (Q + 31) >> 5, dwords = (D + 31) >> 5;
+  const bool one_tile = DT >= D;
 
-  // 1. norms and masks
-  for (int row = wave; row < Q + D; row += 4) {
-    const float* x = row < Q ? qb + (int64_t)row * E : db + (int64_t)(row - Q) * E;
+  // query norms and mask
+  for (int row = wave; row < Q; row += 4) {
+    const float* x = qb + (int64_t)row * E;
     float ss = 0.0f;
     for (int e = lane; e < E; e += 64) ss += x[e] * x[e];
     ss = wave_sum(ss);
     if (lane == 0) {
       const float n = sqrtf(ss);
-      if (row < Q) { nq[row] = n; rq[row] = 1.0f / (n + 1e-13f); qmf[row] = mask_bit(a.qm, pair, qwords, row, Q) ? 1.0f : 0.0f; }
-      else {
-        const int j = row - Q;
-        nd[j] = n; rd[j] = 1.0f / (n + 1e-13f);
+      nq[row] = n; rq[row] = 1.0f / (n + 1e-13f); qmf[row] = mask_bit(a.qm, pair, qwords, row, Q) ? 1.0f : 0.0f;
+      sq[row] = 0.0f;
+    }
+  }
+  for (int idx = tid; idx < Q * kBK; idx += 256) PK[idx] = 0.0f;
+  __syncthreads();
+
+  // document-tile norms, masks and cosines (same factor order as the forward: (dot * rq) * rd)
+  auto load_tile = [&](int j0, int nj) {
+    for (int row = wave; row < nj; row += 4) {
+      const int j = j0 + row;
+      const float* x = db + (int64_t)j * E;
+      float ss = 0.0f;
+      for (int e = lane; e < E; e += 64) ss += x[e] * x[e];
+      ss = wave_sum(ss);
+      if (lane == 0) {
+        const float n = sqrtf(ss);
+        nd[row] = n; rd[row] = 1.0f / (n + 1e-13f);
         const float gate = a.dw ? fmaxf(a.dw[pair * D + j], 0.0f) : 1.0f;   // dmf = mask x gate
-        dmf[j] = mask_bit(a.dm, pair, dwords, j, D) ? gate : 0.0f;
+        const bool real = mask_bit(a.dm, pair, dwords, j, D);
+        dmb[row] = real ? 1.0f : 0.0f;
+        dmf[row] = real ? gate : 0.0f;
       }
     }
+    __syncthreads();
+    for (int idx = tid; idx < Q * nj; idx += 256) {
+      const int i = idx / nj, jj = idx - i * nj;
+      const float* x = qb + (int64_t)i * E;
+      const float* y = db + (int64_t)(j0 + jj) * E;
+      float dot = 0.0f;
+      for (int e = 0; e < E; ++e) dot += x[e] * y[e];
+      C[i * DT + jj] = (dot * rq[i]) * rd[jj];
+    }
+    __syncthreads();
+  };
+
+  // ---- sweep 1: pooled kernels pkq_ik = sum_j dmf_j e_ijk -------------------------------------------------
+  for (int j0 = 0; j0 < D; j0 += DT) {
+    const int nj = D - j0 < DT ? D - j0 : DT;
+    load_tile(j0, nj);
+    for (int idx = tid; idx < Q * K; idx += 256) {      // (i, k) is owned by one thread across the tiles
+      const int i = idx / K, k = idx - i * K;
+      const float mu = a.mu[k], sg = a.sigma[k];
+      const float c2 = -1.0f / (2.0f * sg * sg);
+      float pk = 0.0f;
+      for (int jj = 0; jj < nj; ++jj) {
+        const float t = C[i * DT + jj] - mu;
+        pk += dmf[jj] * __expf(t * t * c2);
+      }
+      PK[i * kBK + k] += pk;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // 2. cosine matrix (same factor order as the forward: (dot * rq) * rd)
-  for (int idx = tid; idx < Q * D; idx += 256) {
-    const int i = idx / D, j = idx - i * D;
-    const float* x = qb + (int64_t)i * E;
-    const float* y = db + (int64_t)j * E;
-    float dot = 0.0f;
-    for (int e = 0; e < E; ++e) dot += x[e] * y[e];
-    C[idx] = (dot * rq[i]) * rd[j];
-  }
-  __syncthreads();
-  // 3. pooled kernels -> A, parameter gradients of this pair
+  // A, parameter gradients of this pair
   for (int idx = tid; idx < Q * K; idx += 256) {
     const int i = idx / K, k = idx - i * K;
-    const float mu = a.mu[k], sg = a.sigma[k];
-    const float c2 = -1.0f / (2.0f * sg * sg);
-    float pk = 0.0f;
-    for (int j = 0; j < D; ++j) {
-      const float t = C[i * D + j] - mu;
-      pk += dmf[j] * __expf(t * t * c2);
-    }
+    const float pk = PK[i * kBK + k];
     const float al = a.alpha[k];
     const bool live = al * pk >= a.clamp_min;
     A[i * kBK + k] = live ? g * qmf[i] * a.w[k] / pk : 0.0f;
@@ -130,70 +170,79 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a)
     a.gw[pair * K + tid] = g * sw;
     a.galpha[pair * K + tid] = g * sa;
   }
-  __syncthreads();
-  // 4. G = d loss / d c
-  for (int idx = tid; idx < Q * D; idx += 256) {
-    const int i = idx / D, j = idx - i * D;
-    const float c = C[idx];
-    float s = 0.0f;
-    if (dmf[j] != 0.0f) {
-      for (int k = 0; k < K; ++k) {
-        const float sg = a.sigma[k];
-        const float t = c - a.mu[k];
-        const float inv = 1.0f / (sg * sg);
-        s += A[i * kBK + k] * __expf(-0.5f * t * t * inv) * (-t * inv);
-      }
-    }
-    G[idx] = s * dmf[j];
-  }
-  __syncthreads();
-  // 4b. gradient of the gate: sum_ik A_ik e_ijk on real tokens whose gate is open (relu'(x) = 0 at x <= 0 is
-  // the caller's chain rule; a closed gate still gets the gradient of the product, as autograd gives it)
-  if (a.gdw) {
-    for (int j = tid; j < D; j += 256) {
+
+  // ---- sweep 2: G = d loss / d c per tile, gate gradient, grad_d (complete per tile), grad_q (accumulated) --
+  for (int j0 = 0; j0 < D; j0 += DT) {
+    const int nj = D - j0 < DT ? D - j0 : DT;
+    if (!one_tile) load_tile(j0, nj);       // a single tile is still resident from sweep 1
+    for (int idx = tid; idx < Q * nj; idx += 256) {
+      const int i = idx / nj, jj = idx - i * nj;
+      const float c = C[i * DT + jj];
       float s = 0.0f;
-      if (mask_bit(a.dm, pair, dwords, j, D)) {
-        for (int i = 0; i < Q; ++i) {
-          const float c = C[i * D + j];
-          for (int k = 0; k < K; ++k) {
-            const float sg = a.sigma[k];
-            const float t = c - a.mu[k];
-            s += A[i * kBK + k] * __expf(-0.5f * t * t / (sg * sg));
-          }
+      if (dmf[jj] != 0.0f) {
+        for (int k = 0; k < K; ++k) {
+          const float sg = a.sigma[k];
+          const float t = c - a.mu[k];
+          const float inv = 1.0f / (sg * sg);
+          s += A[i * kBK + k] * __expf(-0.5f * t * t * inv) * (-t * inv);
         }
       }
-      a.gdw[pair * D + j] = s;
+      G[i * DT + jj] = s * dmf[jj];
     }
+    __syncthreads();
+    // gradient of the gate: sum_ik A_ik e_ijk on real tokens (relu'(x) = 0 at x <= 0 is the caller's chain rule;
+    // a closed gate still gets the gradient of the product, as autograd gives it)
+    if (a.gdw) {
+      for (int jj = tid; jj < nj; jj += 256) {
+        float s = 0.0f;
+        if (dmb[jj] != 0.0f) {
+          for (int i = 0; i < Q; ++i) {
+            const float c = C[i * DT + jj];
+            for (int k = 0; k < K; ++k) {
+              const float sg = a.sigma[k];
+              const float t = c - a.mu[k];
+              s += A[i * kBK + k] * __expf(-0.5f * t * t / (sg * sg));
+            }
+          }
+        }
+        a.gdw[pair * D + j0 + jj] = s;
+      }
+    }
+    // sum_j G c (per query token, over all tiles) and sum_i G c (per document token)
+    for (int i = tid; i < Q; i += 256) {
+      float s = 0.0f;
+      for (int jj = 0; jj < nj; ++jj) s += G[i * DT + jj] * C[i * DT + jj];
+      sq[i] += s;
+    }
+    for (int jj = tid; jj < nj; jj += 256) {
+      float s = 0.0f;
+      for (int i = 0; i < Q; ++i) s += G[i * DT + jj] * C[i * DT + jj];
+      td[jj] = s;
+    }
+    __syncthreads();
+    // grad_q: the sum over this tile's document tokens (element idx is owned by one thread across the tiles)
+    for (int idx = tid; idx < Q * E; idx += 256) {
+      const int i = idx / E, e = idx - i * E;
+      float s = j0 == 0 ? 0.0f : gq[idx];
+      for (int jj = 0; jj < nj; ++jj) s += G[i * DT + jj] * rd[jj] * db[(int64_t)(j0 + jj) * E + e];
+      gq[idx] = s;
+    }
+    // grad_d of this tile's rows
+    for (int idx = tid; idx < nj * E; idx += 256) {
+      const int jj = idx / E, e = idx - jj * E;
+      float s = 0.0f;
+      for (int i = 0; i < Q; ++i) s += G[i * DT + jj] * rq[i] * qb[(int64_t)i * E + e];
+      const float x = db[(int64_t)(j0 + jj) * E + e];
+      const float self = nd[jj] > 0.0f ? td[jj] * x / nd[jj] : 0.0f;
+      gd[(int64_t)(j0 + jj) * E + e] = rd[jj] * (s - self);
+    }
+    __syncthreads();
   }
-  // 5. sum_j G c (per query token) and sum_i G c (per document token)
-  for (int i = tid; i < Q; i += 256) {
-    float s = 0.0f;
-    for (int j = 0; j < D; ++j) s += G[i * D + j] * C[i * D + j];
-    sq[i] = s;
-  }
-  for (int j = tid; j < D; j += 256) {
-    float s = 0.0f;
-    for (int i = 0; i < Q; ++i) s += G[i * D + j] * C[i * D + j];
-    td[j] = s;
-  }
-  __syncthreads();
-  // 6. grad_q
-  float* gq = a.gq + pair * Q * (int64_t)E;
+  // grad_q: the norm term needs sum_j G c over the whole document
   for (int idx = tid; idx < Q * E; idx += 256) {
-    const int i = idx / E, e = idx - i * E;
-    float s = 0.0f;
-    for (int j = 0; j < D; ++j) s += G[i * D + j] * rd[j] * db[(int64_t)j * E + e];
+    const int i = idx / E;
     const float self = nq[i] > 0.0f ? sq[i] * qb[idx] / nq[i] : 0.0f;
-    gq[idx] = rq[i] * (s - self);
-  }
-  // 7. grad_d
-  float* gd = a.gd + pair * D * (int64_t)E;
-  for (int idx = tid; idx < D * E; idx += 256) {
-    const int j = idx / E, e = idx - j * E;
-    float s = 0.0f;
-    for (int i = 0; i < Q; ++i) s += G[i * D + j] * rq[i] * qb[(int64_t)i * E + e];
-    const float self = nd[j] > 0.0f ? td[j] * db[idx] / nd[j] : 0.0f;
-    gd[idx] = rd[j] * (s - self);
+    gq[idx] = rq[i] * (gq[idx] - self);
   }
 }
 
@@ -220,8 +269,15 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
   if (K > kBK) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: K=%d kernels (max %d)", K, kBK);
   if (n_pairs == 0) return MM_OK;
   if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: too many pairs for one launch");
-  const size_t lds = ((size_t)2 * Q * D + (size_t)3 * Q * kBK + 4 * (size_t)Q + 4 * (size_t)D) * 4;
-  if (lds > 160 * 1024) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: Q x D = %d x %d exceeds the LDS tile", Q, D);
+  // document tile: the whole document when it fits 150 KiB of LDS, else the largest multiple of 32 positions that does
+  int DT = D;
+  if (kp_bwd_lds_bytes(Q, DT) > 150 * 1024) {
+    const size_t fixed = ((size_t)4 * Q * kBK + 5 * (size_t)Q) * 4;
+    if (fixed + (size_t)(2 * Q + 5) * 32 * 4 > 150 * 1024)
+      return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: Q = %d query tokens exceed the LDS tile", Q);
+    DT = (int)((150 * 1024 - fixed) / ((size_t)(2 * Q + 5) * 4)) & ~31;
+  }
+  const size_t lds = kp_bwd_lds_bytes(Q, DT);
   KpBwdArgs a{};
   a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w; a.go = grad_out;
   a.dw = d_gate; a.gdw = grad_gate; a.clamp_min = clamp_min;
@@ -232,7 +288,7 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kernel_pool_bwd_kernel, dim3((unsigned)n_pairs), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kernel_pool_bwd_kernel, dim3((unsigned)n_pairs), dim3(256), lds, stream, a, DT);
   return check_launch("kernel_pool_bwd_kernel");
 }
 

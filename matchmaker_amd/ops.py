@@ -39,6 +39,18 @@ def _emb(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _pad_rows(q: torch.Tensor, d: torch.Tensor, mult: int):
+    """Token rows must be 16-byte multiples for the native loads.  Zero columns change neither dot products nor
+    norms, so other widths (KNRM on 50-d GloVe, colbert_compression_dim 100, ...) are padded up — a copy, taken
+    only for such widths.  Returns (q, d, padded E)."""
+    E = q.shape[-1]
+    Ep = (E + mult - 1) // mult * mult
+    if Ep == E:
+        return q, d, E
+    pad = (0, Ep - E)
+    return torch.nn.functional.pad(q, pad), torch.nn.functional.pad(d, pad), Ep
+
+
 def _mask(m: Optional[torch.Tensor], rows: int, L: int, name: str):
     """-> (tensor kept alive, pointer, kind)"""
     if m is None:
@@ -90,6 +102,7 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
     out = torch.empty(B, dtype=torch.float32, device=dev)
     if B == 0:
         return out
+    q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
     with torch.cuda.device(dev):
         wsb = L.mm_maxsim_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
@@ -129,6 +142,12 @@ def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor
     out = torch.empty(B, dtype=torch.float32, device=dev)
     if B == 0:
         return out
+    if not torch.cuda.is_current_stream_capturing():
+        # a stale doc_infos range (another store's, or past the token matrix) would make the LDS-DMA stream read
+        # out of bounds silently: one small D2H per call, skipped under graph capture
+        lo, hi = int(doc_begin.min()), int(torch.maximum(doc_begin, doc_end).max())
+        if lo < 0 or hi > tokens.shape[0]:
+            raise NativeError(f"maxsim_ragged: document ranges [{lo}, {hi}) leave the {tokens.shape[0]}-row token matrix")
     with torch.cuda.device(dev):
         wsb = L.mm_maxsim_ragged_workspace_bytes(B, pairs_per_query, Q, qk)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
@@ -157,6 +176,8 @@ def maxsim_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor],
     qm, qp, qk = _mask(q_mask, B, Q, "q_mask")
     dm, dp, dk = _mask(d_mask, B, D, "d_mask")
     L = _lib.lib()
+    E0 = E
+    q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
     gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
     gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
     if B:
@@ -167,6 +188,8 @@ def maxsim_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor],
                                  gd.data_ptr(), B, Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None,
                                  wsb, _stream(dev))
         _lib.check(rc, "mm_maxsim_bwd")
+    if E != E0:
+        gq, gd = gq[..., :E0].contiguous(), gd[..., :E0].contiguous()
     return gq, gd
 
 
@@ -186,6 +209,9 @@ def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Ten
     dm, dp, dk = _mask(d_mask, Bd, D, "d_mask")
     L = _lib.lib()
     out = torch.empty((Bq, Bd), dtype=torch.float32, device=dev)
+    if Bq == 0 or Bd == 0:
+        return out
+    q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
     with torch.cuda.device(dev):
         wsb = L.mm_maxsim_inbatch_workspace_bytes(Bq, Bd, Q, D, qk, dk)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
@@ -243,6 +269,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     out = torch.empty(B, dtype=torch.float32, device=dev)
     pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
     if B:
+        q, d, E = _pad_rows(q, d, 4)
         with torch.cuda.device(dev):
             wsb = L.mm_kernel_pool_workspace_bytes(max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
@@ -289,6 +316,8 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
     qm, qp, qk = _mask(q_mask, B, Q, "q_mask")
     dm, dp, dk = _mask(d_mask, B, D, "d_mask")
     L = _lib.lib()
+    E0 = E
+    q, d, E = _pad_rows(q, d, 4)
     gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
     gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
     ga = torch.zeros((B, K), dtype=torch.float32, device=dev)
@@ -306,6 +335,8 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
                                          gg.data_ptr() if gg is not None else None, ga.data_ptr(), gw.data_ptr(),
                                          B, Q, D, E, K, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
         _lib.check(rc, "mm_kernel_pool_ex_bwd")
+    if E != E0:
+        gq, gd = gq[..., :E0].contiguous(), gd[..., :E0].contiguous()
     if gate is not None:
         return gq, gd, ga.sum(0), gw.sum(0), gg
     return gq, gd, ga.sum(0), gw.sum(0)

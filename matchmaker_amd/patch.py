@@ -18,7 +18,6 @@ _TABLE = [
     ("matchmaker.models.published.ecai20_tk", "ECAI20_TK", "matchmaker_amd.tk", "ECAI20_TK"),
     ("matchmaker.models.published.sigir20_tkl", "TKL_sigir20", "matchmaker_amd.tkl", "TKL_sigir20"),
     ("matchmaker.models.published.cikm20_tk_sparse", "CIKM20_TK_Sparse", "matchmaker_amd.tk_sparse", "CIKM20_TK_Sparse"),
-    ("matchmaker.models.published.sigir21_idcm", "IDCM", "matchmaker_amd.idcm", "IDCM"),
     ("matchmaker.models.knrm", "KNRM", "matchmaker_amd.knrm", "KNRM"),
     ("matchmaker.models.conv_knrm", "Conv_KNRM", "matchmaker_amd.conv_knrm", "Conv_KNRM"),
 ]

@@ -34,7 +34,13 @@ class FlatIPIndexer:
         self._topk = topk_fn if topk_fn is not None else ops.dot_topk
         self._merge = merge_fn if merge_fn is not None else ops.topk_merge
         self.token_dim = config["token_dim"]
-        self.use_fp16 = config.get("faiss_use_fp16", True)   # the native index always stores 16-bit vectors
+        self.use_fp16 = config.get("faiss_use_fp16", True)
+        if not self.use_fp16:
+            # faiss keeps fp32 vectors AND fp32 queries when useFloat16 is off (faiss_indices.py:58-61); this index
+            # stores fp16 vectors and rounds the queries to fp16 as well, so near-tie rankings could differ from
+            # an fp32 IndexFlatIP.  Refuse instead of silently changing the arithmetic.
+            raise ops.NativeError("FlatIPIndexer stores float16 vectors and rounds queries to float16 (faiss "
+                                  "useFloat16 semantics): set faiss_use_fp16: True, or keep faiss for an fp32 index")
         self.dtype = torch.float16
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())  # noqa: E501
         self.group = group

@@ -57,6 +57,11 @@ class TKL_sigir20(nn.Module):
 
     @staticmethod
     def from_config(config, word_embeddings_out_dim):      # sigir20_tkl.py:17-29
+        if len(config["tk_kernels_mu"]) != 11:
+            raise NativeError(f"TKL: the native window kernels are built for the reference's 11 RBF kernels (tkl.yaml), "
+                              f"got {len(config['tk_kernels_mu'])}")
+        if word_embeddings_out_dim % 4:
+            raise NativeError(f"TKL: embedding width {word_embeddings_out_dim} is not a multiple of 4 floats (16-byte rows)")
         return TKL_sigir20(word_embeddings_out_dim,
                            kernels_mu=config["tk_kernels_mu"],
                            kernels_sigma=config["tk_kernels_sigma"],

@@ -157,10 +157,16 @@ def test_config2_full_size_properties_and_rank_order():
 def test_errors_are_loud():
     from matchmaker_amd import ops, NativeError
     dev = util.require_gpu()
-    q = torch.zeros(1, 4, 12, dtype=torch.bfloat16, device=dev)   # E=12: rows not 16-byte multiples
-    d = torch.zeros(2, 5, 12, dtype=torch.bfloat16, device=dev)
+    q = torch.zeros(1, 4, 16, dtype=torch.bfloat16, device=dev)
+    d = torch.zeros(2, 5, 16, dtype=torch.bfloat16, device=dev)
     with pytest.raises(NativeError):
-        ops.maxsim(q, d, pairs_per_query=2)
+        ops.maxsim(q, d.half(), pairs_per_query=2)                   # dtype mismatch
+    # the C ABI itself refuses rows that are not 16-byte multiples (ops.maxsim pads them before the call)
+    from matchmaker_amd import _lib
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    rc = _lib.lib().mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), None, _lib.MASK_NONE, None, _lib.MASK_NONE, out.data_ptr(), 2, 2,
+                                  4, 5, 12, _lib.MM_BF16, None, 0, torch.cuda.current_stream(dev).cuda_stream)
+    assert rc != 0 and "16-byte" in _lib.lib().mm_last_error().decode()
     with pytest.raises(NativeError):
         ops.maxsim(q.cpu(), d.cpu(), pairs_per_query=2)              # no CPU fallback
     with pytest.raises(NativeError):
@@ -195,3 +201,29 @@ def test_queries_longer_than_one_tile(dtype, tol, Q, D, E, ppq):
     np.testing.assert_allclose(out, ref, atol=tol, rtol=1e-4)
     out2 = ops.maxsim(q.to(dev), d.to(dev), None, None, pairs_per_query=ppq).cpu().numpy()
     np.testing.assert_allclose(out2, O.maxsim_unmasked(q.float().numpy()[qi], d.float().numpy()), atol=tol, rtol=1e-4)
+
+
+def test_widths_that_are_not_16_byte_rows_are_zero_padded():
+    """colbert_compression_dim = 100 (fp16 rows of 200 B) and 50-d fp32 vectors: the host pads the width with zero
+    columns (no effect on dot products), instead of failing where the reference runs; all-pairs with an empty side
+    returns an empty matrix."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(100)
+    for dtype, E, tol in ((torch.float16, 100, util.TOL_BF16), (torch.float32, 50, util.TOL_FP32), (torch.bfloat16, 36, util.TOL_BF16)):
+        q = (torch.randn(2, 9, E, generator=g) / E ** 0.5).to(dtype)
+        d = (torch.randn(6, 41, E, generator=g) / E ** 0.5).to(dtype)
+        dl = torch.tensor([41, 3, 0, 17, 40, 1])
+        out = ops.maxsim(q.to(dev), d.to(dev), None, dl.to(dev), pairs_per_query=3).cpu().numpy()
+        qi = np.arange(6) // 3
+        ref = O.maxsim_paired(q.float().numpy()[qi], d.float().numpy(), np.ones((6, 9)), (np.arange(41)[None] < dl.numpy()[:, None]))
+        np.testing.assert_allclose(out, ref, atol=tol)
+        inb = ops.maxsim_inbatch(q.to(dev), None, d.to(dev), None).cpu().numpy()
+        np.testing.assert_allclose(inb, O.maxsim_inbatch(q.float().numpy(), np.ones((2, 9)), d.float().numpy(), np.ones((6, 41))), atol=tol)
+        gq, gd = ops.maxsim_bwd(q[qi].to(dev), d.to(dev), None, dl.to(dev), torch.ones(6, device=dev))
+        assert gq.shape == (6, 9, E) and gd.shape == (6, 41, E)
+    e = ops.maxsim_inbatch(torch.zeros(0, 4, 16, device=dev), None, torch.zeros(3, 5, 16, device=dev), None)
+    assert e.shape == (0, 3)
+    with pytest.raises(ops.NativeError):          # a document range past the token matrix is refused, not read
+        ops.maxsim_ragged(torch.zeros(1, 4, 128, dtype=torch.bfloat16, device=dev), torch.zeros(10, 128, dtype=torch.bfloat16, device=dev),
+                          torch.tensor([0, 8], device=dev), torch.tensor([5, 12], device=dev), None, pairs_per_query=2)

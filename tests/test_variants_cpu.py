@@ -75,7 +75,8 @@ def _oracle_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, clamp_min=1e-
 
 @pytest.mark.parametrize("fname,ctx_kind", [("idcm_ck.npz", "ck"), ("idcm_ck_small.npz", "ck-small")])
 def test_idcm_host_logic_and_sampler_oracle_match_reference_golden(monkeypatch, fname, ctx_kind):
-    from matchmaker_amd import idcm, ops
+    from matchmaker_amd import ops
+    from tests import idcm_host_fixture as idcm
     g = util.load(fname)
     m = idcm.IDCM(_tiny_distilbert(), sample_n=2, sample_context=ctx_kind, top_k_chunks=2, chunk_size=50, overlap=7,
                   padding_idx=0, sample_train_type="mseloss")
@@ -170,7 +171,8 @@ def test_idcm_dropin_equals_the_live_reference_class_for_every_sampler(monkeypat
     """No fixture for the "tk" sampler (its Transformer weights are 3.5 MB): here the REAL IDCM runs next to the
     drop-in on the same state_dict and inputs (CPU, oracle in the native operator's place)."""
     from oracle import ref_harness as R
-    from matchmaker_amd import idcm, ops
+    from matchmaker_amd import ops
+    from tests import idcm_host_fixture as idcm
     torch.manual_seed(7)
     ref = R.make_idcm(_tiny_distilbert(), sample_n=3, sample_context=ctx_kind, top_k_chunks=3, seed=5)
     with torch.no_grad():
@@ -201,7 +203,7 @@ def test_idcm_without_sampling_equals_the_live_reference_class():
     """idcm.yaml's default is idcm_sample_n: -1 — no passage selection, BERT reads every packed passage
     (sigir21_idcm.py:209-252); the branch never touches the native operator, so it runs on the CPU as is."""
     from oracle import ref_harness as R
-    from matchmaker_amd import idcm
+    from tests import idcm_host_fixture as idcm
     ref = R.make_idcm(_tiny_distilbert(), sample_n=-1, sample_context="ck", top_k_chunks=3, seed=6)
     mine = idcm.IDCM(_tiny_distilbert(), sample_n=-1, sample_context="ck", top_k_chunks=3, chunk_size=50, overlap=7,
                      padding_idx=0)
