@@ -18,204 +18,9 @@
 // HBM-bound by design: 2*Q*E flop per D-side byte pair = 32 flop/B at bf16, far below the MFMA
 // ridge, so everything here is about keeping >= 16 KiB of D stream in flight per wavefront.
 #include "mm_internal.h"
+#include "maxsim_device.h"
 
 namespace mm {
-
-struct MaxsimArgs {
-  const void* q;
-  const void* d;
-  PackedMask qm;  // rows = queries
-  PackedMask dm;  // rows = documents
-  float* out;
-  int64_t n_pairs;
-  int64_t ppq;     // pairs per query (paired mode)
-  int64_t inb_bd;  // > 0: all-pairs mode, pair p = (query p / Bd, doc p % Bd)
-  int inb_bug;     // all-pairs: mask with the document row of the *query* index (colbert.py:158)
-  int Q, D, E;
-  int64_t pairs_per_wave;
-  // ragged (CSR) documents: document p = rows [rag_begin[p], rag_end[p]) of the token matrix `d`
-  // (the reference's on-disk store: token_reps_N.npy + doc_infos, dense_retrieval.py:201-280)
-  const int64_t* rag_begin;
-  const int64_t* rag_end;
-};
-
-template <int DT>
-struct Mfma32x16;
-template <>
-struct Mfma32x16<MM_BF16> {
-  static __device__ __forceinline__ f32x16 run(short8 a, short8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mfma32x16<MM_F16> {
-  static __device__ __forceinline__ f32x16 run(short8 a, short8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-
-// C/D layout of the 32x32 MFMA: lane l holds column (l & 31), rows rowof(i) + 4*(l >> 5).
-__device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
-
-// Running max of one 32-row document block into m[16].
-//   ex: bit r set <=> row r of the block is below the document's effective length
-//   va: bit r set <=> row r is a real token (va is a subset of ex)
-//   fill: value of rows outside ex (-1000 if the document has padding at all, else -inf: rows
-//         past D do not exist and must not take part in the max).
-__device__ __forceinline__ void block_max(float (&m)[16], const f32x16& acc, uint32_t ex, uint32_t va, float fill, int h) {
-  if (va == 0xffffffffu) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], acc[i]);
-  } else {
-    const uint32_t exs = ex >> (4 * h), vas = va >> (4 * h);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int bit = rowof(i);
-      float v = ((vas >> bit) & 1u) ? acc[i] : (((exs >> bit) & 1u) ? -1000.0f : fill);
-      m[i] = fmaxf(m[i], v);
-    }
-  }
-}
-
-// Wave-uniform 32-bit load through the scalar cache.  The compiler cannot use s_load here on its
-// own (the asm "memory" clobbers of the LDS-DMA pipeline make every global look written), and a
-// vector load would make it wait vmcnt(0) and drain the D stream once per pair.  Lengths / mask
-// words are never written by these kernels, so the (non-coherent) scalar cache is safe.
-__device__ __forceinline__ uint32_t sload_u32(const void* base, int64_t idx) {
-  uint32_t v;
-  const uint32_t* p = (const uint32_t*)base + idx;
-  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-  return v;
-}
-
-__device__ __forceinline__ int64_t sload_i64(const int64_t* base, int64_t idx) {
-  int64_t v;
-  const int64_t* p = base + idx;
-  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-  return v;
-}
-
-// Query-tile B fragments: 8 x 16 B per lane at base + kk*32.  Loaded in asm together with their
-// own vmcnt(0) so the compiler never plants vmcnt(N) waits for them inside the block loop (those
-// would also drain the hidden LDS-DMA queue).  Runs once per query, so the drain is harmless.
-__device__ __forceinline__ void load_q_frags(const char* base, short8 (&qf)[8]) {
-  asm volatile(
-      "global_load_dwordx4 %0, %8, off\n\t"
-      "global_load_dwordx4 %1, %8, off offset:32\n\t"
-      "global_load_dwordx4 %2, %8, off offset:64\n\t"
-      "global_load_dwordx4 %3, %8, off offset:96\n\t"
-      "global_load_dwordx4 %4, %8, off offset:128\n\t"
-      "global_load_dwordx4 %5, %8, off offset:160\n\t"
-      "global_load_dwordx4 %6, %8, off offset:192\n\t"
-      "global_load_dwordx4 %7, %8, off offset:224\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]), "=&v"(qf[4]), "=&v"(qf[5]), "=&v"(qf[6]),
-        "=&v"(qf[7])
-      : "v"(base)
-      : "memory");
-}
-
-__device__ __forceinline__ float finish_pair(const float (&m)[16], bool qvalid, int h) {
-  float mx = m[0];
-#pragma unroll
-  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, m[i]);
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // other half holds the other 16 rows of every block
-  return wave_sum((qvalid && h == 0) ? mx : 0.0f);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Roofline path.
-// ---------------------------------------------------------------------------------------------
-constexpr int kBlkBytes = 32 * 256;  // 32 document tokens x 128 dims x 2 B
-
-// 8 LDS-DMA instructions = one 8 KiB document block.  Instruction k moves rows 4k..4k+3:
-// 16 lanes per row, each lane one 16-B chunk.  LDS destination is lane-linear (M0 + lane*16), so
-// the bank swizzle is applied on the SOURCE side: the chunk stored at slot p of row r is chunk
-// p ^ (r & 15).  A later ds_read_b128 of chunk c of row (lane & 31) then reads slot c ^ (r & 15):
-// every 16-lane service group of the read covers 16 distinct slots of the 256-B bank row.
-template <bool NT>
-__device__ __forceinline__ void issue_block(const char* gbase, const uint32_t (&voff)[8], uint32_t lds_dst) {
-  uint32_t keep;
-  if (NT) {
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %10\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %6, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %7, %9 nt\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %8, %9 nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]),
-          "v"(voff[7]), "s"(gbase), "s"(lds_dst)
-        : "memory", "scc");
-  } else {
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %10\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %6, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %7, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %8, %9\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]),
-          "v"(voff[7]), "s"(gbase), "s"(lds_dst)
-        : "memory", "scc");
-  }
-}
-
-// Wait until at most `younger` blocks (8 LDS-DMA each) issued after the one we need are pending.
-__device__ __forceinline__ void wait_block(int younger) {
-  switch (younger) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-  }
-}
 
 // NSL = E / 128: a 32-token block is streamed as NSL slices of 32 rows x 256 B (one ring slot each);
 // the accumulator runs across the slices, the query tile is NSL x 32 VGPRs of B fragments.
@@ -675,8 +480,18 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   a.Q = Q; a.D = D; a.E = E;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
+  // the reference's batch layout (one query tile per pair, eval.py:108): the pair kernel; HF int64 masks are read by
+  // the kernel itself (no pack pass) when their rows are 16-byte multiples
+  const bool pair_kernel = pairs_per_query == 1 && !env().maxsim_generic && maxsim_pair_supported(Q, E, dtype);
+  if (pair_kernel && q_mask_kind == MM_MASK_I64 && d_mask_kind == MM_MASK_I64 && q_mask && d_mask &&
+      maxsim_pair_i64_supported(Q, D, q_mask, d_mask)) {
+    a.qm64 = (const int64_t*)q_mask;
+    a.dm64 = (const int64_t*)d_mask;
+    return maxsim_pair_launch(a, dtype, true, stream);
+  }
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (pair_kernel) return maxsim_pair_launch(a, dtype, false, stream);
   const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);

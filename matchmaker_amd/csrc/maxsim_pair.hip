@@ -1,0 +1,388 @@
+// ColBERT MaxSim in the REFERENCE's batch layout: one query tile per pair (eval.py:108 -> colbert.py:68-75 hands
+// ColBERT.forward pair-per-row batches: query_vecs [B,Q,E] replicated per candidate, int64 HF attention masks).
+//
+// The shared-query kernel (maxsim.hip) reloads the query fragments with plain vector loads + vmcnt(0) whenever the
+// query changes — harmless once per 1000 candidates, a drain of the LDS-DMA prefetch once per PAIR here — and needs
+// a separate pack_mask_kernel pass over the int64 masks.  This kernel keeps everything in ONE in-order stream:
+//
+//   per pair:  [mask DMA of the NEXT pair: 3 LDS-DMA instructions]  [query tile: NSL ring slots]  [document blocks]
+//
+//   * the query tile travels through the same LDS ring as the document blocks (same 8-instruction unit, same
+//     source-side swizzle) and is read into the MFMA B-fragment registers with ds_read_b128 when its slot comes up:
+//     no vector load, no vmcnt(0);
+//   * the int64 masks of the next pair are fetched by LDS-DMA one pair ahead (raw image in LDS), turned into
+//     {effective length, validity words, query bits} with v_cmp + ballot when the producer reaches that pair (it
+//     needs the block count to issue), and handed to the consumer through an 8-entry LDS ring;
+//   * waits stay COUNTED: every in-flight unit carries its instruction count (8, or 8 + 3 when a mask fetch rode in
+//     front of it) in a 6-bit FIFO, and the wait for the oldest unit is vmcnt(sum of the younger ones).
+#include "mm_internal.h"
+#include "maxsim_device.h"
+
+namespace mm {
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n.  n >= 63 needs no wait: fewer than 63 vector-memory loads can
+// be outstanding with these rings (<= 4 units x 11 instructions), so anything that far back has landed.
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
+    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
+    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
+    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
+    default: break;
+  }
+}
+
+constexpr int kMaskRaw = 3072;     // raw int64 image of one pair's masks: document [0, 2048) (D <= 256), query [2048, 3072)
+constexpr int kMaskEntry = 12;     // dwords per converted entry: len, qbits, 8 validity words, 2 pad
+constexpr int kMaskEntries = 8;    // producer runs at most NBUF + 1 pairs ahead of the consumer
+
+// three LDS-DMA instructions: 2 KiB of the document mask row + 1 KiB slot for the query mask row
+__device__ __forceinline__ void issue_masks(const char* dm_row, const uint32_t (&voff_d)[2], const char* qm_row, uint32_t voff_q,
+                                            uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %4\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %4\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %5\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_d[0]), "v"(voff_d[1]), "v"(voff_q), "s"(dm_row), "s"(qm_row), "s"(lds_dst)
+      : "memory", "scc");
+}
+
+template <int DT, int NBUF, int NSL, bool I64>
+__global__ void __launch_bounds__(64) maxsim_pair_kernel(const MaxsimArgs a) {
+  static_assert(NBUF >= 2 && NBUF <= 4, "6-bit x 4 unit FIFO");
+  constexpr int RB = NSL * 256;  // bytes per token row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  char* mraw = smem + NBUF * kBlkBytes;
+  uint32_t* ment = (uint32_t*)(mraw + kMaskRaw);
+  const uint32_t lds_mraw = lds0 + NBUF * kBlkBytes;
+
+  // per-lane LDS-DMA source offsets of a full block, of a document's last block and of the query tile (rows past the
+  // end are redirected to the last real row: never read past the tensors); chunk p of row r is stored at p ^ (r & 15)
+  uint32_t voff[8], voff_tail[8], voff_q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = 4 * k + (lane >> 4);
+    const int c = (lane & 15) ^ (row & 15);
+    const int rowt = row < rows_last ? row : rows_last - 1;
+    const int rowq = row < Q ? row : Q - 1;
+    voff[k] = (uint32_t)(row * RB + c * 16);
+    voff_tail[k] = (uint32_t)(rowt * RB + c * 16);
+    voff_q[k] = (uint32_t)(rowq * RB + c * 16);
+  }
+  uint32_t lo[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
+  // mask rows: lane l of instruction n fetches bytes 16 (64 n + l) .. +15, clamped into the row
+  uint32_t moff_d[2], moff_q = 0;
+  if (I64) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int b = 16 * (64 * n + lane);
+      moff_d[n] = (uint32_t)(b < D * 8 - 16 ? b : D * 8 - 16);
+    }
+    moff_q = (uint32_t)(16 * lane < Q * 8 - 16 ? 16 * lane : Q * 8 - 16);
+  } else {
+    moff_d[0] = moff_d[1] = 0;
+  }
+
+  const char* dbase = (const char*)a.d;
+  const char* qbase = (const char*)a.q;
+
+  // ---- producer: next (pair, query slice | block, slice) to put in flight --------------------------------------
+  int64_t pp = p0;
+  bool pnew = true;        // pp has not been opened yet (masks not converted, block count unknown)
+  int pphase = 0;          // 0: query-tile slices, 1: document blocks
+  int pt = 0, psl = 0, pn = 0;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  uint32_t fifo = 0;       // instruction counts of the in-flight units, 6 bits each, oldest lowest
+  int total_ops = 0;       // their sum
+  int pend_extra = 0;      // mask-fetch instructions issued after the youngest unit (ride on the next unit's count)
+  int ops_since_pm = 0;    // loads issued after the mask fetch in flight
+
+  if (I64) {
+    issue_masks((const char*)(a.dm64 + pp * D), moff_d, (const char*)(a.qm64 + pp * Q), moff_q, lds_mraw);
+  }
+
+  auto open_pair = [&]() {   // producer reaches pair pp: its block count, and (I64) its converted masks
+    int len;
+    if (I64) {
+      wait_vm(ops_since_pm);                                  // the raw masks of pp have landed
+      const int64_t* md = (const int64_t*)mraw;
+      const int64_t* mq = (const int64_t*)(mraw + 2048);
+      unsigned long long b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        b[i] = 0;
+        if (64 * i < D) {
+          const int j = 64 * i + lane;
+          b[i] = __ballot(j < D && md[j < D ? j : D - 1] != 0);
+        }
+      }
+      const uint32_t qb = (uint32_t)__ballot(lane < Q && mq[lane < Q ? lane : Q - 1] != 0);
+      len = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (b[i]) len = 64 * i + 64 - __builtin_clzll(b[i]);
+      if (lane == 0) {
+        uint32_t* e = ment + (int)(pp & (kMaskEntries - 1)) * kMaskEntry;
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        ((u32x4*)e)[0] = u32x4{(uint32_t)len, qb, (uint32_t)b[0], (uint32_t)(b[0] >> 32)};
+        ((u32x4*)e)[1] = u32x4{(uint32_t)b[1], (uint32_t)(b[1] >> 32), (uint32_t)b[2], (uint32_t)(b[2] >> 32)};
+        ((u32x4*)e)[2] = u32x4{(uint32_t)b[3], (uint32_t)(b[3] >> 32), 0u, 0u};
+      }
+      if (pp + 1 < p1) {   // fetch the next pair's masks (the raw image is free again: converted above)
+        issue_masks((const char*)(a.dm64 + (pp + 1) * D), moff_d, (const char*)(a.qm64 + (pp + 1) * Q), moff_q, lds_mraw);
+        pend_extra += 3;
+        ops_since_pm = 0;
+      }
+    } else {
+      len = a.dm.len ? (int)sload_u32(a.dm.len, pp) : D;
+      len = len < 0 ? 0 : (len > D ? D : len);
+    }
+    pn = (len + 31) >> 5;
+    pnew = false;
+  };
+
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      if (pnew) open_pair();
+      const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes;
+      if (pphase == 0) {
+        issue_block<true>(qbase + pp * Q * (int64_t)RB + psl * 256, voff_q, dst);
+      } else {
+        const char* g = dbase + (pp * D + (int64_t)pt * 32) * RB + psl * 256;
+        if (pt == nblk_tot - 1 && rows_last != 32)
+          issue_block<true>(g, voff_tail, dst);
+        else
+          issue_block<true>(g, voff, dst);
+      }
+      const int cnt = 8 + pend_extra;
+      pend_extra = 0;
+      fifo |= (uint32_t)cnt << (6 * inflight);
+      total_ops += cnt;
+      ops_since_pm += 8;
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (NSL > 1 && ++psl < NSL) continue;
+      psl = 0;
+      bool next_pair = false;
+      if (pphase == 0) {
+        pphase = 1;
+        pt = 0;
+        next_pair = pn == 0;
+      } else {
+        next_pair = ++pt == pn;
+      }
+      if (next_pair) {
+        ++pp;
+        pphase = 0;
+        pnew = true;
+      }
+    }
+  };
+  // the oldest unit has landed / is consumed
+  auto wait_oldest = [&]() { wait_vm(total_ops - (int)(fifo & 63u) + pend_extra); };
+  auto pop = [&]() {
+    total_ops -= (int)(fifo & 63u);
+    fifo >>= 6;
+    cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+    --inflight;
+  };
+  top_up();
+
+  short8 qf[NSL][8];
+  for (int64_t pair = p0; pair < p1; ++pair) {
+    // ---- this pair's masks ----------------------------------------------------------------------------------
+    int len;
+    uint32_t qbits, dw[8];
+    if (I64) {
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+      const u32x4* e = (const u32x4*)(ment + (int)(pair & (kMaskEntries - 1)) * kMaskEntry);
+      const u32x4 e0 = e[0], e1 = e[1], e2 = e[2];
+      len = __builtin_amdgcn_readfirstlane((int)e0[0]);
+      qbits = __builtin_amdgcn_readfirstlane(e0[1]);
+      dw[0] = __builtin_amdgcn_readfirstlane(e0[2]); dw[1] = __builtin_amdgcn_readfirstlane(e0[3]);
+      dw[2] = __builtin_amdgcn_readfirstlane(e1[0]); dw[3] = __builtin_amdgcn_readfirstlane(e1[1]);
+      dw[4] = __builtin_amdgcn_readfirstlane(e1[2]); dw[5] = __builtin_amdgcn_readfirstlane(e1[3]);
+      dw[6] = __builtin_amdgcn_readfirstlane(e2[0]); dw[7] = __builtin_amdgcn_readfirstlane(e2[1]);
+    } else {
+      len = a.dm.len ? (int)sload_u32(a.dm.len, pair) : D;
+      len = len < 0 ? 0 : (len > D ? D : len);
+      int qlen = a.qm.len ? (int)sload_u32(a.qm.len, pair) : Q;
+      qlen = qlen < 0 ? 0 : (qlen > 32 ? 32 : qlen);
+      qbits = qlen >= 32 ? 0xffffffffu : ((1u << qlen) - 1u);
+      if (a.qm.bits) qbits &= sload_u32(a.qm.bits, pair);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dw[i] = 0xffffffffu;
+    }
+    const bool qvalid = r < Q && ((qbits >> r) & 1u);
+    // ---- query tile out of the ring ----------------------------------------------------------------------------
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      top_up();
+      wait_oldest();
+      const char* buf = smem + cbuf * kBlkBytes;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) qf[sl][kk] = *(const short8*)(buf + lo[kk]);
+      pop();
+    }
+    const int nb = (len + 31) >> 5;
+    const float fill = len < D ? -1000.0f : neg_inf();
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = fill;
+    for (int t = 0; t < nb; ++t) {
+      f32x16 acc = f32x16{0};
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) {
+        top_up();
+        wait_oldest();
+        const char* buf = smem + cbuf * kBlkBytes;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const short8 av = *(const short8*)(buf + lo[kk]);
+          acc = Mfma32x16<DT>::run(av, qf[sl][kk], acc);
+        }
+        pop();
+      }
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      uint32_t va = ex;
+      if (I64) {
+        uint32_t w = dw[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) w = t == i ? dw[i] : w;
+        va = w & ex;
+      } else if (a.dm.bits) {
+        va = sload_u32(a.dm.bits, pair * nblk_tot + t) & ex;
+      }
+      block_max(m, acc, ex, va, fill, h);
+    }
+    const float s = finish_pair(m, qvalid, h);
+    if (lane == 0) a.out[pair] = s;
+  }
+}
+
+template <int DT, int NSL, bool I64>
+static int launch_pair(const MaxsimArgs& a0, hipStream_t stream) {
+  MaxsimArgs a = a0;
+  const int nbuf = env().maxsim_nbuf >= 3 ? 3 : 2;
+  const int lds = nbuf * kBlkBytes + (I64 ? kMaskRaw + kMaskEntries * kMaskEntry * 4 : 0);
+  int wpc = env().maxsim_wpc > 0 ? env().maxsim_wpc : 4;
+  if (wpc > 8) wpc = 8;
+  int64_t waves = (int64_t)kCUs * wpc;
+  if (waves > a.n_pairs) waves = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
+  waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  if (nbuf == 3)
+    hipLaunchKernelGGL((maxsim_pair_kernel<DT, 3, NSL, I64>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  else
+    hipLaunchKernelGGL((maxsim_pair_kernel<DT, 2, NSL, I64>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  return check_launch("maxsim_pair_kernel");
+}
+
+template <int DT, bool I64>
+static int launch_pair_e(const MaxsimArgs& a, hipStream_t stream) {
+  switch (a.E / 128) {
+    case 1: return launch_pair<DT, 1, I64>(a, stream);
+    case 2: return launch_pair<DT, 2, I64>(a, stream);
+    case 3: return launch_pair<DT, 3, I64>(a, stream);
+    case 4: return launch_pair<DT, 4, I64>(a, stream);
+    default: return launch_pair<DT, 6, I64>(a, stream);
+  }
+}
+
+bool maxsim_pair_supported(int Q, int E, int dtype) {
+  return dtype != MM_F32 && Q <= 32 && (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
+}
+
+// int64 masks straight from the tokenizer: rows must be 16-byte multiples (even Q / D) for the LDS-DMA fetch
+bool maxsim_pair_i64_supported(int Q, int D, const void* qm, const void* dm) {
+  return D <= 256 && D >= 2 && Q >= 2 && !(D & 1) && !(Q & 1) && !(((uintptr_t)qm | (uintptr_t)dm) & 15);
+}
+
+int maxsim_pair_launch(const MaxsimArgs& a, int dtype, bool i64, hipStream_t stream) {
+  if (dtype == MM_BF16) return i64 ? launch_pair_e<MM_BF16, true>(a, stream) : launch_pair_e<MM_BF16, false>(a, stream);
+  return i64 ? launch_pair_e<MM_F16, true>(a, stream) : launch_pair_e<MM_F16, false>(a, stream);
+}
+
+}  // namespace mm

@@ -227,3 +227,49 @@ def test_widths_that_are_not_16_byte_rows_are_zero_padded():
     with pytest.raises(ops.NativeError):          # a document range past the token matrix is refused, not read
         ops.maxsim_ragged(torch.zeros(1, 4, 128, dtype=torch.bfloat16, device=dev), torch.zeros(10, 128, dtype=torch.bfloat16, device=dev),
                           torch.tensor([0, 8], device=dev), torch.tensor([5, 12], device=dev), None, pairs_per_query=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Q,D,E", [(32, 180, 128), (30, 200, 768), (8, 64, 256), (20, 256, 384), (32, 34, 512), (2, 2, 128),
+                                   (31, 181, 128), (32, 300, 128)])
+def test_pair_per_row_layout_with_tokenizer_masks(dtype, Q, D, E):
+    """The reference's own batch layout (eval.py:108 -> colbert.py:68-75): one query tile PER PAIR, int64 HF masks — the
+    pair kernel (query tile through the LDS ring, masks fetched and converted inside the kernel; odd Q / D or D > 256
+    take the packed-mask variant).  Holes, all-padding documents, an all-padding query, many pairs per wavefront and
+    fewer pairs than wavefronts, lengths / no masks through the same kernel."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 1000 + D + E)
+    for B in (3, 2500):
+        q = (torch.randn(B, Q, E, generator=g) / E ** 0.5).to(dtype)
+        d = (torch.randn(B, D, E, generator=g) / E ** 0.5).to(dtype)
+        ql = torch.randint(1, Q + 1, (B,), generator=g)
+        dl = torch.randint(0, D + 1, (B,), generator=g)
+        dl[0] = D
+        dl[1] = 0                                           # an empty document: -1000 per real query token
+        qm = (torch.arange(Q)[None] < ql[:, None]).long()
+        dm = (torch.arange(D)[None] < dl[:, None]).long()
+        qm[2] = 0                                           # an all-padding query scores 0
+        if D > 4:
+            dm[0, 1] = 0                                    # holes
+            dm[0, D - 2] = 0
+        if Q > 2:
+            qm[0, 1] = 0
+        dm[dm != 0] = torch.randint(1, 1 << 40, (int((dm != 0).sum()),), generator=g)     # any non-zero word is a real token
+        out = ops.maxsim(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), pairs_per_query=1).cpu().numpy()
+        ref = O.maxsim_paired(q.float().numpy(), d.float().numpy(), qm.numpy(), dm.numpy())
+        np.testing.assert_allclose(out, ref, atol=util.TOL_BF16, rtol=1e-4)
+        assert out[2] == 0.0 and out[1] == -1000.0 * int((qm[1] != 0).sum())
+        # the same pairs with lengths and with no masks at all
+        out_len = ops.maxsim(q.to(dev), d.to(dev), ql.to(dev), dl.to(dev), pairs_per_query=1).cpu().numpy()
+        ref_len = O.maxsim_paired(q.float().numpy(), d.float().numpy(), (torch.arange(Q)[None] < ql[:, None]).numpy(),
+                                  (torch.arange(D)[None] < dl[:, None]).numpy())
+        np.testing.assert_allclose(out_len, ref_len, atol=util.TOL_BF16, rtol=1e-4)
+        out_none = ops.maxsim(q.to(dev), d.to(dev), None, None, pairs_per_query=1).cpu().numpy()
+        np.testing.assert_allclose(out_none, O.maxsim_unmasked(q.float().numpy(), d.float().numpy()), atol=util.TOL_BF16, rtol=1e-4)
+        # identical to the shared-query kernel on the same numbers (pairs of one query stored once)
+        if B == 3:
+            shared = ops.maxsim(q[:1].to(dev), d.to(dev), qm[:1].to(dev), dm.to(dev), pairs_per_query=B)
+            rep = ops.maxsim(q[:1].expand(B, -1, -1).contiguous().to(dev), d.to(dev), qm[:1].expand(B, -1).contiguous().to(dev),
+                             dm.to(dev), pairs_per_query=1)
+            assert torch.equal(shared, rep)
