@@ -23,34 +23,164 @@ constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows sta
 constexpr int kWThreads = 512;
 
 
-// slot -> (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2); -1 = dropped
-// chunk.  Stage 1 only writes the blocks below a chunk's effective length, so pair rows past them are
-// taken as zeros by stage 2 instead of being zero-filled in HBM first (that memset of the whole pair
-// buffer was 255 MB at B = 256 x 2048 tokens).
-__global__ void __launch_bounds__(256) tkl_slot_map_kernel(const int32_t* __restrict__ chunk_slot,
-                                                           const int32_t* __restrict__ chunk_len, int64_t P,
-                                                           int64_t BC, int all_pairs, int32_t* __restrict__ slot2p) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p < P) {
-    const int32_t s = chunk_slot[p];
-    int len = chunk_len[p];
-    len = len < 0 ? 0 : (len > 40 ? 40 : len);
+// Preparation in two launches instead of five (memset + emb + two mask packs + slot map were ~25 us of a 0.3 ms call).
+//
+// tkl_prep_query_kernel — three roles by block range (all independent of each other):
+//   [0, n_fill)               slot2p[...] = -1 (dropped chunk) for the B*C slots;
+//   [n_fill, n_fill + n_emb)  sat_emb_reduce1(q_ctx) (:224): one wavefront per (document, query token) -> emb[b][i];
+//   the rest                  effective query lengths + validity bits of the float query masks (one wavefront per row).
+__global__ void __launch_bounds__(256) tkl_prep_query_kernel(int32_t* __restrict__ slot2p, int64_t BC, int n_fill,
+                                                             const float* __restrict__ q_ctx, const float* __restrict__ prm,
+                                                             float* __restrict__ emb, int64_t BQ, int E, int n_emb,
+                                                             const float* __restrict__ q_mask, int64_t B, int Q,
+                                                             int32_t* __restrict__ qlen_out, uint32_t* __restrict__ qbits_out) {
+  const int lane = threadIdx.x & 63;
+  int blk = blockIdx.x;
+  if (blk < n_fill) {
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
+    if (i < BC) slot2p[i] = -1;
+    return;
+  }
+  blk -= n_fill;
+  if (blk < n_emb) {
+    const int64_t row = (int64_t)blk * 4 + (threadIdx.x >> 6);
+    if (row >= BQ) return;
+    const float* qr = q_ctx + row * E;
+    float s = 0.0f;
+    for (int e = lane; e < E; e += 64) s += qr[e] * prm[TklParams::emb() + e];
+    s = wave_sum(s);
+    if (lane == 0) emb[row] = s;
+    return;
+  }
+  blk -= n_emb;
+  const int64_t row = (int64_t)blk * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const int words = (Q + 31) >> 5;
+  const float* m = q_mask + row * Q;
+  int last = 0;
+  for (int base = 0; base < Q; base += 64) {
+    const int j = base + lane;
+    const unsigned long long bal = __ballot(j < Q && m[j < Q ? j : Q - 1] != 0.0f);
+    if (lane == 0) {
+      const int w = base >> 5;
+      qbits_out[row * words + w] = (uint32_t)bal;
+      if (w + 1 < words) qbits_out[row * words + w + 1] = (uint32_t)(bal >> 32);
+    }
+    if (bal) last = base + 64 - __builtin_clzll(bal);
+  }
+  if (lane == 0) qlen_out[row] = last;
+}
+
+// tkl_prep_chunk_kernel — one wavefront per packed chunk: effective length + validity bits of its 40 centre tokens
+// (columns 5..44 of the [P, 50] mask) and the slot map entry
+//   slot2p[slot] = (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2);
+// -1 (from tkl_prep_query_kernel, earlier in the stream) = dropped chunk.  Stage 1 only writes the blocks below a
+// chunk's effective length, so pair rows past them are taken as zeros by stage 2 instead of being zero-filled in HBM
+// first (that memset of the whole pair buffer was 255 MB at B = 256 x 2048 tokens).
+__global__ void __launch_bounds__(256) tkl_prep_chunk_kernel(const float* __restrict__ chunk_mask,
+                                                             const int32_t* __restrict__ chunk_slot, int64_t P, int64_t BC,
+                                                             int all_pairs, int32_t* __restrict__ len_out,
+                                                             uint32_t* __restrict__ bits_out, int32_t* __restrict__ slot2p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const float* m = chunk_mask + p * 50 + 5;
+  const unsigned long long bal = __ballot(lane < 40 && m[lane < 40 ? lane : 39] != 0.0f);
+  if (lane == 0) {
+    const int len = bal ? 64 - __builtin_clzll(bal) : 0;
+    len_out[p] = len;
+    bits_out[p * 2] = (uint32_t)bal;
+    bits_out[p * 2 + 1] = (uint32_t)(bal >> 32);
+    const int32_t sl = chunk_slot[p];
     // the grouped stage-1 kernel writes every pair of a chunk; the per-chunk kernels only the blocks below its length
-    if (s >= 0 && s < BC) slot2p[s] = (int32_t)((p << 2) | (all_pairs ? 2 : ((len + 31) >> 5)));
+    if (sl >= 0 && sl < BC) slot2p[sl] = (int32_t)((p << 2) | (all_pairs ? 2 : ((len + 31) >> 5)));
   }
 }
 
-// sat_emb_reduce1(q_ctx) (:224): one wavefront per (document, query token) -> emb[b][i]
-__global__ void __launch_bounds__(256) tkl_emb_kernel(const float* __restrict__ q_ctx, const float* __restrict__ prm,
-                                                      float* __restrict__ emb, int64_t BQ, int E) {
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= BQ) return;
-  const float* qr = q_ctx + row * E;
-  float s = 0.0f;
-  for (int e = lane; e < E; e += 64) s += qr[e] * prm[TklParams::emb() + e];
-  s = wave_sum(s);
-  if (lane == 0) emb[row] = s;
+// The (window, query token) items of one tile: see tkl_window_kernel.  red[w][i] for i < ql is written for every
+// window of the tile (0 for windows past W).
+template <int SAT, int kG>
+__device__ __forceinline__ void window_items(const float* tile, float* red, const float* emb, const float* __restrict__ q_mask,
+                                             const float* __restrict__ prm, const float* sp, int b, int Q, int ql, int rowf,
+                                             int w0, int W, int tid) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  constexpr int kE = kG - 1;                              // edge rows on each side
+  for (int item = tid; item < (kWT / kG) * ql; item += kWThreads) {
+    const int wp = item / ql, i = item - wp * ql;
+    const int wl = kG * wp;
+    if (w0 + wl >= W) {
+#pragma unroll
+      for (int which = 0; which < kG; ++which) red[(wl + which) * Q + i] = 0.0f;
+      continue;
+    }
+    auto row = [&](int j, f32x2 (&dst)[kKC / 2]) {
+      const f32x4* src = (const f32x4*)(tile + (size_t)(wl + j) * rowf + i * kKC);
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const f32x4 x = src[v];
+        dst[2 * v] = f32x2{x[0], x[1]};
+        dst[2 * v + 1] = f32x2{x[2], x[3]};
+      }
+    };
+    // rows 0..kE-1 and 15..15+kE-1 are the edges, rows kE..14 the core every window of the item contains
+    f32x2 core[kKC / 2], edge[2 * kE + 1][kKC / 2], tmp[kKC / 2];
+#pragma unroll
+    for (int e = 0; e < kE; ++e) row(e, edge[e]);
+    row(kE, core);
+#pragma unroll
+    for (int j = kE + 1; j < kWinPairs; ++j) {
+      row(j, tmp);
+#pragma unroll
+      for (int k = 0; k < kKC / 2; ++k) core[k] += tmp[k];
+    }
+#pragma unroll
+    for (int e = 0; e < kE; ++e) row(kWinPairs + e, edge[kE + e]);
+    const float qmv = q_mask[(int64_t)b * Q + i];
+#pragma unroll
+    for (int which = 0; which < kG; ++which) {
+      // window wl + which = head edges which..kE-1 + core + tail edges 0..which-1
+      f32x2 acc2[kKC / 2];
+#pragma unroll
+      for (int k = 0; k < kKC / 2; ++k) {
+        f32x2 v = core[k];
+#pragma unroll
+        for (int e = 0; e < 2 * kE; ++e)
+          if ((e < kE && e >= which) || (e >= kE && e < kE + which)) v += edge[e][k];
+        acc2[k] = v;
+      }
+      float pk[kKC];
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) pk[k] = acc2[k >> 1][k & 1];
+      float val = 0.0f;
+      const float len = pk[kK];                                        // :210 (exact small integer)
+      const float factor = qmv * (len > 0.0f ? 1.0f : 0.0f);          // :248
+      if (SAT == MM_TKL_SAT_EMBEDDING) {
+        const float x0 = emb[i], x1 = len;                             // :224-225
+        const float mean = (x0 + x1) * 0.5f;                           // LayerNorm(2) :228
+        const float d0 = x0 - mean, d1 = x1 - mean;
+        const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
+        const float n0 = d0 * rstd * sp[9] + sp[11], n1 = d1 * rstd * sp[10] + sp[12];
+        const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];              // :230
+        const float s2 = 1.0f / (n0 * sp[3] + n1 * sp[4] + sp[5]);      // :231
+        const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];              // :232
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          // x^s2 = exp2(s2 * log2 x) on the hardware transcendentals (x >= 1e-10 > 0): 3 instructions
+          // instead of ~80 for powf; |s2 * log2 x| <= ~33 |s2| keeps the error ~1e-6 relative
+          const float xp = __builtin_amdgcn_exp2f(s2 * __builtin_amdgcn_logf(fmaxf(pk[k], 1e-10f)));
+          const float sat = s1 * xp - s3;  // :234
+          val += prm[TklParams::dense() + k] * (sat * factor);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          const float sat = logf(fmaxf(pk[k] * prm[TklParams::kmult() + k], 1e-10f));   // :246
+          val += prm[TklParams::dense() + k] * (sat * factor);
+        }
+      }
+      red[(wl + which) * Q + i] = (w0 + wl + which < W) ? val : 0.0f;
+    }
+  }
 }
 
 // One workgroup = kWT consecutive windows of one document.
@@ -81,6 +211,18 @@ __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __re
     cinfo[tid] = c < C ? slot2p[(int64_t)b * C + c] : -1;
   }
   __syncthreads();
+  // a tile none of whose chunks exists (padding past the document's end) is all zeros: every window is empty and
+  // scores exactly 0 (:248) — half of all tiles with config 3's U{50..2048} document lengths
+  {
+    bool live = false;
+    const int cb = (w0 + nu - 1) / kU - c0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) live = live || (c <= cb && cinfo[c] >= 0);
+    if (!live) {
+      if (tid < kWT && w0 + tid < W) win[(int64_t)b * W + w0 + tid] = 0.0f;
+      return;
+    }
+  }
 
   // ---- stage the pair-sum rows (zeros for dropped chunks) --------------------------------------
   // All row loads of a batch of kStage elements are issued before the first LDS store, so a thread pays
@@ -123,89 +265,15 @@ __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __re
   __syncthreads();
 
   const float* sp = prm + TklParams::sat();
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  // One item = FOUR adjacent windows of one query token: windows wl .. wl + 3 share 12 of their 15 pair rows, so
-  // the shared rows are summed once (18 row reads for four windows instead of 60).  Only additions of
-  // non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
-  constexpr int kG = 4;
-  for (int item = tid; item < (kWT / kG) * Q; item += kWThreads) {
-    const int wp = item / Q, i = item - wp * Q;
-    const int wl = kG * wp;
-    if (w0 + wl >= W) {
-#pragma unroll
-      for (int which = 0; which < kG; ++which) red[(wl + which) * Q + i] = 0.0f;
-      continue;
-    }
-    auto row = [&](int j, f32x2 (&dst)[kKC / 2]) {
-      const f32x4* src = (const f32x4*)(tile + (size_t)(wl + j) * rowf + i * kKC);
-#pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        const f32x4 x = src[v];
-        dst[2 * v] = f32x2{x[0], x[1]};
-        dst[2 * v + 1] = f32x2{x[2], x[3]};
-      }
-    };
-    // rows 0..2 and 15..17 are the edges, rows 3..14 the core every window of the item contains
-    f32x2 core[kKC / 2], edge[6][kKC / 2], tmp[kKC / 2];
-    row(0, edge[0]);
-    row(1, edge[1]);
-    row(2, edge[2]);
-    row(3, core);
-#pragma unroll
-    for (int j = 4; j < kWinPairs; ++j) {
-      row(j, tmp);
-#pragma unroll
-      for (int k = 0; k < kKC / 2; ++k) core[k] += tmp[k];
-    }
-    row(kWinPairs, edge[3]);
-    row(kWinPairs + 1, edge[4]);
-    row(kWinPairs + 2, edge[5]);
-    const float qmv = q_mask[(int64_t)b * Q + i];
-#pragma unroll
-    for (int which = 0; which < kG; ++which) {
-      // window wl + which = edges which..2 (head) + core + edges 3..2+which (tail)
-      f32x2 acc2[kKC / 2];
-#pragma unroll
-      for (int k = 0; k < kKC / 2; ++k) {
-        f32x2 v = core[k];
-#pragma unroll
-        for (int e = 0; e < 6; ++e)
-          if ((e < 3 && e >= which) || (e >= 3 && e < 3 + which)) v += edge[e][k];
-        acc2[k] = v;
-      }
-      float pk[kKC];
-#pragma unroll
-      for (int k = 0; k < kKC; ++k) pk[k] = acc2[k >> 1][k & 1];
-      float val = 0.0f;
-      const float len = pk[kK];                                        // :210 (exact small integer)
-      const float factor = qmv * (len > 0.0f ? 1.0f : 0.0f);          // :248
-      if (SAT == MM_TKL_SAT_EMBEDDING) {
-        const float x0 = emb[i], x1 = len;                             // :224-225
-        const float mean = (x0 + x1) * 0.5f;                           // LayerNorm(2) :228
-        const float d0 = x0 - mean, d1 = x1 - mean;
-        const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
-        const float n0 = d0 * rstd * sp[9] + sp[11], n1 = d1 * rstd * sp[10] + sp[12];
-        const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];              // :230
-        const float s2 = 1.0f / (n0 * sp[3] + n1 * sp[4] + sp[5]);      // :231
-        const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];              // :232
-#pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          // x^s2 = exp2(s2 * log2 x) on the hardware transcendentals (x >= 1e-10 > 0): 3 instructions
-          // instead of ~80 for powf; |s2 * log2 x| <= ~33 |s2| keeps the error ~1e-6 relative
-          const float xp = __builtin_amdgcn_exp2f(s2 * __builtin_amdgcn_logf(fmaxf(pk[k], 1e-10f)));
-          const float sat = s1 * xp - s3;  // :234
-          val += prm[TklParams::dense() + k] * (sat * factor);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          const float sat = logf(fmaxf(pk[k] * prm[TklParams::kmult() + k], 1e-10f));   // :246
-          val += prm[TklParams::dense() + k] * (sat * factor);
-        }
-      }
-      red[(wl + which) * Q + i] = (w0 + wl + which < W) ? val : 0.0f;
-    }
-  }
+  // One item = kG adjacent windows of one query token: the windows share 15 - (kG - 1) of their pair rows, which are
+  // summed once (kG = 4: 18 row reads for four windows instead of 60).  Only tokens below the effective query length
+  // are evaluated (the others are multiplied by 0 in :248), and kG adapts to it so that one pass of the 512 threads
+  // covers the tile with as little work per thread as possible: 16 ql items of four windows for long queries,
+  // 32 ql of two / 64 ql of one when that still fits one pass (MSMARCO queries average ~6 tokens).
+  // Only additions of non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
+  if (ql * (kWT / 1) <= kWThreads) window_items<SAT, 1>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, w0, W, tid);
+  else if (ql * (kWT / 2) <= kWThreads) window_items<SAT, 2>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, w0, W, tid);
+  else window_items<SAT, 4>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, w0, W, tid);
   __syncthreads();
   if (tid < kWT && w0 + tid < W) {                                     // :249 sum over query tokens, :251 dense
     float s = 0.0f;
@@ -318,22 +386,24 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   ws += ps_bytes;
   size_t left = workspace_bytes - (size_t)(ws - (char*)workspace);
   float* win = win_scores;
-  if (hipMemsetAsync(slot2p, 0xFF, (size_t)B * C * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "tkl: memset failed");
   char* tail = (char*)workspace + align256((size_t)B * C * 4) + ps_bytes + packed_mask_bytes(MM_MASK_F32, P, 40);
   if (!win) win = (float*)tail;
   float* emb = (float*)(tail + align256((size_t)B * W * 4));
-  if (saturation == MM_TKL_SAT_EMBEDDING) {
-    hipLaunchKernelGGL(tkl_emb_kernel, dim3((unsigned)((B * Q + 3) / 4)), dim3(256), 0, stream, (const float*)q_ctx, params,
-                       emb, B * (int64_t)Q, E);
-    if (int e = check_launch("tkl_emb_kernel")) return e;
-  }
-  // effective query lengths (last real token + 1): query tokens past them are masked in :248, so stage 1 does not
-  // write their pair rows and stage 2 does not read or evaluate them
+  // launch 1: slot map cleared, sat_emb_reduce1(q_ctx), effective query lengths (last real token + 1: query tokens
+  // past them are masked in :248, so stage 1 does not write their pair rows and stage 2 does not evaluate them)
   PackedMask qmk;
   {
     char* qws = (char*)emb + align256((size_t)B * Q * 4);
-    size_t qleft = packed_mask_bytes(MM_MASK_F32, B, Q);
-    if (int e = resolve_mask(q_mask, MM_MASK_F32, B, Q, &qws, &qleft, stream, &qmk)) return e;
+    int32_t* qlen = (int32_t*)qws;
+    uint32_t* qbits = (uint32_t*)(qws + (size_t)B * 4);
+    const int n_fill = (int)((B * (int64_t)C + 255) / 256);
+    const int n_emb = saturation == MM_TKL_SAT_EMBEDDING ? (int)((B * (int64_t)Q + 3) / 4) : 0;
+    const int n_q = (int)((B + 3) / 4);
+    hipLaunchKernelGGL(tkl_prep_query_kernel, dim3((unsigned)(n_fill + n_emb + n_q)), dim3(256), 0, stream, slot2p,
+                       B * (int64_t)C, n_fill, (const float*)q_ctx, params, emb, B * (int64_t)Q, E, n_emb, q_mask, B, Q, qlen, qbits);
+    if (int e = check_launch("tkl_prep_query_kernel")) return e;
+    qmk.len = qlen;
+    qmk.bits = qbits;
   }
   // Stages 1 + 2 fused per document (pair sums stay in LDS) when the shape fits; otherwise stage 1 writes the
   // pair sums to the workspace and the window kernel reads them back.
@@ -341,10 +411,18 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   PackedMask dm;
   if (P > 0) {
     if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
-    if (int e = resolve_mask(chunk_mask, MM_MASK_F32, P, 40, &ws, &left, stream, &dm, 50, 5)) return e;
-    hipLaunchKernelGGL(tkl_slot_map_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, dm.len, P,
-                       B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, slot2p);
-    if (int e = check_launch("tkl_slot_map_kernel")) return e;
+    // launch 2: chunk masks (effective length + validity bits of the 40 centre tokens) and the slot map
+    const size_t need_dm = packed_mask_bytes(MM_MASK_F32, P, 40);
+    if (left < need_dm) return set_error(MM_EWORKSPACE, "tkl: workspace too small for the chunk masks");
+    int32_t* clen = (int32_t*)ws;
+    uint32_t* cbits = (uint32_t*)(ws + (size_t)P * 4);
+    ws += need_dm;
+    left -= need_dm;
+    hipLaunchKernelGGL(tkl_prep_chunk_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, chunk_mask, chunk_slot, P,
+                       B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, clen, cbits, slot2p);
+    if (int e = check_launch("tkl_prep_chunk_kernel")) return e;
+    dm.len = clen;
+    dm.bits = cbits;
     if (!fused) {
       if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, qmk.len, chunk_slot, C,
                                     params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
