@@ -27,7 +27,11 @@ namespace mm {
 // NQT = query tiles of 32 tokens held in registers (Q <= 32 * NQT): the reference's defaults stay under 32
 // (max_query_length 30, defaults.yaml:127) but ColBERT's [MASK] query augmentation
 // (query_augment_mask_number, independent_reranking_loader.py:106-112) pushes Q to 38.
-template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT>
+// INB: all-pairs mode (colbert.py:154-162): pair p = (query p / Bd, document p % Bd), masked with the document's own
+// mask row or — bug-compatible, :158 — with the row of the query index.  A wavefront's pairs are consecutive documents of
+// one query, so the query tile stays in registers and the documents stream from L2 / the Infinity Cache (they are read
+// once per query).
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, bool INB = false>
 __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,12 +62,14 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
 
   const char* dbase = (const char*)a.d;
+  auto doc_row = [&](int64_t p) -> int64_t { return INB ? p % a.inb_bd : p; };
+  auto mask_row = [&](int64_t p) -> int64_t { return INB ? (a.inb_bug ? p / a.inb_bd : p % a.inb_bd) : p; };
   auto doc_len = [&](int64_t p) -> int {
     if (RAG) {
       const int64_t l = sload_i64(a.rag_end, p) - sload_i64(a.rag_begin, p);
       return l < 0 ? 0 : (l > 0x7fffffe0LL ? 0x7fffffe0 : (int)l);
     }
-    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, mask_row(p)) : D;
     return len < 0 ? 0 : (len > D ? D : len);
   };
 
@@ -75,7 +81,7 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
 
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
-      const int64_t row0 = RAG ? sload_i64(a.rag_begin, pp) : pp * D;
+      const int64_t row0 = RAG ? sload_i64(a.rag_begin, pp) : doc_row(pp) * D;
       const char* g = dbase + (row0 + (int64_t)pt * 32) * RB + psl * 256;
       const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes;
       if (RAG) {
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
       }
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-      const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, mask_row(pair) * nblk_tot + t) & ex) : ex;
 #pragma unroll
       for (int n = 0; n < NQT; ++n) block_max(m[n], acc[n], ex, va, fill, h);
     }
@@ -416,6 +422,35 @@ static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   return check_launch("maxsim_stream_kernel");
 }
 
+template <int DT, int NSL>
+static int launch_stream_inb(const MaxsimArgs& a0, hipStream_t stream) {
+  MaxsimArgs a = a0;
+  const int lds = 2 * kBlkBytes;
+  int64_t waves = (int64_t)kCUs * 4;
+  if (waves > a.n_pairs) waves = a.n_pairs;
+  a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
+  waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  if constexpr (NSL <= 4) {
+    if (a.Q > 32) {
+      hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, 2, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+      return check_launch("maxsim_stream_kernel<all pairs>");
+    }
+  }
+  hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, 1, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  return check_launch("maxsim_stream_kernel<all pairs>");
+}
+
+template <int DT>
+static int launch_stream_inb_cfg(const MaxsimArgs& a, hipStream_t stream) {
+  switch (a.E / 128) {
+    case 1: return launch_stream_inb<DT, 1>(a, stream);
+    case 2: return launch_stream_inb<DT, 2>(a, stream);
+    case 3: return launch_stream_inb<DT, 3>(a, stream);
+    case 4: return launch_stream_inb<DT, 4>(a, stream);
+    default: return launch_stream_inb<DT, 6>(a, stream);
+  }
+}
+
 template <int DT, int NSL, bool RAG>
 static int launch_stream_nsl(const MaxsimArgs& a, hipStream_t stream) {
   const bool nt = env().maxsim_nt != 0;
@@ -526,6 +561,14 @@ extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, Bq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, Bd, D, &ws, &left, stream, &a.dm)) return e;
+  // the streaming kernel in all-pairs mode (query tile resident, documents of one query consecutive: no non-temporal
+  // hint, every document is read once per query); Q > 32 at E = 768 and fp32 stay on the one-wavefront-per-pair kernel
+  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
+                         (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
+  if (stream_ok) {
+    a.ppq = Bd;
+    return dtype == MM_BF16 ? launch_stream_inb_cfg<MM_BF16>(a, stream) : launch_stream_inb_cfg<MM_F16>(a, stream);
+  }
   return launch_generic(a, dtype, stream);
 }
 

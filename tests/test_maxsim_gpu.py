@@ -273,3 +273,33 @@ def test_pair_per_row_layout_with_tokenizer_masks(dtype, Q, D, E):
             rep = ops.maxsim(q[:1].expand(B, -1, -1).contiguous().to(dev), d.to(dev), qm[:1].expand(B, -1).contiguous().to(dev),
                              dm.to(dev), pairs_per_query=1)
             assert torch.equal(shared, rep)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bq,Bd,Q,D,E", [(70, 300, 32, 180, 128), (9, 1100, 38, 200, 128), (33, 33, 30, 64, 768), (5, 2000, 20, 47, 256)])
+def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
+    """forward_inbatch_aggregation (colbert.py:154-162) at teacher-batch sizes: the streaming kernel in all-pairs mode
+    (query tile resident, documents of one query consecutive) — holes, empty documents, padded queries, Bq != Bd,
+    Q = 38 (two query tiles), both masking conventions (by document j; by row i as the reference's :158 does)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Bq * 7 + Bd)
+    q = (torch.randn(Bq, Q, E, generator=g) / E ** 0.5).to(dtype)
+    d = (torch.randn(Bd, D, E, generator=g) / E ** 0.5).to(dtype)
+    ql = torch.randint(1, Q + 1, (Bq,), generator=g)
+    dl = torch.randint(0, D + 1, (Bd,), generator=g)
+    dl[0], dl[1] = D, 0
+    qm = (torch.arange(Q)[None] < ql[:, None]).long()
+    dm = (torch.arange(D)[None] < dl[:, None]).long()
+    dm[0, 1] = 0
+    qm[0, 0] = 0
+    out = ops.maxsim_inbatch(q.to(dev), qm.to(dev), d.to(dev), dm.to(dev), bug_compatible=False).cpu().numpy()
+    ref = O.maxsim_inbatch(q.float().numpy(), qm.numpy(), d.float().numpy(), dm.numpy(), bug_compatible=False)
+    np.testing.assert_allclose(out, ref, atol=util.TOL_BF16, rtol=1e-4)
+    if Bq == Bd:
+        bug = ops.maxsim_inbatch(q.to(dev), qm.to(dev), d.to(dev), dm.to(dev), bug_compatible=True).cpu().numpy()
+        np.testing.assert_allclose(bug, O.maxsim_inbatch(q.float().numpy(), qm.numpy(), d.float().numpy(), dm.numpy(), bug_compatible=True),
+                                   atol=util.TOL_BF16, rtol=1e-4)
+    # every row of the matrix equals the paired operator on that query against all documents
+    row = ops.maxsim(q[3:4].to(dev), d.to(dev), qm[3:4].to(dev), dm.to(dev), pairs_per_query=Bd)
+    assert torch.equal(row.cpu(), torch.from_numpy(out[3]))
