@@ -183,6 +183,21 @@ int mm_kernel_pool_ex_fwd(const void* q, const void* d,
                           int Q, int D, int E, int K, int dtype,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Several (query tensor, document tensor) combinations pooled in ONE launch and summed: Conv-KNRM scores every
+ * n-gram width of the query against every n-gram width of the document (n_grams^2 match matrices,
+ * matchmaker/models/conv_knrm.py:130-132) and its dense layer (:137) is a weighted sum over all of them:
+ *   out[p] = sum_{i < n_q, t < n_d} kernel_pool(q_list[i], d_list[t]; bin weights w[(i * n_d + t) * K ...])[p]
+ * (summed in (i, t) order: deterministic).  q_list[i] [n_queries, Q, E], d_list[t] [n_pairs, D, E] float32, one mask
+ * pair for all of them (the n-gram tensors share the token masks).  1 <= n_q, n_d <= 4, K = 11.
+ * Workspace: mm_kernel_pool_multi_workspace_bytes (mask packing + the n_q * n_d partial score rows). */
+size_t mm_kernel_pool_multi_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int n_q, int n_d, int Q, int D,
+                                            int q_mask_kind, int d_mask_kind);
+int mm_kernel_pool_multi_fwd(const void* const* q_list, int n_q, const void* const* d_list, int n_d,
+                             const void* q_mask, int q_mask_kind, const void* d_mask, int d_mask_kind,
+                             const float* mu, const float* sigma, const float* alpha, const float* w,
+                             float clamp_min, float* out, int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                             int E, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of mm_kernel_pool_fwd in the pair-per-row layout (training: train.py:347-348, loss.backward()
  * :503-524; the embedding model is called from neuralIR_encoder.py:86-87).  Gradients of the score w.r.t.
  * the contextualised embeddings and the two trainable pooling parameters (kernel_alpha_scaler

@@ -2,7 +2,7 @@
 forward surface and state_dict keys (`convolutions.<n>.1.{weight,bias}`, `dense.weight`).  The n-gram
 convolutions (:39-46, :120-126) stay PyTorch as in the reference; the n_grams^2 cosine-match + kernel
 pooling blocks (forward_matrix_kernel_pooling, :147-173) run in libmm_native.so through the TK pooling
-kernel: the concatenation + dense layer of :132-137 is a sum over the (i, t) blocks of
+kernel (inference: ONE launch over all n_grams^2 blocks, mm_kernel_pool_multi_fwd): the concatenation + dense layer of :132-137 is a sum over the (i, t) blocks of
 kernel_pool(q_i, d_t, w = 0.01 * dense.weight[block]) — the per-block [B, K] tensors never exist.
 Selected by models/all.py:152.
 """
@@ -66,17 +66,21 @@ class Conv_KNRM(nn.Module):
         qm, dm = query_pad_oov_mask, document_pad_oov_mask
         needs_grad = torch.is_grad_enabled() and (self.dense.weight.requires_grad or q_grams[0].requires_grad)
         mu, sigma = self.mu.view(-1), self.sigma.view(-1)
-        score = None
-        block = 0
-        for qg in q_grams:                                                     # :130-132, same (i, t) order as the concat
-            for dg in d_grams:
-                wb = w[block * K:(block + 1) * K]
-                if needs_grad:
-                    s = _KernelPoolFn.apply(qg, dg, qm.float(), dm.float(), mu, sigma, self._ones, wb)
-                else:
-                    s = ops.kernel_pool(qg, dg, qm, dm, mu, sigma, self._ones, wb)
-                score = s if score is None else score + s
-                block += 1
+        if not needs_grad and K == 11 and len(q_grams) <= 4:
+            # inference: all n_grams^2 match matrices in one launch, summed in the concat's (i, t) order
+            score = ops.kernel_pool_multi(q_grams, d_grams, qm, dm, mu, sigma, self._ones, w)
+        else:
+            score = None
+            block = 0
+            for qg in q_grams:                                                 # :130-132, same (i, t) order as the concat
+                for dg in d_grams:
+                    wb = w[block * K:(block + 1) * K]
+                    if needs_grad:
+                        s = _KernelPoolFn.apply(qg, dg, qm.float(), dm.float(), mu, sigma, self._ones, wb)
+                    else:
+                        s = ops.kernel_pool(qg, dg, qm, dm, mu, sigma, self._ones, wb)
+                    score = s if score is None else score + s
+                    block += 1
         if output_secondary_output:
             return score, {}
         return score

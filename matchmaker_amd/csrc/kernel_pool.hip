@@ -348,8 +348,9 @@ __device__ __forceinline__ void load_q_slice_split(const char* base, const char*
 
 
 template <int NS, int K, int NBUF, bool NT, bool TKL, bool W = false>
-__global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a) {
+__global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in) {
   static_assert(!(TKL && W), "the gate is a TK-Sparse feature");
+  const KpArgs a = kp_block_args(a_in);
   static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -1249,7 +1250,8 @@ int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int3
 // generic kernel: one wavefront per pair, direct fragment loads, any E % 4 == 0, any Q / D.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool TKL, bool W = false>
-__global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a) {
+__global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a_in) {
+  const KpArgs a = kp_block_args(a_in);
   __shared__ float rdbuf[32];
   __shared__ float lwbuf[32];
   const int lane = threadIdx.x;
@@ -1370,10 +1372,10 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  const dim3 grid((unsigned)waves), block(64);
+  const dim3 grid((unsigned)waves, (unsigned)(a.n_md > 0 ? a.n_mblk : 1)), block(64);
   // MM_KP_F32MFMA=1 selects the exact-f32 MFMA kernel (A/B runs, tools/bench_kernel_pool.py);
   // the default is the split-bf16 kernel (same numerics class, 4x less matrix-pipe time)
-  if (env().kp_f32mfma && !W && !a.pair_q) {
+  if (env().kp_f32mfma && !W && !a.pair_q && a.n_md == 0) {
     if (a.E == 100)
       hipLaunchKernelGGL((kernel_pool_stream_kernel<1, K, NBUF, true, TKL>), grid, block, lds, stream, a);
     else if (a.E == 200)
@@ -1439,7 +1441,8 @@ static int launch_k(const KpArgs& a0, hipStream_t stream) {
   }
   if (stream_ok) return launch_stream<K, false>(a, stream);
   if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
-  hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false>), dim3((unsigned)a.n_pairs, (unsigned)(a.n_md > 0 ? a.n_mblk : 1)), dim3(64), 0,
+                     stream, a);
   return check_launch("kernel_pool_generic_kernel");
 }
 
@@ -1491,6 +1494,65 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
   else
     hipLaunchKernelGGL((kernel_pool_generic_kernel<kMaxK, false, false>), dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   return check_launch("kernel_pool_generic_kernel<run-time K>");
+}
+
+// out[p] = sum over the partial rows, in block order (deterministic)
+__global__ void __launch_bounds__(256) kp_sum_blocks_kernel(const float* __restrict__ partial, int64_t n, int nblk,
+                                                            float* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  float s = 0.0f;
+  for (int y = 0; y < nblk; ++y) s += partial[(int64_t)y * n + p];
+  out[p] = s;
+}
+
+extern "C" size_t mm_kernel_pool_multi_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int n_q, int n_d, int Q, int D,
+                                                        int q_mask_kind, int d_mask_kind) {
+  return mm_kernel_pool_workspace_bytes(n_pairs, pairs_per_query, Q, D, q_mask_kind, d_mask_kind) +
+         (((size_t)n_q * n_d * (size_t)n_pairs * 4 + 255) & ~(size_t)255);
+}
+
+extern "C" int mm_kernel_pool_multi_fwd(const void* const* q_list, int n_q, const void* const* d_list, int n_d,
+                                        const void* q_mask, int q_mask_kind, const void* d_mask, int d_mask_kind,
+                                        const float* mu, const float* sigma, const float* alpha, const float* w,
+                                        float clamp_min, float* out, int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                                        int E, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q_list || !d_list || !out || !mu || !sigma || !alpha || !w) return set_error(MM_EINVAL, "kernel_pool_multi: null pointer");
+  if (n_q < 1 || n_q > 4 || n_d < 1 || n_d > 4) return set_error(MM_EUNSUPPORTED, "kernel_pool_multi: 1..4 query and document tensors");
+  if (dtype != MM_F32) return set_error(MM_EUNSUPPORTED, "kernel_pool_multi: float32 only");
+  if (n_pairs < 0 || Q <= 0 || D <= 0 || E <= 0 || pairs_per_query <= 0) return set_error(MM_EINVAL, "kernel_pool_multi: bad shape");
+  if (!(clamp_min > 0.0f)) return set_error(MM_EINVAL, "kernel_pool_multi: clamp_min must be > 0");
+  if (K != 11) return set_error(MM_EUNSUPPORTED, "kernel_pool_multi: K=%d kernels (the 11-kernel instantiation only)", K);
+  if (E % 4) return set_error(MM_EUNSUPPORTED, "kernel_pool_multi: E=%d rows are not 16-byte multiples", E);
+  if (n_pairs == 0) return MM_OK;
+  if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool_multi: too many pairs for one launch");
+  KpArgs a{};
+  for (int i = 0; i < n_q; ++i) {
+    if (!q_list[i] || ((uintptr_t)q_list[i] & 15)) return set_error(MM_EINVAL, "kernel_pool_multi: query tensor %d null / not 16-byte aligned", i);
+    a.mq[i] = (const float*)q_list[i];
+  }
+  for (int t = 0; t < n_d; ++t) {
+    if (!d_list[t] || ((uintptr_t)d_list[t] & 15)) return set_error(MM_EINVAL, "kernel_pool_multi: document tensor %d null / not 16-byte aligned", t);
+    a.md[t] = (const float*)d_list[t];
+  }
+  a.q = a.mq[0]; a.d = a.md[0];
+  a.n_md = n_d; a.n_mblk = n_q * n_d;
+  a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w;
+  a.n_pairs = n_pairs; a.ppq = pairs_per_query; a.Q = Q; a.D = D; a.E = E; a.K = K;
+  a.d_doc_rows = D; a.d_row0 = 0; a.clamp_min = clamp_min;
+  char* ws = (char*)workspace;
+  size_t left = workspace ? workspace_bytes : 0;
+  const int64_t q_rows = (n_pairs + pairs_per_query - 1) / pairs_per_query;
+  if (int e = resolve_mask(q_mask, q_mask_kind, q_rows, Q, &ws, &left, stream, &a.qm)) return e;
+  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  const size_t need = (size_t)a.n_mblk * (size_t)n_pairs * 4;
+  if (!ws || left < need) return set_error(MM_EWORKSPACE, "kernel_pool_multi: workspace needs %zu more bytes", need);
+  float* partial = (float*)ws;
+  a.out = partial;
+  if (int e = launch_k<11>(a, stream)) return e;
+  hipLaunchKernelGGL(kp_sum_blocks_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, partial, n_pairs, a.n_mblk, out);
+  return check_launch("kp_sum_blocks_kernel");
 }
 
 extern "C" int mm_kernel_pool_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,

@@ -79,8 +79,9 @@ __device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint
 // MX: 0 = kernel pooling; 1 = fp32 MaxSim with the two-term split (4 MFMAs per K step); 2 = fp32 MaxSim with the
 // three-term split x = hi + lo + c (6 MFMAs: + c.hi and hi.c; operand error 2^-25, i.e. fp32-class scores)
 template <int NSL, int K, bool W, int KS, int MX = 0>
-__global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a) {
+__global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a_in) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
+  const KpArgs a = kp_block_args(a_in);
   static_assert(!MX || !W, "the fp32 MaxSim mode has no gate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = kS128Nbuf;
@@ -467,7 +468,7 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
   if (groups > a.n_pairs) groups = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
   groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  const dim3 grid((unsigned)groups);
+  const dim3 grid((unsigned)groups, (unsigned)(a.n_md > 0 ? a.n_mblk : 1));
 #define MM_KP128(NSL, KS) \
   return gated ? launch128<NSL, true, KS>(a, grid, lds, stream) : launch128<NSL, false, KS>(a, grid, lds, stream)
   switch (nsl) {

@@ -39,7 +39,26 @@ struct KpArgs {
   //   pair_q != nullptr: the query of pair p is row pair_q[p] of q (ragged groups: IDCM's packed passages);
   //   overrides ppq
   const int32_t* pair_q;
+  // several (query tensor, document tensor) combinations in ONE launch (Conv-KNRM's n_grams^2 match matrices,
+  // conv_knrm.py:130-132): blockIdx.y = i * n_md + t scores q = mq[i] against d = md[t] with the bin weights
+  // w + y * K and writes its scores to out + y * n_pairs (summed in block order afterwards).  n_md = 0: one combination.
+  const float* mq[4];
+  const float* md[4];
+  int n_md;
+  int n_mblk;  // n_mq * n_md = grid.y (0 when n_md = 0)
 };
+
+__device__ __forceinline__ KpArgs kp_block_args(const KpArgs& a) {
+  KpArgs b = a;
+  if (a.n_md > 0) {
+    const int y = blockIdx.y, i = y / a.n_md, t = y - i * a.n_md;
+    b.q = a.mq[i];
+    b.d = a.md[t];
+    b.w = a.w + y * a.K;
+    b.out = a.out + (int64_t)y * a.n_pairs;
+  }
+  return b;
+}
 
 __device__ __forceinline__ constexpr int rowof(int i) { return (i & 3) + 8 * (i >> 2); }
 

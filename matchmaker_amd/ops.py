@@ -284,6 +284,52 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     return (out, pk) if return_per_kernel else out
 
 
+def kernel_pool_multi(q_list, d_list, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor], mu: torch.Tensor,
+                      sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor, clamp_min: float = 1e-10) -> torch.Tensor:
+    """Sum over all (i, t) of kernel_pool(q_list[i], d_list[t], bin weights w[i * len(d_list) + t]) in ONE launch
+    (+ a deterministic sum): Conv-KNRM's n_grams^2 match matrices and its dense layer (conv_knrm.py:130-137).
+    q_list[i] [B, Q, E], d_list[t] [B, D, E] float32 (pair-per-row), w [len(q_list) * len(d_list), K].  Returns [B]."""
+    import ctypes
+    q_list = [_emb(t, "q") for t in q_list]
+    d_list = [_emb(t, "d") for t in d_list]
+    dev = _dev_check(*q_list, *d_list, q_mask, d_mask, mu, sigma, alpha, w)
+    B, Q, E = q_list[0].shape
+    D = d_list[0].shape[1]
+    for t in q_list:
+        if tuple(t.shape) != (B, Q, E) or t.dtype != torch.float32:
+            raise NativeError(f"kernel_pool_multi: query tensors must all be float32 [{B},{Q},{E}]")
+    for t in d_list:
+        if tuple(t.shape) != (B, D, E) or t.dtype != torch.float32:
+            raise NativeError(f"kernel_pool_multi: document tensors must all be float32 [{B},{D},{E}]")
+    nq_, nd_ = len(q_list), len(d_list)
+    K = mu.numel()
+    f = lambda t: t.detach().reshape(-1).to(torch.float32).contiguous()
+    mu, sigma, alpha, w = f(mu), f(sigma), f(alpha), f(w)
+    if w.numel() != nq_ * nd_ * K or sigma.numel() != K or alpha.numel() != K:
+        raise NativeError("kernel_pool_multi: w must hold K weights per (query tensor, document tensor) combination")
+    if E % 4:
+        pad = (0, 4 - E % 4)
+        q_list = [torch.nn.functional.pad(t, pad) for t in q_list]
+        d_list = [torch.nn.functional.pad(t, pad) for t in d_list]
+        E = q_list[0].shape[-1]
+    qm, qp, qk = _mask(q_mask, B, Q, "q_mask")
+    dm, dp, dk = _mask(d_mask, B, D, "d_mask")
+    L = _lib.lib()
+    out = torch.empty(B, dtype=torch.float32, device=dev)
+    if B == 0:
+        return out
+    qa = (ctypes.c_void_p * nq_)(*[t.data_ptr() for t in q_list])
+    da = (ctypes.c_void_p * nd_)(*[t.data_ptr() for t in d_list])
+    with torch.cuda.device(dev):
+        wsb = L.mm_kernel_pool_multi_workspace_bytes(B, 1, nq_, nd_, Q, D, qk, dk)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = L.mm_kernel_pool_multi_fwd(ctypes.cast(qa, ctypes.c_void_p), nq_, ctypes.cast(da, ctypes.c_void_p), nd_, qp, qk, dp, dk,
+                                        mu.data_ptr(), sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
+                                        out.data_ptr(), B, 1, Q, D, E, K, _lib.MM_F32, ws.data_ptr(), wsb, _stream(dev))
+    _lib.check(rc, "mm_kernel_pool_multi_fwd")
+    return out
+
+
 def _gate(d_gate, B, D):
     if d_gate is None:
         return None

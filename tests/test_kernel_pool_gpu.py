@@ -235,3 +235,31 @@ def test_short_queries_take_the_redistributed_epilogue(qlen, E, gated):
                                    dtype=np.float64, return_per_kernel=True)
     np.testing.assert_allclose(pk.cpu().numpy(), ref_pk, atol=5e-3, rtol=1e-4)
     np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+@pytest.mark.parametrize("E,D", [(128, 180), (64, 50), (300, 70), (36, 33)])
+def test_multi_block_pooling_equals_the_sum_of_single_launches(E, D):
+    """mm_kernel_pool_multi_fwd (Conv-KNRM: n_grams^2 match matrices in one launch, conv_knrm.py:130-137) vs the sum of
+    per-combination launches and vs the oracle — on the 64n, 100n and generic kernel families."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(E + D)
+    B, Q, n = 37, 12, 3
+    qs = [torch.relu(torch.randn(B, Q, E, generator=g)) for _ in range(n)]
+    ds = [torch.relu(torch.randn(B, D, E, generator=g)) for _ in range(n)]
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B,), generator=g)[:, None]).float()
+    dm = (torch.arange(D)[None] < torch.randint(0, D + 1, (B,), generator=g)[:, None]).float()
+    mu, sigma = torch.tensor(MU), torch.tensor(SIGMA)
+    ones = torch.ones(11)
+    w = torch.randn(n * n, 11, generator=g) * 0.01
+    t = lambda x: x.to(dev)
+    got = ops.kernel_pool_multi([t(x) for x in qs], [t(x) for x in ds], t(qm), t(dm), t(mu), t(sigma), t(ones), t(w))
+    want = torch.zeros(B, device=dev)
+    ref = np.zeros(B)
+    for i in range(n):
+        for j in range(n):
+            want = want + ops.kernel_pool(t(qs[i]), t(ds[j]), t(qm), t(dm), t(mu), t(sigma), t(ones), t(w[i * n + j]))
+            ref += O.tk_kernel_pool(qs[i].numpy(), ds[j].numpy(), qm.numpy(), dm.numpy(), MU, SIGMA, ones.numpy(),
+                                    w[i * n + j].numpy(), dtype=np.float64)
+    assert torch.equal(got, want)           # same kernels, same (i, t) summation order
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
