@@ -261,6 +261,21 @@ int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask,
                int64_t B, int64_t P, int C, int Q, int E, int K, int saturation,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of mm_tkl_fwd (training: train.py:503-524 through sigir20_tkl.py:180-286).  The document score is a weighted
+ * sum of at most 15 window scores whose indices are piecewise constant, so the exact gradient involves only those windows:
+ * they are recomputed from the contextualised vectors and differentiated on the device.
+ *   win_scores [B, W]  the forward's window scores (selects the windows; 0 = empty window = constant)
+ *   grad_out [B];  grad_q [B, Q, E];  grad_chunks [P, 50, E] (zeroed by the call; only rows of selected windows are non-zero);
+ *   grad_params [B, MM_TKL_NPARAMS(K, E)]: per-document gradients in the layout of `params` (mu / sigma columns are 0) —
+ *   sum over the documents on the host side (deterministic, no atomics).  Q <= 32.
+ * Workspace: mm_tkl_bwd_workspace_bytes(B, C). */
+size_t mm_tkl_bwd_workspace_bytes(int64_t B, int C);
+int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
+               const float* q_mask, const float* params, const float* win_scores, const float* grad_out,
+               float* grad_q, float* grad_chunks, float* grad_params,
+               int64_t B, int64_t P, int C, int Q, int E, int K, int saturation,
+               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Brute-force inner-product top-k over one GPU's shard of the collection (dense retrieval).
  *

@@ -423,6 +423,42 @@ def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tenso
     return (out, win) if return_windows else out
 
 
+def tkl_bwd(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor, chunk_slot: torch.Tensor,
+            q_mask: torch.Tensor, params: torch.Tensor, win: torch.Tensor, grad_out: torch.Tensor, B: int, C: int, K: int,
+            saturation: str = "embedding"):
+    """Backward of tkl_score (mm_tkl_bwd): returns float32 (grad_q_ctx [B,Q,E], grad_chunks [P,50,E],
+    grad_params [MM_TKL_NPARAMS] summed over the documents, in the layout of `params`)."""
+    dev = _dev_check(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, win, grad_out)
+    q_ctx, chunks = _emb(q_ctx.detach(), "q_ctx"), _emb(chunks.detach(), "chunks")
+    if q_ctx.dtype != torch.float32 or chunks.dtype != torch.float32:
+        raise NativeError("tkl_bwd: float32 only")
+    Bq, Q, E = q_ctx.shape
+    P = chunks.shape[0]
+    sat = {"embedding": _lib.TKL_SAT_EMBEDDING, "log": _lib.TKL_SAT_LOG}.get(saturation)
+    if sat is None or Bq != B or (P and (chunks.shape[1] != 50 or chunks.shape[2] != E)):
+        raise NativeError(f"tkl_bwd: bad arguments (saturation {saturation!r}, q_ctx {tuple(q_ctx.shape)}, chunks {tuple(chunks.shape)})")
+    chunk_mask = chunk_mask.to(torch.float32).contiguous()
+    chunk_slot = chunk_slot.to(torch.int32).contiguous()
+    q_mask = q_mask.to(torch.float32).contiguous()
+    params = params.detach().to(torch.float32).contiguous()
+    win = win.detach().to(torch.float32).contiguous()
+    go = grad_out.detach().reshape(-1).to(torch.float32).contiguous()
+    NP = params.numel()
+    gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
+    gc = torch.empty((P, 50, E), dtype=torch.float32, device=dev)
+    gp = torch.empty((B, NP), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        wsb = L.mm_tkl_bwd_workspace_bytes(B, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = L.mm_tkl_bwd(q_ctx.data_ptr(), chunks.data_ptr() if P else None, chunk_mask.data_ptr() if P else None,
+                          chunk_slot.data_ptr() if P else None, q_mask.data_ptr(), params.data_ptr(), win.data_ptr(), go.data_ptr(),
+                          gq.data_ptr(), gc.data_ptr() if P else None, gp.data_ptr(), B, P, C, Q, E, K, sat, ws.data_ptr(), wsb,
+                          _stream(dev))
+    _lib.check(rc, "mm_tkl_bwd")
+    return gq, gc, gp.sum(0)
+
+
 def dot_topk(queries: torch.Tensor, corpus: torch.Tensor, k: int, max_rounds: int = 6):
     """Exact brute-force inner-product top-k over one shard (faiss IndexFlatIP.search semantics;
     matchmaker/retrieval/faiss_indices.py:22-36, :49-74; score = bert_dot.py:62).

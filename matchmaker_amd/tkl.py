@@ -8,9 +8,11 @@ saturation, dense layer, top-3 region scoring (:180-286) — runs in libmm_nativ
 
 Training (train.py:347-348, loss.backward() :503-524): the document score is a weighted sum of at most 15
 window scores (3 regions x 5 neighbours, :257-286) and the region choice is piecewise constant, so the
-exact gradient only involves those windows.  The forward value and the window scores come from the native
-kernels; the 15 selected windows per document (30 tokens each, out of up to 2,000) are then re-evaluated
-with differentiable torch ops on the device to carry the gradient (`_selected_window_scores`).
+exact gradient only involves those windows.  Forward AND backward are native: `_TKLScoreFn` wraps mm_tkl_fwd /
+mm_tkl_bwd (the backward kernel recomputes the 15 selected windows of each document — 30 tokens each, out of up
+to 2,000 — and differentiates them: gradients w.r.t. the contextualised query, the contextualised chunk rows and
+every scoring parameter).  `_selected_window_scores` is the same computation in differentiable torch ops; it is
+kept as the reference the native backward is tested against, not used by forward().
 """
 from typing import List
 
@@ -50,6 +52,40 @@ def chunk_documents(document_embeddings: torch.Tensor, document_mask: torch.Tens
         torch.arange(EXT_CHUNK, device=emb.device)
     chunks = emb.reshape(-1, E)[flat]                       # gather only the kept chunks
     return chunks, chunk_mask[chunk_slot], chunk_slot.to(torch.int32), C
+
+
+class _TKLScoreFn(torch.autograd.Function):
+    """mm_tkl_fwd / mm_tkl_bwd behind autograd.  `scoring` are the parameter tensors in pack order (see
+    TKL_sigir20._pack): their gradients come back as slices of the packed gradient vector."""
+
+    @staticmethod
+    def forward(ctx, q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, meta, *scoring):
+        B, C, K, saturation, packed, sizes = meta
+        score, win = ops.tkl_score(q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, packed, B, C, K, saturation,
+                                   return_windows=True)
+        ctx.save_for_backward(q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, packed, win)
+        ctx.meta = (B, C, K, saturation, sizes, [t.shape for t in scoring], [t.dtype for t in scoring])
+        ctx.mark_non_differentiable(win)
+        return score, win
+
+    @staticmethod
+    def backward(ctx, g, _gwin):
+        q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, packed, win = ctx.saved_tensors
+        B, C, K, saturation, sizes, shapes, dtypes = ctx.meta
+        gq, gc, gp = ops.tkl_bwd(q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, packed, win, g, B, C, K, saturation)
+        grads, off = [], 0
+        for n, shp, dt in zip(sizes, shapes, dtypes):
+            if n is None:                       # a parameter the kernels do not read in this configuration
+                grads.append(None)
+                continue
+            lo, cnt, full = n
+            gpar = gp[lo:lo + cnt]
+            if full != cnt:                     # kernel_mult [4,1,1,1,K]: only row 0 is used (:246)
+                z = torch.zeros(full, dtype=gpar.dtype, device=gpar.device)
+                z[:cnt] = gpar
+                gpar = z
+            grads.append(gpar.reshape(shp).to(dt))
+        return (gq.to(q_ctx.dtype), gc.to(chunks_ctx.dtype), None, None, None, None, *grads)
 
 
 class TKL_sigir20(nn.Module):
@@ -165,15 +201,16 @@ class TKL_sigir20(nn.Module):
         else:
             chunks_ctx = chunks
         K = self.mu.numel()
-        with torch.no_grad():
-            score, win = ops.tkl_score(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
-                                       self.pack_params(), B, C, K, "embedding" if self.use_embedding_sat else "log",
-                                       return_windows=True)
+        saturation = "embedding" if self.use_embedding_sat else "log"
         if torch.is_grad_enabled() and (query_ctx.requires_grad or chunks_ctx.requires_grad or
                                         any(p.requires_grad for p in self._scoring_parameters())):
-            carrier = self._selected_window_scores(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot,
-                                                   query_pad_oov_mask, win, C)
-            score = score + (carrier - carrier.detach())     # the native value, the gradient of the selected windows
+            scoring, sizes = self._pack_layout()
+            score, win = _TKLScoreFn.apply(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
+                                           (B, C, K, saturation, self.pack_params(), sizes), *scoring)
+        else:
+            with torch.no_grad():
+                score, win = ops.tkl_score(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
+                                           self.pack_params(), B, C, K, saturation, return_windows=True)
         if output_secondary_output:
             query_mean_vector = query_ctx.sum(dim=1) / query_pad_oov_mask.sum(dim=1).unsqueeze(-1)
             return score, {"score": score, "orig_score": win, "orig_doc_len": document_pad_oov_mask.sum(dim=-1),
@@ -181,7 +218,22 @@ class TKL_sigir20(nn.Module):
                            "query_mean_vector": query_mean_vector}
         return score
 
-    # ------------------------------------------------------------------ gradient carrier (training)
+    # ------------------------------------------------------------------ training
+    def _pack_layout(self):
+        """The parameter tensors in the order of the packed vector (pack_params) with (offset, used length, numel) per
+        tensor; None for tensors the native scoring does not read (mu / sigma are constants)."""
+        K, E = self.mu.numel(), self.sat_emb_reduce1.weight.numel()
+        o_dense, o_km, o_sat, o_cs, o_emb = 2 * K, 3 * K, 4 * K, 4 * K + 13, 4 * K + 28
+        scoring = [self.dense.weight, self.kernel_mult,
+                   self.saturation_linear.weight, self.saturation_linear.bias,
+                   self.saturation_linear2.weight, self.saturation_linear2.bias,
+                   self.saturation_linear3.weight, self.saturation_linear3.bias,
+                   self.sat_normer.weight, self.sat_normer.bias, self.chunk_scoring, self.sat_emb_reduce1.weight]
+        sizes = [(o_dense, K, K), (o_km, K, self.kernel_mult.numel()),
+                 (o_sat + 0, 2, 2), (o_sat + 2, 1, 1), (o_sat + 3, 2, 2), (o_sat + 5, 1, 1), (o_sat + 6, 2, 2), (o_sat + 8, 1, 1),
+                 (o_sat + 9, 2, 2), (o_sat + 11, 2, 2), (o_cs, 15, 15), (o_emb, E, E)]
+        return scoring, sizes
+
     def _scoring_parameters(self):
         ps = [self.dense.weight, self.chunk_scoring]
         if self.use_embedding_sat:

@@ -120,4 +120,20 @@ def _(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, B, C, K, saturation
     return q_ctx.new_empty((B,), dtype=torch.float32), q_ctx.new_empty((B, W), dtype=torch.float32)
 
 
+def _tkl_setup(ctx, inputs, output):
+    q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, B, C, K, saturation = inputs
+    ctx.save_for_backward(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, output[1])
+    ctx.meta = (B, C, K, saturation)
+
+
+def _tkl_backward(ctx, g, _gwin):
+    """mm_tkl_bwd: gradients w.r.t. the contextualised query, the contextualised chunks and the packed parameter vector
+    (the window scores are an auxiliary output: no gradient flows through them)."""
+    q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, win = ctx.saved_tensors
+    B, C, K, saturation = ctx.meta
+    gq, gc, gp = ops.tkl_bwd(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, win, g, B, C, K, saturation)
+    return gq.to(q_ctx.dtype), gc.to(chunks.dtype), None, None, None, gp.view_as(params).to(params.dtype), None, None, None, None
+
+
+tkl_window_pool.register_autograd(_tkl_backward, setup_context=_tkl_setup)
 torch.library.register_autocast(_NS + "::tkl_window_pool", "cuda", torch.float32)

@@ -217,3 +217,65 @@ def test_tkl_full_model_trains_end_to_end():
     with torch.no_grad():
         s1 = m.forward(q, d, qm, dm)
     assert torch.isfinite(s1).all() and not torch.equal(s0.detach(), s1)
+
+
+@pytest.mark.parametrize("sat", ["embedding", "log"])
+@pytest.mark.parametrize("B,Q,D,E", [(4, 20, 2048, 300), (3, 7, 120, 64), (2, 32, 41, 128)])
+def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, D, E):
+    """mm_tkl_bwd vs autograd through `_selected_window_scores` (the same 15-window computation in torch ops, itself pinned on
+    the real class's gradients above): gradients w.r.t. the contextualised query, the contextualised chunks and every
+    scoring parameter, on documents long enough for three separate regions, short ones (clamped / duplicate neighbour
+    indices) and ragged lengths."""
+    from matchmaker_amd.tkl import chunk_documents
+    dev = util.require_gpu()
+    torch.manual_seed(B * 100 + Q + D)
+    m = make_model(E, sat, dev, bypass=True).train()
+    with torch.no_grad():      # move the saturation off its init plateau so that every parameter carries gradient
+        for lin in (m.saturation_linear, m.saturation_linear2, m.saturation_linear3):
+            lin.bias.fill_(2.0)
+            lin.weight.normal_(0, 0.3)
+        m.sat_normer.weight.normal_(1.0, 0.2)
+        m.chunk_scoring.normal_(1.0, 0.3)
+        m.kernel_mult.normal_(1.0, 0.1).abs_()
+    q = torch.randn(B, Q, E, device=dev)
+    d = torch.randn(B, D, E, device=dev)
+    d[0, 7] = q[0, 1] * 1.5                                      # planted matches -> activity in the high-mu kernels
+    ql = torch.randint(1, Q + 1, (B,), device=dev)
+    dl = torch.randint(D // 3 + 1, D + 1, (B,), device=dev)
+    dl[0] = D
+    qm = (torch.arange(Q, device=dev)[None] < ql[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < dl[:, None]).float()
+    go = torch.randn(B, device=dev)
+    names = ["dense.weight", "chunk_scoring"] + (["saturation_linear.weight", "saturation_linear.bias", "saturation_linear2.weight",
+             "saturation_linear2.bias", "saturation_linear3.weight", "saturation_linear3.bias", "sat_normer.weight",
+             "sat_normer.bias", "sat_emb_reduce1.weight"] if sat == "embedding" else ["kernel_mult"])
+    params = dict(m.named_parameters())
+
+    def run(native):
+        for p in m.parameters():
+            p.grad = None
+        q_ctx = (q * qm.unsqueeze(-1)).detach().requires_grad_(True)
+        chunks, cmask, slot, C = chunk_documents(d * dm.unsqueeze(-1), dm)
+        chunks = chunks.detach().requires_grad_(True)
+        if native:
+            from matchmaker_amd.tkl import _TKLScoreFn
+            scoring, sizes = m._pack_layout()
+            s, _ = _TKLScoreFn.apply(q_ctx, chunks, cmask, slot, qm, (B, C, 11, sat, m.pack_params(), sizes), *scoring)
+        else:
+            with torch.no_grad():
+                _, win = ops_tkl(q_ctx, chunks, cmask, slot, qm, m, B, C, sat)
+            s = m._selected_window_scores(q_ctx, chunks, cmask, slot, qm, win, C)
+        (s * go).sum().backward()
+        return s.detach(), q_ctx.grad, chunks.grad, {k: params[k].grad.clone() for k in names}
+
+    s_n, gq_n, gc_n, gp_n = run(True)
+    s_t, gq_t, gc_t, gp_t = run(False)
+    torch.testing.assert_close(s_n, s_t, rtol=1e-4, atol=1e-3)
+    for got, want, name in [(gq_n, gq_t, "grad_q"), (gc_n, gc_t, "grad_chunks")] + [(gp_n[k], gp_t[k], k) for k in names]:
+        scale = max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(got, want, rtol=2e-3, atol=3e-4 * scale, msg=lambda m_, n=name: f"{n}: {m_}")
+
+
+def ops_tkl(q_ctx, chunks, cmask, slot, qm, m, B, C, sat):
+    from matchmaker_amd import ops
+    return ops.tkl_score(q_ctx.detach(), chunks.detach(), cmask, slot, qm, m.pack_params(), B, C, 11, sat, return_windows=True)

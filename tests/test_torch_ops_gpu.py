@@ -83,6 +83,18 @@ def test_tkl_window_pool_op_equals_the_dropin_path():
         chunks_ctx, _ = m.forward_representation(chunks, cmask)
         score, win = torch.ops.mm_native.tkl_window_pool(q_ctx, chunks_ctx, cmask, slot, qm, m.pack_params(), B, C, 11, "embedding")
     assert torch.equal(score, want) and torch.equal(win, sec["orig_score"])
+    # autograd through the registered op = mm_tkl_bwd: the same gradients as the drop-in's training path
+    q_l = q_ctx.clone().requires_grad_(True)
+    c_l = chunks_ctx.clone().requires_grad_(True)
+    p_l = m.pack_params().clone().requires_grad_(True)
+    s2, _ = torch.ops.mm_native.tkl_window_pool(q_l, c_l, cmask, slot, qm, p_l, B, C, 11, "embedding")
+    s2.sum().backward()
+    m.train()
+    q2, d2 = q.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    m.forward(q2, d2, qm, dm).sum().backward()
+    assert torch.isfinite(q_l.grad).all() and float(c_l.grad.abs().sum()) > 0
+    torch.testing.assert_close(p_l.grad[22:33], m.dense.weight.grad.view(-1), rtol=1e-5, atol=1e-6)     # dense block of the packed vector
+    torch.testing.assert_close(q_l.grad * qm.unsqueeze(-1), q2.grad, rtol=1e-4, atol=1e-5)             # bypass model: q_ctx = q * mask
 
 
 def test_operators_are_reentrant_across_threads_and_streams():
