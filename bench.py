@@ -198,6 +198,39 @@ def extra_dropin_forward(q, d, q_len, d_len, steps):
             "bit_identical_to_shared_q_scores": same, "profile": "profiles/r02_dropin_pmc.json"}
 
 
+def extra_sustained(score_shard, B, seconds=4.0):
+    """The same launch back to back for a few seconds of wall clock: long enough for an external sampler (rocm-smi at a
+    multi-second cadence) to see the GPU busy, and a cross-check of the 20-step figure on the host clock."""
+    import torch
+    score_shard()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(100):
+            score_shard()
+        torch.cuda.synchronize()
+        n += 100
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"workload": "the headline launch repeated back to back", "steps": n, "seconds": dt, "ms_per_step": 1e3 * dt / n,
+            "pairs_per_s": n * B / dt}
+
+
+def tk_exact_f32_subprocess():
+    """TK pooling on the exact-f32 MFMA kernel (MM_KP_F32MFMA=1, read once per process -> a child process), timed
+    beside the split-bf16 default: VERDICT r01 asked for the A/B in the driver-timed line."""
+    env = dict(os.environ, MM_KP_F32MFMA="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_kernel_pool.py"), "--full", "--queries", "64", "--steps", "5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            j = json.loads(line)
+            return {"kernel": "kernel_pool_stream_kernel (v_mfma_f32_32x32x2_f32, exact fp32 operands)", "ms": j["ms"],
+                    "pairs_per_s": j["pairs_per_s"], "GBps": j["GBps_padded_bytes"]}
+    return {"error": (r.stderr or r.stdout)[-300:]}
+
+
 def extra_tk(steps, cpu_budget):
     """BASELINE.json configs[0] shapes (TK kernel pooling, Q=20 / D=200 / dim=300, fp32) at GPU scale:
     64 queries x 1000 candidates, every position real (the padded figure of DESIGN.md §3.3)."""
@@ -223,6 +256,15 @@ def extra_tk(steps, cpu_budget):
            "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by, "flop": B * (2 * Qt * Dt * Et + 2 * (Qt + Dt) * Et),
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
            "kernel": "kernel_pool_split_kernel", "profile": "profiles/r02_tk_pmc.json"}
+    del q, d
+    torch.cuda.empty_cache()
+    try:
+        out["exact_f32_mfma"] = tk_exact_f32_subprocess()
+    except Exception as e:
+        out["exact_f32_mfma"] = {"error": repr(e)}
+    g = torch.Generator(device=dev).manual_seed(1001)
+    q = torch.randn(nq, Qt, Et, generator=g, device=dev)
+    d = torch.randn(200, Dt, Et, generator=g, device=dev)
     # --- CPU legs: scoring only (torch port of :105-124) and full forward (+ the 2-layer Transformer contextualiser)
     if cpu_budget > 0:
         from oracle import torch_port as TP
@@ -510,7 +552,7 @@ def main():
             busy = profile_summary("*maxsim*pmc*.json", "maxsim_stream_kernel", "_mfma_busy_frac")
             if busy is not None:
                 out["roofline"]["mfma_util"]["pmc_busy_frac"] = busy[0]
-                out["roofline"]["mfma_util"]["pmc_source"] = f"profiles/{busy[1]} (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x SQ_BUSY_CYCLES-derived kernel cycles))"
+                out["roofline"]["mfma_util"]["pmc_source"] = f"profiles/{busy[1]} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), tools/summarize_rocprof.py)"
             if world == 1:      # CPU leg and extras are N = 1 figures; ranks > 0 would idle through them
                 if not args.no_cpu_baseline:
                     nsamp = min(nq, 24)
@@ -519,6 +561,10 @@ def main():
                 if not args.no_extras:
                     extra = {}
                     cpu_b = 0.0 if args.no_cpu_baseline else 3.0
+                    try:
+                        extra["sustained"] = extra_sustained(score_shard, B)
+                    except Exception as e:
+                        extra["sustained"] = {"error": repr(e)}
                     try:
                         extra["dropin_forward"] = extra_dropin_forward(q, d, q_len, d_len, max(5, args.steps // 2))
                     except Exception as e:      # an extra must never take the headline line down with it
