@@ -31,7 +31,6 @@ const EnvCfg& env() {
     c.maxsim_f32_terms = env_int("MM_MAXSIM_F32_TERMS", 3) == 2 ? 2 : 3;
     c.kp_generic = env_int("MM_KP_GENERIC", 0);
     c.kp_f32mfma = env_int("MM_KP_F32MFMA", 0);
-    c.tkl_fused = env_int("MM_TKL_FUSED", 0);
     c.dot_prof = env_int("MM_DOT_PROF", 0);
     return c;
   }();

@@ -878,375 +878,6 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// TKL stages 1 + 2 fused: one workgroup (3 wavefronts) per document.
-//
-// The two-kernel path writes 0.26 GB of pair sums and reads 0.31 GB of them back for 0.65 GB of chunk
-// rows (256 documents x 2048 tokens): the kernels are bound by that traffic.  Here the pair sums never
-// leave the CU.  The document's kept chunks form one virtual document of 40 * slots rows; in round g the
-// three wavefronts compute blocks 3g, 3g+1, 3g+2 (32 rows = 16 position pairs each) exactly like
-// tkl_stage1_run_kernel, but write their pair sums into a 64-row circular buffer in LDS; after a barrier
-// all 192 threads evaluate the sliding windows that became complete (start s in [48g - 14, 48g + 34)),
-// reduce over query tokens in LDS and write the window scores.  Each wavefront keeps its own 2-slot
-// LDS-DMA ring for the chunk rows (the only HBM traffic besides the query and the [B, W] scores).
-// ---------------------------------------------------------------------------------------------
-constexpr int kFW = 3;          // wavefronts per workgroup
-constexpr int kFRound = 48;     // pairs per round (3 blocks x 16)
-constexpr int kFRing = 64;      // pair rows kept in LDS (48 new + >= 14 halo)
-constexpr int kFNBUF = 2;
-
-struct TklFusedArgs {
-  const float* q_ctx;
-  const float* chunks;
-  PackedMask dm;          // rows = packed chunks, 40 positions
-  const int32_t* slot2p;  // [B, C]: packed chunk << 2 | x, or < 0 (as written by tkl_slot_map_kernel)
-  const float* q_mask;
-  const float* prm;
-  const float* emb;       // [B, Q] or null
-  float* win;             // [B, W]
-  int C, Q, W;
-};
-
-template <int NS, int K, int SAT>
-__global__ void __launch_bounds__(64 * kFW) tkl_fused_kernel(const TklFusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int E = 100 * NS;
-  constexpr int RB = E * 4;
-  constexpr int KC = K + 1;
-  constexpr int KP = (K + 1) / 2;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.x;
-  const int C = a.C, Q = a.Q, W = a.W;
-  const int rowf = Q * KC;
-
-  // ---- LDS map -----------------------------------------------------------------------------------
-  char* ring_w = smem + w * (kFNBUF * kSliceBytes);                    // this wavefront's LDS-DMA ring
-  float* rdbuf = (float*)(smem + kFW * kFNBUF * kSliceBytes) + w * 32; // 32 floats per wavefront
-  float* pring = (float*)(smem + kFW * kFNBUF * kSliceBytes + kFW * 128);   // [kFRing][Q][12] pair sums
-  float* red = pring + kFRing * rowf;                                  // [kFRound][Q]
-  float* embl = red + kFRound * Q;                                     // [Q]
-  int* sp = (int*)(embl + ((Q + 3) & ~3));                             // [C] packed chunk per slot or -1
-  int* meta = sp + ((C + 3) & ~3);                                     // [0] = kept slots (last kept + 1), [1] = min packed index
-  const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_w;
-
-  if (tid == 0) { meta[0] = 0; meta[1] = 0x7fffffff; }
-  __syncthreads();
-  for (int c = tid; c < C; c += 64 * kFW) {
-    const int info = a.slot2p[(int64_t)b * C + c];
-    const int p = info >= 0 ? (info >> 2) : -1;
-    sp[c] = p;
-    if (p >= 0) { atomicMax(&meta[0], c + 1); atomicMin(&meta[1], p); }
-  }
-  if (SAT == MM_TKL_SAT_EMBEDDING && tid < Q) embl[tid] = a.emb[(int64_t)b * Q + tid];
-  __syncthreads();
-  const int kept = meta[0];
-  const int pmin = meta[1];
-  const int nrows = 40 * kept;
-  const int nblk = (nrows + 31) >> 5;
-  const int npairs = nrows >> 1;  // pair rows that exist; everything beyond reads as zeros
-
-  // ---- per-lane constants of the streaming part (as tkl_stage1_run_kernel) --------------------------
-  int srow[kSliceInstr];
-  uint32_t scol[kSliceInstr];
-#pragma unroll
-  for (int n = 0; n < kSliceInstr; ++n) {
-    int s = 64 * n + lane;
-    if (s > 32 * kSC - 1) s = 32 * kSC - 1;
-    srow[n] = s / kSC;
-    scol[n] = (uint32_t)((s - srow[n] * kSC) * 16);
-  }
-  const uint32_t a_off = (uint32_t)(r * (kSC * 16) + h * 32);
-  const uint32_t l_off = (uint32_t)(r * (kSC * 16) + 24 * 16);
-  Rbf rbf;
-  load_rbf<K>(a.prm + TklParams::mu(), a.prm + TklParams::sigma(), nullptr, nullptr, rbf);
-  const char* dbase = (const char*)a.chunks + (int64_t)(pmin == 0x7fffffff ? 0 : pmin) * 50 * RB;
-
-  // producer cursor of THIS wavefront: blocks w, w + 3, ... ; NS slices each
-  int pt = w, ps = 0, pbuf = 0, cbuf = 0, inflight = 0;
-  uint32_t vrun[kSliceInstr];
-  auto top_up = [&]() {
-    while (pt < nblk && inflight < kFNBUF) {
-      if (ps == 0) {
-#pragma unroll
-        for (int n = 0; n < kSliceInstr; ++n) {
-          const int i = 32 * pt + srow[n];
-          const int c = (i * 205) >> 13;  // i / 40 (i < 400 * 10: C <= 64 slots -> i < 2592: use exact division below)
-          const int cc = i / 40;
-          (void)c;
-          const int p = cc < C ? sp[cc] : -1;
-          // rows of dropped / absent chunks are masked out; they re-read a valid row
-          vrun[n] = (uint32_t)(((p < 0 ? 0 : (p - pmin) * 50) + 5 + (p < 0 ? 0 : i - 40 * cc)) * RB) + scol[n];
-        }
-      }
-      issue_slice<true>(dbase + ps * (kSC * 16), vrun, 0u, false, lds_ring + (uint32_t)pbuf * kSliceBytes);
-      pbuf = (pbuf + 1 == kFNBUF) ? 0 : pbuf + 1;
-      ++inflight;
-      if (++ps == NS) {
-        ps = 0;
-        pt += kFW;
-      }
-    }
-  };
-  if (kept > 0) top_up();
-
-  // ---- query tile (the document's query) as bf16 hi / lo B fragments --------------------------------
-  bf16x8 qhi[NS][kSplitSteps], qlo[NS][kSplitSteps], qhiL, qloL;
-  float rq = 0.0f;
-  if (kept > 0) {
-    const int qr = r < Q ? r : Q - 1;
-    const char* qrow = (const char*)a.q_ctx + ((int64_t)b * Q + qr) * RB;
-    float ss = 0.0f;
-    f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      f32x4 raw[13];
-      load_q_slice_split(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw);
-#pragma unroll
-      for (int p = 0; p < kSplitSteps; ++p) {
-        split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
-        ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
-      }
-      if (h == 0) ss += sumsq4(raw[12]);
-      if (h == (s >> 1)) park[s & 1] = raw[12];
-    }
-    split8(park[0], park[1], qhiL, qloL);
-    ss += __shfl_xor(ss, 32, 64);
-    rq = 1.0f / (sqrtf(ss) + 1e-13f);
-  }
-
-  const float* sprm = a.prm + TklParams::sat();
-  const int rounds = (nblk + kFW - 1) / kFW;
-  int w_done = 0;  // windows [0, w_done) have been written
-
-  for (int g = 0; g <= rounds; ++g) {
-    // ================= phase 1: this wavefront's block of the round -> pair rows in LDS =============
-    const int t = kFW * g + w;
-    if (g < rounds && t < nblk) {
-      f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
-      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-      f32x2 ss2 = {0.0f, 0.0f};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        top_up();
-        wait_slices(inflight - 1);
-        const char* buf = ring_w + cbuf * kSliceBytes;
-        f32x4 x[13];
-#pragma unroll
-        for (int p = 0; p < kSplitSteps; ++p) {
-          x[2 * p] = *(const f32x4*)(buf + a_off + p * 64);
-          x[2 * p + 1] = *(const f32x4*)(buf + a_off + p * 64 + 16);
-        }
-        x[12] = *(const f32x4*)(buf + l_off);
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 ah, al;
-        split8(x[0], x[1], ah, al);
-#pragma unroll
-        for (int p = 0; p < kSplitSteps; ++p) {
-          bf16x8 nh = ah, nl = al;
-          if (p + 1 < kSplitSteps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
-          acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
-          acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
-          acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
-          acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
-          {
-            const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
-            const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
-            ss2 += a0 * a0;
-            ss2 += a1 * a1;
-            ss2 += b0 * b0;
-            ss2 += b1 * b1;
-          }
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-          }
-          ah = nh;
-          al = nl;
-        }
-        const f32x4 xl = x[12];
-        if (h == 0) ss2 += f32x2{xl[0] * xl[0] + xl[1] * xl[1], xl[2] * xl[2] + xl[3] * xl[3]};
-        if (h == (s >> 1)) park[s & 1] = xl;
-        cbuf = (cbuf + 1 == kFNBUF) ? 0 : cbuf + 1;
-        --inflight;
-      }
-      {
-        bf16x8 ah, al;
-        split8(park[0], park[1], ah, al);
-        acc_hh = mfma_bf16(ah, qhiL, acc_hh);
-        acc_lh = mfma_bf16(al, qhiL, acc_lh);
-        acc_xl = mfma_bf16(ah, qloL, acc_xl);
-        acc_xl = mfma_bf16(al, qloL, acc_xl);
-      }
-      float ss = ss2[0] + ss2[1];
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
-      ss += __shfl_xor(ss, 32, 64);
-      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
-      float rdr[16];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g4 + 4 * h);
-        rdr[4 * g4 + 0] = v[0]; rdr[4 * g4 + 1] = v[1]; rdr[4 * g4 + 2] = v[2]; rdr[4 * g4 + 3] = v[3];
-      }
-      // validity bits of virtual rows 32t .. 32t+31 (at most two slots)
-      const int i0 = 32 * t;
-      const int c0 = i0 / 40, r0 = i0 - 40 * c0;
-      uint32_t va = 0;
-      {
-        const int pa = __builtin_amdgcn_readfirstlane(c0 < C ? sp[c0] : -1);
-        const int pb = __builtin_amdgcn_readfirstlane(c0 + 1 < C ? sp[c0 + 1] : -1);
-        if (pa >= 0) {
-          const uint32_t w0 = sload_u32(a.dm.bits, (int64_t)pa * 2), w1 = sload_u32(a.dm.bits, (int64_t)pa * 2 + 1);
-          va = (uint32_t)((((unsigned long long)(w1 & 0xffu) << 32) | w0) >> r0);
-        }
-        const int n0 = 40 - r0;
-        if (n0 < 32 && pb >= 0) va |= sload_u32(a.dm.bits, (int64_t)pb * 2) << n0;
-      }
-      const uint32_t vbits = va >> (4 * h);
-      // pair sums of this block -> circular pair buffer (pair 16t + ...)
-#pragma unroll
-      for (int ip = 0; ip < 8; ++ip) {
-        f32x2 o2[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) o2[k] = f32x2{0.0f, 0.0f};
-        float cnt = 0.0f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int i = 2 * ip + half;
-          float c = (acc[i] * rq) * rdr[i];
-          c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
-          const f32x2 cc = {c, c};
-          f32x2 any2 = {0.0f, 0.0f};
-#pragma unroll
-          for (int kp = 0; kp < KP; ++kp) {
-            const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
-            const f32x2 av = -(sv * sv);
-            const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
-            o2[kp] += e;
-            any2 += e;
-          }
-          cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;
-        }
-        const int gp = 16 * t + ((rowof(2 * ip) + 4 * h) >> 1);
-        if (r < Q) {
-          f32x4* dst = (f32x4*)(pring + ((gp & (kFRing - 1)) * Q + r) * KC);
-#pragma unroll
-          for (int v = 0; v < KC / 4 - 1; ++v) dst[v] = f32x4{o2[2 * v][0], o2[2 * v][1], o2[2 * v + 1][0], o2[2 * v + 1][1]};
-          dst[KC / 4 - 1] = f32x4{o2[KP - 2][0], o2[KP - 2][1], o2[KP - 1][0], cnt};
-        }
-      }
-    }
-    __syncthreads();
-    // ================= phase 2: windows that are complete after this round ==========================
-    // pairs [0, avail) are final; window s needs pairs s .. s+14 (pairs >= npairs are zeros)
-    const int avail = g < rounds ? (kFW * (g + 1) * 16 < npairs ? kFW * (g + 1) * 16 : npairs) : npairs;
-    int w_end = g < rounds && avail < npairs ? avail - 14 : W;  // last round(s): everything that is left
-    if (w_end > W) w_end = W;
-    while (w_done < w_end) {
-      const int nw = w_end - w_done < kFRound ? w_end - w_done : kFRound;
-      for (int item = tid; item < nw * Q; item += 64 * kFW) {
-        const int wl = item / Q, i = item - wl * Q;
-        const int s0 = w_done + wl;
-        f32x2 pk2[KC / 2];
-#pragma unroll
-        for (int k = 0; k < KC / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
-        if (s0 < npairs) {
-#pragma unroll
-          for (int j = 0; j < 15; ++j) {
-            if (s0 + j < npairs) {
-              const f32x4* src = (const f32x4*)(pring + (((s0 + j) & (kFRing - 1)) * Q + i) * KC);
-#pragma unroll
-              for (int v = 0; v < 3; ++v) {
-                const f32x4 x = src[v];
-                pk2[2 * v] += f32x2{x[0], x[1]};
-                pk2[2 * v + 1] += f32x2{x[2], x[3]};
-              }
-            }
-          }
-        }
-        float pk[KC];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) pk[k] = pk2[k >> 1][k & 1];
-        const float len = pk[K];
-        const float factor = a.q_mask[(int64_t)b * Q + i] * (len > 0.0f ? 1.0f : 0.0f);
-        float val = 0.0f;
-        if (SAT == MM_TKL_SAT_EMBEDDING) {
-          const float x0 = embl[i], x1 = len;
-          const float mean = (x0 + x1) * 0.5f;
-          const float d0 = x0 - mean, d1 = x1 - mean;
-          const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
-          const float n0 = d0 * rstd * sprm[9] + sprm[11], n1 = d1 * rstd * sprm[10] + sprm[12];
-          const float s1 = n0 * sprm[0] + n1 * sprm[1] + sprm[2];
-          const float s2 = 1.0f / (n0 * sprm[3] + n1 * sprm[4] + sprm[5]);
-          const float s3 = n0 * sprm[6] + n1 * sprm[7] + sprm[8];
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const float xp = __builtin_amdgcn_exp2f(s2 * __builtin_amdgcn_logf(fmaxf(pk[k], 1e-10f)));
-            const float sat = s1 * xp - s3;
-            val += a.prm[TklParams::dense() + k] * (sat * factor);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < K; ++k) {
-            const float sat = logf(fmaxf(pk[k] * a.prm[TklParams::kmult() + k], 1e-10f));
-            val += a.prm[TklParams::dense() + k] * (sat * factor);
-          }
-        }
-        red[wl * Q + i] = val;
-      }
-      __syncthreads();
-      if (tid < nw) {
-        float s = 0.0f;
-        for (int i = 0; i < Q; ++i) s += red[tid * Q + i];
-        a.win[(int64_t)b * W + w_done + tid] = s;
-      }
-      __syncthreads();
-      w_done += nw;
-    }
-  }
-}
-
-bool tkl_fused_supported(int C, int Q, int E) {
-  // Opt-in (MM_TKL_FUSED=1): correct (same parity tests as the two-kernel path) but measured SLOWER in round 1
-  // — 0.47 ms vs 0.39 ms per 256 full documents, 0.44 vs 0.27 ms on ragged lengths: three wavefronts per CU with a
-  // 2-slot ring expose the HBM latency, the window phase runs on the same three SIMDs, and one workgroup per
-  // document serialises long documents.  Kept as the base for a version with a dedicated window wavefront.
-  if (!env().tkl_fused) return false;
-  if (!kp_stream_supported(Q, E)) return false;
-  if (C > 1024) return false;
-  const size_t lds = (size_t)kFW * kFNBUF * kSliceBytes + kFW * 128 + ((size_t)kFRing * Q * 12 + (size_t)kFRound * Q + ((Q + 3) & ~3)) * 4 +
-                     (size_t)((C + 3) & ~3) * 4 + 16;
-  return lds <= 160 * 1024;
-}
-
-template <int NS, int SAT>
-static int tkl_fused_launch(const TklFusedArgs& a, int64_t B, size_t lds, hipStream_t stream) {
-  (void)hipFuncSetAttribute((const void*)tkl_fused_kernel<NS, 11, SAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((tkl_fused_kernel<NS, 11, SAT>), dim3((unsigned)B), dim3(64 * kFW), lds, stream, a);
-  return check_launch("tkl_fused_kernel");
-}
-
-int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* slot2p, const float* q_mask,
-              const float* prm, const float* emb, float* win, int64_t B, int C, int Q, int E, int W, int saturation,
-              hipStream_t stream) {
-  TklFusedArgs a{};
-  a.q_ctx = q_ctx; a.chunks = chunks; a.dm = dm; a.slot2p = slot2p; a.q_mask = q_mask; a.prm = prm; a.emb = emb; a.win = win;
-  a.C = C; a.Q = Q; a.W = W;
-  const size_t lds = (size_t)kFW * kFNBUF * kSliceBytes + kFW * 128 + ((size_t)kFRing * Q * 12 + (size_t)kFRound * Q + ((Q + 3) & ~3)) * 4 +
-                     (size_t)((C + 3) & ~3) * 4 + 16;
-  const bool emb_sat = saturation == MM_TKL_SAT_EMBEDDING;
-  switch (E) {
-    case 100: return emb_sat ? tkl_fused_launch<1, MM_TKL_SAT_EMBEDDING>(a, B, lds, stream) : tkl_fused_launch<1, MM_TKL_SAT_LOG>(a, B, lds, stream);
-    case 200: return emb_sat ? tkl_fused_launch<2, MM_TKL_SAT_EMBEDDING>(a, B, lds, stream) : tkl_fused_launch<2, MM_TKL_SAT_LOG>(a, B, lds, stream);
-    default: return emb_sat ? tkl_fused_launch<3, MM_TKL_SAT_EMBEDDING>(a, B, lds, stream) : tkl_fused_launch<3, MM_TKL_SAT_LOG>(a, B, lds, stream);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // generic kernel: one wavefront per pair, direct fragment loads, any E % 4 == 0, any Q / D.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool TKL, bool W = false>

@@ -31,7 +31,6 @@ struct EnvCfg {
   int maxsim_f32_terms = 3; // MM_MAXSIM_F32_TERMS: 2 = two-term split for fp32 MaxSim (A/B), default three terms
   int kp_generic = 0;       // MM_KP_GENERIC: force the generic pooling kernel
   int kp_f32mfma = 0;       // MM_KP_F32MFMA: exact-f32 MFMA pooling kernel instead of split-bf16
-  int tkl_fused = 0;        // MM_TKL_FUSED: fused TKL stages 1 + 2
   int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
 };
 const EnvCfg& env();
@@ -74,12 +73,6 @@ struct TklParams {            // offsets into the packed float parameter vector 
 // kernel_pool.hip exports used by tkl.hip
 bool kp_stream_supported(int Q, int E);
 bool tkl_stage1_writes_all_pairs(int Q, int E);
-// Fused TKL stages 1 + 2 (one workgroup per document; kernel_pool.hip).  Returns MM_EUNSUPPORTED without
-// launching when the shape does not fit (caller falls back to the two-kernel path).
-bool tkl_fused_supported(int C, int Q, int E);
-int tkl_fused(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* slot2p, const float* q_mask,
-              const float* prm, const float* emb, float* win, int64_t B, int C, int Q, int E, int W, int saturation,
-              hipStream_t stream);
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* q_len,
                       const int32_t* chunk_slot, int C, const float* mu, const float* sigma, float* ps_out, int64_t P,
                       int Q, int E, hipStream_t stream);

@@ -405,9 +405,6 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     qmk.len = qlen;
     qmk.bits = qbits;
   }
-  // Stages 1 + 2 fused per document (pair sums stay in LDS) when the shape fits; otherwise stage 1 writes the
-  // pair sums to the workspace and the window kernel reads them back.
-  const bool fused = tkl_fused_supported(C, Q, E);
   PackedMask dm;
   if (P > 0) {
     if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
@@ -423,17 +420,11 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     if (int e = check_launch("tkl_prep_chunk_kernel")) return e;
     dm.len = clen;
     dm.bits = cbits;
-    if (!fused) {
-      if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, qmk.len, chunk_slot, C,
-                                    params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
-        return e;
-    }
-  }
-  if (fused) {
-    if (int e = tkl_fused((const float*)q_ctx, (const float*)chunks, dm, slot2p, q_mask, params,
-                          saturation == MM_TKL_SAT_EMBEDDING ? emb : nullptr, win, B, C, Q, E, W, saturation, stream))
+    if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, qmk.len, chunk_slot, C,
+                                  params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
       return e;
-  } else {
+  }
+  {
     const int nu = kWT + kWinPairs - 1;
     const size_t lds2 = ((size_t)nu * Q * kKC + ((Q + 3) & ~3) + (size_t)kWT * Q) * 4;
     if (lds2 > 160 * 1024) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
