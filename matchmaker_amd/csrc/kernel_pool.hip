@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
   bool qvalid = false;
   uint32_t qbits = 0xffffffffu;
   int qn = Q, np = 2;  // effective query length; lanes sharing one query token in the epilogue (2 = the MFMA layout)
+  int rrows = 0, rtk = 0, rsub = 0;  // redistributed epilogue: rows per lane (0 = MFMA layout), this lane's token and row group
   int64_t cur_q = -1;
   int64_t qi = TKL ? 0 : p0 / a.ppq;
   int64_t q_left = TKL ? 0 : a.ppq - (p0 - qi * a.ppq);
@@ -457,9 +458,13 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
       qvalid = r < Q && r < qlen;
       qbits = a.qm.bits ? sload_u32(a.qm.bits, qi) : 0xffffffffu;
       if (a.qm.bits) qvalid = qvalid && ((qbits >> r) & 1u);
-      // short queries: share each query token's epilogue between np = 4 .. 32 lanes (see rbf_redistributed)
+      // queries of <= 21 real tokens: share each query token's epilogue between np = ceil(32 / rows) lanes (see
+      // rbf_redistributed): 3 lanes x 11 rows at qn = 20 instead of 2 x 16 with 24 of the 64 lanes idle
       qn = qlen < Q ? (qlen < 0 ? 0 : qlen) : Q;
-      np = TKL ? 2 : (qn == 0 || qn > 16) ? 2 : (qn > 8 ? 4 : (qn > 4 ? 8 : (qn > 2 ? 16 : 32)));
+      rrows = TKL ? 0 : redist_rows(qn);
+      np = rrows ? (32 + rrows - 1) / rrows : 2;
+      rtk = lane / np;
+      rsub = lane - rtk * np;
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
@@ -559,10 +564,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
           *(f32x4*)(T + r * 32 + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
                                                        (acc[4 * g + 2] * rq) * rdr[4 * g + 2], (acc[4 * g + 3] * rq) * rdr[4 * g + 3]};
         const float* lwrow = W ? wbuf + 32 * t : nullptr;
-        if (np == 4) rbf_redistributed<K, W, 8>(pk2, T, lwrow, lane, va, rbf);
-        else if (np == 8) rbf_redistributed<K, W, 4>(pk2, T, lwrow, lane, va, rbf);
-        else if (np == 16) rbf_redistributed<K, W, 2>(pk2, T, lwrow, lane, va, rbf);
-        else rbf_redistributed<K, W, 1>(pk2, T, lwrow, lane, va, rbf);
+        rbf_redistributed_rows<K, W>(rrows, pk2, T, lwrow, rtk, rsub, va, rbf);
       } else if constexpr (W) {
         float lw[16];
 #pragma unroll
@@ -580,12 +582,8 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
       if (np > 2) {  // np consecutive lanes hold the partial sums of one query token
 #pragma unroll
         for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
-        for (int o = np >> 1; o >= 1; o >>= 1) {
-#pragma unroll
-          for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], o, 64);
-        }
-        const int tk = lane / np;
-        const bool count = (lane & (np - 1)) == 0 && tk < qn && ((qbits >> tk) & 1u);
+        redist_reduce<K>(pk, np, lane);
+        const bool count = rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u);
         finish_pool<K>(a, pair, pk, count, lane, rbf);
       } else {
 #pragma unroll

@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
   bool qvalid = false;
   uint32_t qbits = 0xffffffffu;
   int qn = Q, np = 2;  // effective query length; lanes sharing one query token in the epilogue (kernel_pool.hip, 3.3)
+  int rrows = 0, rtk = 0, rsub = 0;
   int64_t cur_q = -1;
   int64_t qi = p0 / a.ppq;
   int64_t q_left = a.ppq - (p0 - qi * a.ppq);
@@ -208,7 +209,10 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
       if (a.qm.bits) qvalid = qvalid && ((qbits >> r) & 1u);
       qn = qlen < Q ? (qlen < 0 ? 0 : qlen) : Q;
       constexpr bool kRedist = KS == 1 && !MX && !(W && NSL == 6);  // (gated E = 384 would spill registers)
-      np = (!kRedist || qn == 0 || qn > 16) ? 2 : (qn > 8 ? 4 : (qn > 4 ? 8 : (qn > 2 ? 16 : 32)));
+      rrows = kRedist ? redist_rows(qn) : 0;
+      np = rrows ? (32 + rrows - 1) / rrows : 2;
+      rtk = lane / np;
+      rsub = lane - rtk * np;
     }
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
@@ -338,10 +342,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
           *(f32x4*)(T + r * 32 + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
                                                        (acc[4 * g + 2] * rq) * rdr[4 * g + 2], (acc[4 * g + 3] * rq) * rdr[4 * g + 3]};
         const float* lwrow = W ? wbuf + 32 * t : nullptr;
-        if (np == 4) rbf_redistributed<K, W, 8>(pk2, T, lwrow, lane, va, rbf);
-        else if (np == 8) rbf_redistributed<K, W, 4>(pk2, T, lwrow, lane, va, rbf);
-        else if (np == 16) rbf_redistributed<K, W, 2>(pk2, T, lwrow, lane, va, rbf);
-        else rbf_redistributed<K, W, 1>(pk2, T, lwrow, lane, va, rbf);
+        rbf_redistributed_rows<K, W>(rrows, pk2, T, lwrow, rtk, rsub, va, rbf);
       } else if constexpr (W) {
         float lw[16];
 #pragma unroll
@@ -371,12 +372,8 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
     if (KS == 1 && np > 2) {  // np consecutive lanes hold the partial sums of one query token
 #pragma unroll
       for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
-      for (int o = np >> 1; o >= 1; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], o, 64);
-      }
-      const int tk = lane / np;
-      finish_pool<K>(a, pair, pk, (lane & (np - 1)) == 0 && tk < qn && ((qbits >> tk) & 1u), lane, rbf);
+      redist_reduce<K>(pk, np, lane);
+      finish_pool<K>(a, pair, pk, rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u), lane, rbf);
       continue;
     }
 #pragma unroll

@@ -187,37 +187,83 @@ __device__ __forceinline__ void rbf_rows(f32x2 (&pk2)[kMaxK / 2], const float (&
   }
 }
 
-// read this lane's ROWS values of the transposed tile T[token][32 rows] (and of the gate vector) and evaluate them
+// read this lane's ROWS values of the transposed tile T[token][32 rows] (and of the gate vector) and evaluate them:
+// lane = (token t, row group s), rows s * ROWS .. s * ROWS + ROWS - 1 (rows >= 32 do not exist: their bits are 0).
+// ROWS need not divide 32: a 20-token query puts 3 lanes on a token (11 + 11 + 10 rows).
 template <int K, bool W, int ROWS>
-__device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow, int lane,
+__device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow, int t, int s,
                                                   uint32_t va, const Rbf& rbf) {
-  constexpr int NP = 32 / ROWS;                 // lanes per query token
-  const int t = lane / NP, s = lane % NP;       // token, row group
-  const float* src = T + t * 32 + s * ROWS;
+  const int row0 = s * ROWS;
+  const float* src = T + t * 32 + row0;
   float c[ROWS], lw[ROWS];
-  if constexpr (ROWS >= 4) {
+  if constexpr (ROWS % 4 == 0) {
 #pragma unroll
     for (int v = 0; v < ROWS / 4; ++v) {
       const f32x4 x = *(const f32x4*)(src + 4 * v);
       c[4 * v] = x[0]; c[4 * v + 1] = x[1]; c[4 * v + 2] = x[2]; c[4 * v + 3] = x[3];
       if (W) {
-        const f32x4 y = *(const f32x4*)(lwrow + s * ROWS + 4 * v);
+        const f32x4 y = *(const f32x4*)(lwrow + row0 + 4 * v);
         lw[4 * v] = y[0]; lw[4 * v + 1] = y[1]; lw[4 * v + 2] = y[2]; lw[4 * v + 3] = y[3];
       }
     }
   } else {
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
-      c[j] = src[j];
-      if (W) lw[j] = lwrow[s * ROWS + j];
+      const int rr = row0 + j < 32 ? row0 + j : 31;      // stay inside the tile / the gate row; the bit of a row >= 32 is 0
+      c[j] = T[t * 32 + rr];
+      if (W) lw[j] = lwrow[rr];
     }
   }
   if (!W) {
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) lw[j] = 0.0f;
   }
-  const uint32_t bits = (va >> (s * ROWS)) & ((ROWS == 32) ? 0xffffffffu : ((1u << ROWS) - 1u));
+  const uint32_t bits = (row0 < 32 ? (va >> row0) : 0u) & ((ROWS == 32) ? 0xffffffffu : ((1u << ROWS) - 1u));
   rbf_rows<K, W, ROWS>(pk2, c, bits, rbf, lw);
+}
+
+// rows per lane of the redistributed epilogue for a query of qn real tokens: the smallest ROWS of the instantiated set
+// whose ceil(32 / ROWS) lanes per token fit all qn tokens into the 64 lanes (0 = keep the MFMA layout: 16 rows per lane)
+__device__ __forceinline__ int redist_rows(int qn) {
+  if (qn <= 0 || qn > 21) return 0;
+  if (qn <= 2) return 1;
+  if (qn <= 4) return 2;
+  if (qn <= 8) return 4;
+  if (qn <= 16) return 8;      // (5 / 6 / 7 rows on 7 / 6 / 5 lanes for qn = 9 .. 12 measured slower than 8 rows on 4: unaligned LDS reads)
+  return 11;                   // 17 .. 21 tokens: 3 lanes per token, +1.3 % at Q = 20
+}
+
+template <int K, bool W>
+__device__ __forceinline__ void rbf_redistributed_rows(int rows, f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow,
+                                                       int t, int s, uint32_t va, const Rbf& rbf) {
+  switch (rows) {
+    case 1: rbf_redistributed<K, W, 1>(pk2, T, lwrow, t, s, va, rbf); break;
+    case 2: rbf_redistributed<K, W, 2>(pk2, T, lwrow, t, s, va, rbf); break;
+    case 4: rbf_redistributed<K, W, 4>(pk2, T, lwrow, t, s, va, rbf); break;
+    case 8: rbf_redistributed<K, W, 8>(pk2, T, lwrow, t, s, va, rbf); break;
+    default: rbf_redistributed<K, W, 11>(pk2, T, lwrow, t, s, va, rbf); break;
+  }
+}
+
+// partial sums of the np lanes of a token -> its first lane (s == 0); np = lanes per token (any value <= 32)
+template <int K>
+__device__ __forceinline__ void redist_reduce(float (&pk)[kMaxK], int np, int lane) {
+  if ((np & (np - 1)) == 0) {
+    for (int o = np >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], o, 64);
+    }
+  } else {
+    float acc[kMaxK];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = pk[k];
+    for (int o = 1; o < np; ++o) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += __shfl(pk[k], lane + o, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) pk[k] = acc[k];
+  }
 }
 
 
