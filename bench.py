@@ -423,6 +423,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in-layout / TK / TKL / dot-top-k legs (N = 1 only)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"])
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the per-step all-gather even with one rank (exercises the "
+                         "RCCL path on a single-GPU box)")
     ap.add_argument("--dry", action="store_true",
                     help="launch + collective plumbing only (fabricated scores, value = null); for GPU-less machines")
     args = ap.parse_args()
@@ -447,8 +450,13 @@ def main():
         torch.cuda.set_device(dev)
     else:
         dev = torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        # the GPU boxes export NCCL_DEBUG=VERSION: RCCL would print its banner on STDOUT after the JSON line (per rank);
+        # the version is reported in the line itself instead
+        os.environ["NCCL_DEBUG"] = os.environ.get("MM_NCCL_DEBUG", "WARN")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         kw = {"device_id": dev} if dev.type == "cuda" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
@@ -463,11 +471,11 @@ def main():
         q, d, q_len, d_len = synth.colbert_batch(nq, CANDS, Q, D, E, torch.bfloat16, dev, seed=4004 + rank,
                                                  lengths=args.lengths)
         score_shard = lambda: ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
-    gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         s = score_shard()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, s)     # RCCL over xGMI: the ranking merge
         return s
 
@@ -476,7 +484,7 @@ def main():
 
     def barrier():
         sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             sync()
 
@@ -491,25 +499,25 @@ def main():
         s = score_shard()
         if use_ev:
             ev[i][1].record()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, s)
     barrier()
     t = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if use_ev else None
 
     tt = torch.tensor([t], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t = float(tt.item())
     gather_ok = None
-    if world > 1 and args.dry:
+    if use_dist and args.dry:
         want = torch.arange(world * B, dtype=torch.float32, device=dev)
         gather_ok = bool(torch.equal(gathered, want))
 
     if rank == 0:
         total_pairs = world * B * args.steps
         coll = None
-        if world > 1:
+        if use_dist:
             ver = None
             if backend == "nccl":
                 try:
@@ -579,7 +587,7 @@ def main():
                         torch.cuda.empty_cache()
                     out["extra"] = extra
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
