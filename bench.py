@@ -452,9 +452,12 @@ def main():
         dev = torch.device("cpu")
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        # the GPU boxes export NCCL_DEBUG=VERSION: RCCL would print its banner on STDOUT after the JSON line (per rank);
-        # the version is reported in the line itself instead
-        os.environ["NCCL_DEBUG"] = os.environ.get("MM_NCCL_DEBUG", "WARN")
+        # the GPU boxes export NCCL_DEBUG=VERSION and RCCL prints to STDOUT (its banner would follow the JSON line, once
+        # per rank; WARN is noisier still): no RCCL logging unless MM_NCCL_DEBUG asks for it — the version is reported
+        # in the line itself
+        os.environ.pop("NCCL_DEBUG", None)
+        if os.environ.get("MM_NCCL_DEBUG"):
+            os.environ["NCCL_DEBUG"] = os.environ["MM_NCCL_DEBUG"]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         kw = {"device_id": dev} if dev.type == "cuda" else {}
