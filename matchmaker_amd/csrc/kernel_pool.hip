@@ -622,46 +622,66 @@ __device__ __forceinline__ void sload4_u32(const void* base, int64_t idx, uint32
 
 // Epilogue of block t of a run: pairs of virtual rows (i0, i0 + 1), i0 = 32t + rowof(2ip) + 4h, belong
 // to chunk i0 / 40, pair (i0 % 40) / 2.  rows_blk = rows of this block that exist (multiple of 8).
+//
+// The pair sums leave through LDS.  A lane owns one query token, so writing them straight from the registers is
+// 24 store instructions per block whose 40 active lanes each put 16 B at a 48-B stride (measured by removal on
+// config 3: 49 of stage 1's 189 us).  The 16 pair rows of a block are ONE contiguous region of the pair buffer
+// ((chunk * 20 + pair) * Q * 12 floats is linear in the run's pair index), so each half of the block (8 pair rows,
+// <= 12 KiB) is staged in the ring slot the block just freed and written out as one contiguous run of qlim * 48 B per
+// store instruction: 16 stores per block, every one a full-width burst.  (Measured: 189 -> 184 us — the cost is the
+// write traffic in the read stream and the stores sitting in the in-order vmcnt queue, not the shape of the stores.)
 template <int K>
-__device__ __forceinline__ void tkl_block_run(float* ps_run, int Q, int qlim, int t, int rows_blk, int r, int h,
-                                              const f32x16& acc, const float (&rdr)[16], float rq, uint32_t vbits,
+__device__ __forceinline__ void tkl_block_run(float* ps_run, float* stage, int lane, int Q, int qlim, int t, int rows_blk, int r,
+                                              int h, const f32x16& acc, const float (&rdr)[16], float rq, uint32_t vbits,
                                               const Rbf& rbf) {
   constexpr int KC = K + 1;
   constexpr int KP = (K + 1) / 2;
-  static_assert(KC % 4 == 0 && K % 2 == 1, "K kernels + the count channel must fill whole float4s");
+  static_assert(KC == 12 && K % 2 == 1, "K kernels + the count channel fill three float4s");
+  f32x4* stage4 = (f32x4*)stage;                                  // [8 pair rows][Q][3]
+  f32x4* out4 = (f32x4*)ps_run + (int64_t)16 * t * (3 * Q);       // pair row g of the run at g * Q * 12 floats
 #pragma unroll
-  for (int ip = 0; ip < 8; ++ip) {
-    if (rowof(2 * ip) < rows_blk) {  // wave-uniform (rows_blk is a multiple of 8, rowof(2ip) + 4h + 1 < its 8-row group end)
-      f32x2 o2[KP];
+  for (int hf = 0; hf < 2; ++hf) {
+    if (16 * hf >= rows_blk) break;                               // wave-uniform
 #pragma unroll
-      for (int k = 0; k < KP; ++k) o2[k] = f32x2{0.0f, 0.0f};
-      float cnt = 0.0f;
+    for (int iq = 0; iq < 4; ++iq) {
+      const int ip = 4 * hf + iq;
+      if (rowof(2 * ip) < rows_blk) {  // wave-uniform (rows_blk is a multiple of 8, rowof(2ip) + 4h + 1 < its 8-row group end)
+        f32x2 o2[KP];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int i = 2 * ip + half;
-        float c = (acc[i] * rq) * rdr[i];
-        c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;  // masked: every kernel underflows to exactly 0 (:194)
-        const f32x2 cc = {c, c};
-        f32x2 any2 = {0.0f, 0.0f};
+        for (int k = 0; k < KP; ++k) o2[k] = f32x2{0.0f, 0.0f};
+        float cnt = 0.0f;
 #pragma unroll
-        for (int kp = 0; kp < KP; ++kp) {
-          const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
-          const f32x2 av = -(sv * sv);
-          const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
-          o2[kp] += e;
-          any2 += e;
+        for (int half = 0; half < 2; ++half) {
+          const int i = 2 * ip + half;
+          float c = (acc[i] * rq) * rdr[i];
+          c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;  // masked: every kernel underflows to exactly 0 (:194)
+          const f32x2 cc = {c, c};
+          f32x2 any2 = {0.0f, 0.0f};
+#pragma unroll
+          for (int kp = 0; kp < KP; ++kp) {
+            const f32x2 sv = cc * rbf.sq2[kp] - rbf.msq2[kp];
+            const f32x2 av = -(sv * sv);
+            const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+            o2[kp] += e;
+            any2 += e;
+          }
+          cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;  // (:210)
         }
-        cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;  // (:210)
+        const int j8 = ((rowof(2 * ip) + 4 * h) >> 1) - 8 * hf;   // pair row inside this half (0..7)
+        if (r < qlim) {  // query tokens past the query's effective length are masked in stage 2 (:248): never written, never read
+          f32x4* dst = stage4 + (j8 * Q + r) * 3;
+          dst[0] = f32x4{o2[0][0], o2[0][1], o2[1][0], o2[1][1]};
+          dst[1] = f32x4{o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
+          dst[2] = f32x4{o2[KP - 2][0], o2[KP - 2][1], o2[KP - 1][0], cnt};
+        }
       }
-      const int i0 = 32 * t + rowof(2 * ip) + 4 * h;
-      const int ci = (i0 * 205) >> 13;  // i0 / 40 for i0 < 400
-      const int u = (i0 - 40 * ci) >> 1;
-      if (r < qlim) {  // query tokens past the query's effective length are masked in stage 2 (:248): never written, never read
-        f32x4* dst = (f32x4*)(ps_run + (int64_t)ci * (20 * Q * KC) + ((int64_t)u * Q + r) * KC);
+    }
+    // the half's pair rows that exist: rows_blk / 2 - 8 hf of them (a multiple of 4), one contiguous store each
+    const int npr = rows_blk / 2 - 8 * hf < 8 ? rows_blk / 2 - 8 * hf : 8;
+    for (int l = lane; l < 3 * qlim; l += 64) {                  // (one pass for queries of <= 21 tokens)
 #pragma unroll
-        for (int v = 0; v < KC / 4 - 1; ++v) dst[v] = f32x4{o2[2 * v][0], o2[2 * v][1], o2[2 * v + 1][0], o2[2 * v + 1][1]};
-        dst[KC / 4 - 1] = f32x4{o2[KP - 2][0], o2[KP - 2][1], o2[KP - 1][0], cnt};
-      }
+      for (int j = 0; j < 8; ++j)
+        if (j < npr) out4[(int64_t)(8 * hf + j) * (3 * Q) + l] = stage4[j * (3 * Q) + l];
     }
   }
 }
@@ -869,7 +889,9 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       }
       const int rows_blk = 40 * crun - i0 < 32 ? 40 * crun - i0 : 32;
       if (rows_blk < 32) va &= (1u << rows_blk) - 1u;
-      tkl_block_run<K>(ps_run, Q, qlim, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+      // staging area: the ring slot this block's last slice just left (free until the next top_up())
+      float* stage = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
+      tkl_block_run<K>(ps_run, stage, lane, Q, qlim, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
     }
     pair += crun;
   }
