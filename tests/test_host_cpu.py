@@ -298,3 +298,49 @@ def test_patch_matchmaker_rebinds_the_model_classes():
     finally:                                             # other tests drive the real classes
         for (ref_mod, ref_attr), obj in saved.items():
             setattr(importlib.import_module(ref_mod), ref_attr, obj)
+
+
+def test_rerank_helpers_follow_eval_py_and_core_metrics():
+    """matchmaker_amd.rerank: evaluate_batches unrolls scores per query id exactly as eval.py:189-203 does (arrival order
+    kept), and unrolled_to_ranked_result is the reference's ranking rule — compared with the REAL function of
+    utils/core_metrics.py:502-511 when the reference tree is mounted (ties keep arrival order: Python's sort is stable)."""
+    import torch
+    from matchmaker_amd import rerank
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, query, document, use_fp16=True, output_secondary_output=False):
+            s = document["input_ids"].float().sum(-1) - query["input_ids"].float().sum(-1)
+            return (s, {}) if output_secondary_output else s
+
+    g = torch.Generator().manual_seed(3)
+    batches, want = [], {}
+    for b in range(4):
+        n = 5
+        qid = [f"q{(b * n + i) // 7}" for i in range(n)]
+        did = [f"d{b * n + i}" for i in range(n)]
+        q = torch.randint(0, 3, (n, 4), generator=g)
+        d = torch.randint(0, 3, (n, 6), generator=g)          # small range -> plenty of exact ties
+        batches.append({"query_tokens": {"input_ids": q}, "doc_tokens": {"input_ids": d}, "query_id": qid, "doc_id": did})
+        for i in range(n):
+            want.setdefault(qid[i], []).append((did[i], float(d[i].sum() - q[i].sum())))
+    got = rerank.evaluate_batches(Model(), batches, use_fp16=False, device="cpu")
+    assert got == want
+    got2 = rerank.evaluate_batches(Model(), batches, use_fp16=False, device="cpu", output_secondary_output=True)
+    assert got2 == want
+    ranked = rerank.unrolled_to_ranked_result(got)
+    for qid, rows in want.items():
+        assert ranked[qid] == [d for d, _ in sorted(rows, key=lambda x: x[1], reverse=True)]
+    from oracle import ref_harness as R
+    if R.available():
+        import importlib.util, os
+        spec = importlib.util.spec_from_file_location("ref_core_metrics", os.path.join(R.REFERENCE_ROOT, "matchmaker", "utils", "core_metrics.py"))
+        mod = importlib.util.module_from_spec(spec)
+        try:
+            spec.loader.exec_module(mod)
+        except Exception:
+            return                                             # optional dependencies of the reference missing here
+        assert mod.unrolled_to_ranked_result(got) == ranked
