@@ -53,6 +53,24 @@ if "dropin" in which:
     report("bf16 pair-per-row Q + int32 lengths",
            timeit(lambda: ops.maxsim(qp, d, q_len.repeat_interleave(C), d_len, 1)), B, B * ((D + Q) * E * 2 + 12))
     del qp, dm, qm
+if "dropin_msmarco" in which:
+    g = torch.Generator(device=dev).manual_seed(7)
+    dl = synth.msmarco_doc_lengths(B, D, g, dev)
+    qp = q.repeat_interleave(C, 0).contiguous()
+    dm = synth.len_to_mask(dl, D, torch.int64)
+    qm = synth.len_to_mask(q_len, Q, torch.int64).repeat_interleave(C, 0).contiguous()
+    rd = int((((dl + 31) // 32) * 32).clamp(max=D).sum().item()) * E * 2 + B * (Q * E * 2 + 8 * (D + Q) + 4)
+    report("bf16 drop-in layout, msmarco document lengths (bytes = blocks actually read + query tiles + masks)",
+           timeit(lambda: ops.maxsim(qp, d, qm, dm, 1)), B, rd)
+    del qp, dm, qm
+if "dropin768" in which:
+    n = 16000
+    q7 = torch.randn(n, 32, 768, device=dev).to(torch.float16)
+    d7 = torch.randn(n, 200, 768, device=dev).to(torch.float16)
+    qm7 = torch.ones(n, 32, dtype=torch.int64, device=dev); dm7 = torch.ones(n, 200, dtype=torch.int64, device=dev)
+    report("fp16 drop-in layout at the reference's defaults (colbert_compression_dim 768, Q 32, D 200, autocast fp16)",
+           timeit(lambda: ops.maxsim(q7, d7, qm7, dm7, 1)), n, n * ((200 + 32) * 768 * 2 + 8 * 232 + 4))
+    del q7, d7, qm7, dm7
 if "i64mask" in which:
     dm = synth.len_to_mask(d_len, D, torch.int64)
     qm = synth.len_to_mask(q_len, Q, torch.int64)
