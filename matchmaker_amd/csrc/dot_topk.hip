@@ -466,8 +466,13 @@ static DotGeom dot_geom(int64_t n_docs, int nq) {
   g.qpw = 128 * g.nqt;
   int G = (nq + g.qpw - 1) / g.qpw;
   if (G > 32) G = 32;
-  g.T = 32 / G > 0 ? 32 / G : 1;
+  // G * T workgroups run on the 32 CUs of an XCD: T = 32 / gcd(G, 32) makes that a whole number of rounds (6,980 queries
+  // = 28 groups: T = 1 left 4 of every 32 CUs idle for the whole launch, T = 8 gives 7 full rounds: 15.3 -> 13.6 ms)
+  int gcd = G, b32 = 32;
+  while (b32) { const int r = gcd % b32; gcd = b32; b32 = r; }
+  g.T = 32 / gcd;
   const int64_t per_xcd = ((n_docs + 31) / 32 + 7) / 8;
+  while (g.T > 1 && per_xcd / g.T < 16) g.T >>= 1;   // keep >= 16 blocks per workgroup (the query tile load is a prologue)
   if (g.T > per_xcd) g.T = per_xcd > 0 ? (int)per_xcd : 1;
   return g;
 }
