@@ -1,6 +1,6 @@
 #!/bin/bash
 # All rocprofv3 evidence of a round in one go (run on the GPU box from the repo root):
-#   bash tools/profile_round.sh <tag>   -> gpurun_out/prof_<tag>_{maxsim,dropin,tk,tkl,dot}/summary.json
+#   bash tools/profile_round.sh <tag> ["workloads"]   -> gpurun_out/prof_<tag>_{maxsim,dropin,tk,tkl,tklragged,dot}/summary.json
 # Counters are collected in their own passes with --kernel-trace only (never with sys/hip tracing).
 set -u
 TAG=${1:-r02}
@@ -23,9 +23,14 @@ prof() {   # prof <name> <command...>
   find $O -name "*.db" -delete      # raw traces are tens of MB; the summary is what gets committed
   echo "== $W"; tail -1 $O/bench_trace.log | cut -c1-400
 }
-prof maxsim python bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2
-NQ=256 prof dropin python tools/bench_maxsim_variants.py dropin
-prof tk python tools/bench_kernel_pool.py --full --queries 64 --steps 5
-prof tkl python tools/bench_tkl.py --full --steps 5
-prof tklragged python tools/bench_tkl.py --steps 5
-prof dot python tools/bench_dot_topk.py --steps 2
+WL=${2:-"maxsim dropin tk tkl tklragged dot"}
+for W in $WL; do
+  case $W in
+    maxsim) prof maxsim python bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 2;;
+    dropin) NQ=256 prof dropin python tools/bench_maxsim_variants.py dropin;;
+    tk) prof tk python tools/bench_kernel_pool.py --full --queries 64 --steps 5;;
+    tkl) prof tkl python tools/bench_tkl.py --full --steps 5;;
+    tklragged) prof tklragged python tools/bench_tkl.py --steps 5;;
+    dot) prof dot python tools/bench_dot_topk.py --steps 2;;
+  esac
+done
