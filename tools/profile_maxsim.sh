@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd $R
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $O/trace -o maxsim -- $B --steps 20 --warmup 3 > $O/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o maxsim -- $B --steps 5 --warmup 1 > $O/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o maxsim -- $B --steps 5 --warmup 1 > $O/bench_write.log 2>&1
