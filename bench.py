@@ -70,6 +70,16 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def timed_cpu(fn, budget_s, unit_per_call):
     """2 warm-ups, then whole calls until ~budget_s seconds -> (units/s, calls, seconds)."""
     fn(); fn()
@@ -135,7 +145,7 @@ def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
     torch.set_num_threads(1)
     rate1, n1, pairs1, t1 = leg(min(4.0, budget_s / 3))
     torch.set_num_threads(threads)
-    return {"value": rate, "unit": "pairs/s", "cores": threads, "kind": "port",
+    return {"value": rate, "unit": "pairs/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "single_thread_value": rate1,
             "sample": f"{n} forward calls over whole queries ({nq} distinct) x {cands} candidates = {pairs} pairs of the "
                       f"bench workload in {t_total:.1f} s with {threads} torch threads (host has "
