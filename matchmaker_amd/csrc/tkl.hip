@@ -99,18 +99,18 @@ __global__ void __launch_bounds__(256) tkl_prep_chunk_kernel(const float* __rest
 
 // The (window, query token) items of one tile: see tkl_window_kernel.  red[w][i] for i < ql is written for every
 // window of the tile (0 for windows past W).
-template <int SAT, int kG>
+template <int SAT, int kG, bool ONCE>
 __device__ __forceinline__ void window_items(const float* tile, float* red, const float* emb, const float* __restrict__ q_mask,
                                              const float* __restrict__ prm, const float* sp, int b, int Q, int ql, int rowf,
-                                             int w0, int W, int tid) {
+                                             int w0, int W, int tid, int wt) {
   typedef __attribute__((ext_vector_type(2))) float f32x2;
   constexpr int kE = kG - 1;                              // edge rows on each side
-  for (int item = tid; item < (kWT / kG) * ql; item += kWThreads) {
+  for (int item = tid; item < (wt / kG) * ql; item += kWThreads) {
     const int wp = item / ql, i = item - wp * ql;
     const int wl = kG * wp;
     if (w0 + wl >= W) {
 #pragma unroll
-      for (int which = 0; which < kG; ++which) red[(wl + which) * Q + i] = 0.0f;
+      for (int which = 0; which < kG; ++which) red[(wl + which) * (ql | 1) + i] = 0.0f;
       continue;
     }
     auto row = [&](int j, f32x2 (&dst)[kKC / 2]) {
@@ -178,33 +178,49 @@ __device__ __forceinline__ void window_items(const float* tile, float* red, cons
           val += prm[TklParams::dense() + k] * (sat * factor);
         }
       }
-      red[(wl + which) * Q + i] = (w0 + wl + which < W) ? val : 0.0f;
+      red[(wl + which) * (ql | 1) + i] = (w0 + wl + which < W) ? val : 0.0f;
     }
+    if (ONCE) break;      // the caller knows the 512 threads cover the items in one pass (no loop-carried registers)
   }
 }
 
-// One workgroup = kWT consecutive windows of one document.
+// LDS bytes of one pass over `wt` windows of a query of effective length ql: the wt + 14 pair rows, ql x 12 floats each
+// (rows are stored compactly: tokens past the effective length do not exist), sat_emb_reduce1, the per-(window, token)
+// values, the chunk lookups.
+__host__ __device__ inline size_t window_pass_bytes(int wt, int ql) {
+  return ((size_t)(wt + kWinPairs - 1) * ql * kKC + ((ql + 3) & ~3) + (size_t)wt * (ql | 1)) * 4 + 32;
+}
+#ifndef MM_WIN_LDS
+#define MM_WIN_LDS (80 * 1024)      // -D overrides for A/B builds only
+#endif
+constexpr int kWindowLds = MM_WIN_LDS;     // two workgroups per CU: one stages its rows while the other evaluates
+
+// One workgroup = kWT consecutive windows of one document, in passes of wt = 64 / 32 / 16 windows — the largest that
+// fits the workgroup's LDS at the document's effective query length.
 template <int SAT>
-__global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
+__global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
                                                          const float* __restrict__ emb_g,
                                                          const float* __restrict__ q_mask,
                                                          const int32_t* __restrict__ q_len,
                                                          const float* __restrict__ prm, float* __restrict__ win,
-                                                         int C, int Q, int W) {
+                                                         int C, int Q, int W, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y;
   const int w0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
-  const int nu = kWT + kWinPairs - 1;                 // pair rows needed by this tile
-  const int rowf = Q * kKC;                           // floats per pair row
-  float* tile = (float*)smem;                         // [nu][Q][12]
-  float* emb = tile + (size_t)nu * rowf;              // [Q]   sat_emb_reduce1(q_ctx)  (:224)
-  float* red = emb + ((Q + 3) & ~3);                  // [kWT][Q] per-(window, query token) dense-weighted value
-  __shared__ int cinfo[8];                            // slot2p entries of the (<= 4) chunks this tile touches
-
-  // the chunk lookups first, once per tile, so that the row loads below are independent of each other
   int ql = q_len ? q_len[b] : Q;                      // effective query length (rows of later tokens do not exist)
   ql = ql < 0 ? 0 : (ql > Q ? Q : ql);
+  int wt = kWT;
+  while (wt > 4 && window_pass_bytes(wt, ql) > (size_t)lds_bytes) wt >>= 1;
+  const int nu = wt + kWinPairs - 1;                  // pair rows needed by one pass
+  const int rowf = ql * kKC;                          // floats per staged pair row
+  const int srcf = Q * kKC;                           // floats per pair row in the pair-sum buffer
+  int* cinfo = (int*)smem;                            // slot2p entries of the (<= 5) chunks this tile touches
+  float* tile = (float*)(smem + 32);                  // [nu][ql][12]
+  float* emb = tile + (size_t)nu * rowf;              // [ql]  sat_emb_reduce1(q_ctx)  (:224)
+  float* red = emb + ((ql + 3) & ~3);                 // [wt][ql | 1] per-(window, query token) dense-weighted value
+
+  // the chunk lookups first, once per tile, so that the row loads below are independent of each other
   const int c0 = w0 / kU;
   if (tid < 8) {
     const int c = c0 + tid;
@@ -212,73 +228,84 @@ __global__ void __launch_bounds__(kWThreads) tkl_window_kernel(const float* __re
   }
   __syncthreads();
   // a tile none of whose chunks exists (padding past the document's end) is all zeros: every window is empty and
-  // scores exactly 0 (:248) — half of all tiles with config 3's U{50..2048} document lengths
+  // scores exactly 0 (:248) — half of all tiles with config 3's U{50..2048} document lengths; so is every window of
+  // a query without a real token
   {
     bool live = false;
-    const int cb = (w0 + nu - 1) / kU - c0;
+    const int cb = (w0 + kWT + kWinPairs - 2) / kU - c0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) live = live || (c <= cb && cinfo[c] >= 0);
-    if (!live) {
+    if (!live || ql == 0) {
       if (tid < kWT && w0 + tid < W) win[(int64_t)b * W + w0 + tid] = 0.0f;
       return;
     }
   }
-
-  // ---- stage the pair-sum rows (zeros for dropped chunks) --------------------------------------
-  // All row loads of a batch of kStage elements are issued before the first LDS store, so a thread pays
-  // one memory latency per batch (a tile of Q = 20 is ONE batch); the kernel was 67 % s_waitcnt when every
-  // element did its own dependent slot -> chunk -> row chain.
-  const int row4 = rowf / 4;
-  const int total4 = nu * row4;
-  constexpr int kStage = 10;
-  for (int base = tid; base < total4; base += kWThreads * kStage) {
-    int pidx[kStage];
-    int off[kStage];
-#pragma unroll
-    for (int s = 0; s < kStage; ++s) {
-      const int idx = base + kWThreads * s;
-      pidx[s] = -1;
-      off[s] = 0;
-      if (idx < total4) {
-        const int j = idx / row4, v = idx - j * row4;
-        const int ug = w0 + j;
-        const int c = ug / kU, uu = ug - c * kU;
-        off[s] = uu * rowf + v * 4;
-        const int info = cinfo[c - c0];                                // c - c0 <= (19 + nu) / 20 < 8
-        // rows of unwritten blocks and of query tokens past the effective length are zeros
-        if (info >= 0 && uu < 16 * (info & 3) && v < 3 * ql) pidx[s] = info >> 2;
+  if (SAT == MM_TKL_SAT_EMBEDDING && tid < ql) emb[tid] = emb_g[(int64_t)b * Q + tid];
+  const float* sp = prm + TklParams::sat();
+  for (int ws = w0; ws < w0 + kWT && ws < W; ws += wt) {
+    // the thread index is re-materialised per pass: with everything derived from it loop-invariant the compiler
+    // hoisted the index arithmetic of all passes' phases and kept 175-198 registers live (85 for a single pass);
+    // two workgroups per CU need <= 128
+    int tz;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tz) : "v"(tid) : "memory");
+    // ---- stage the pair-sum rows (zeros for dropped chunks) --------------------------------------
+    // All row loads of a batch of kStage elements are issued before the first LDS store, so a thread pays
+    // one memory latency per batch (a tile of Q = 20 is ONE batch); the kernel was 67 % s_waitcnt when every
+    // element did its own dependent slot -> chunk -> row chain.
+    const int row4 = rowf / 4;
+    const int total4 = nu * row4;
+    constexpr int kStage = 10;
+    for (int base = tz; base < total4; base += kWThreads * kStage) {
+      int pidx[kStage];
+      int off[kStage];
+  #pragma unroll
+      for (int s = 0; s < kStage; ++s) {
+        const int idx = base + kWThreads * s;
+        pidx[s] = -1;
+        off[s] = 0;
+        if (idx < total4) {
+          const int j = idx / row4, v = idx - j * row4;
+          const int ug = ws + j;
+          const int c = ug / kU, uu = ug - c * kU;
+          off[s] = uu * srcf + v * 4;
+          const int info = cinfo[c - c0];                                // c - c0 <= (19 + kWT + 14) / 20 < 8
+          // rows of unwritten blocks are zeros
+          if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;
+        }
+      }
+      f32x4 val[kStage];
+  #pragma unroll
+      for (int s = 0; s < kStage; ++s) {
+        val[s] = f32x4{0, 0, 0, 0};
+        if (pidx[s] >= 0) val[s] = *(const f32x4*)(ps + (int64_t)pidx[s] * kU * srcf + off[s]);
+      }
+  #pragma unroll
+      for (int s = 0; s < kStage; ++s) {
+        const int idx = base + kWThreads * s;
+        if (idx < total4) *(f32x4*)(tile + (size_t)idx * 4) = val[s];
       }
     }
-    f32x4 val[kStage];
-#pragma unroll
-    for (int s = 0; s < kStage; ++s) {
-      val[s] = f32x4{0, 0, 0, 0};
-      if (pidx[s] >= 0) val[s] = *(const f32x4*)(ps + (int64_t)pidx[s] * kU * rowf + off[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < kStage; ++s) {
-      const int idx = base + kWThreads * s;
-      if (idx < total4) *(f32x4*)(tile + (size_t)idx * 4) = val[s];
-    }
-  }
-  if (SAT == MM_TKL_SAT_EMBEDDING && tid < Q) emb[tid] = emb_g[(int64_t)b * Q + tid];
-  __syncthreads();
+    __syncthreads();
 
-  const float* sp = prm + TklParams::sat();
-  // One item = kG adjacent windows of one query token: the windows share 15 - (kG - 1) of their pair rows, which are
-  // summed once (kG = 4: 18 row reads for four windows instead of 60).  Only tokens below the effective query length
-  // are evaluated (the others are multiplied by 0 in :248), and kG adapts to it so that one pass of the 512 threads
-  // covers the tile with as little work per thread as possible: 16 ql items of four windows for long queries,
-  // 32 ql of two / 64 ql of one when that still fits one pass (MSMARCO queries average ~6 tokens).
-  // Only additions of non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
-  if (ql * (kWT / 1) <= kWThreads) window_items<SAT, 1>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, w0, W, tid);
-  else if (ql * (kWT / 2) <= kWThreads) window_items<SAT, 2>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, w0, W, tid);
-  else window_items<SAT, 4>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, w0, W, tid);
-  __syncthreads();
-  if (tid < kWT && w0 + tid < W) {                                     // :249 sum over query tokens, :251 dense
-    float s = 0.0f;
-    for (int i = 0; i < ql; ++i) s += red[tid * Q + i];
-    win[(int64_t)b * W + w0 + tid] = s;
+    // One item = kG adjacent windows of one query token: the windows share 15 - (kG - 1) of their pair rows, which are
+    // summed once (kG = 4: 18 row reads for four windows instead of 60).  Only tokens below the effective query length
+    // are evaluated (the others are multiplied by 0 in :248), and kG adapts to it so that one pass of the 512 threads
+    // covers the tile with as little work per thread as possible: 16 ql items of four windows for long queries,
+    // 32 ql of two / 64 ql of one when that still fits one pass (MSMARCO queries average ~6 tokens).
+    // Only additions of non-negative terms: exact zeros stay exact, `lengths` stays an exact integer.
+    if (ql * (wt / 1) <= kWThreads) window_items<SAT, 1, true>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, ws, W, tz, wt);
+    else if (ql * (wt / 2) <= kWThreads) window_items<SAT, 2, true>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, ws, W, tz, wt);
+    else if (ql * (wt / 4) <= kWThreads) window_items<SAT, 4, true>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, ws, W, tz, wt);
+    else window_items<SAT, 4, false>(tile, red, emb, q_mask, prm, sp, b, Q, ql, rowf, ws, W, tz, wt);
+    __syncthreads();
+    if (tz < wt && ws + tz < W) {                                    // :249 sum over query tokens, :251 dense
+      float s = 0.0f;
+      const float* r = red + tz * (ql | 1);                              // odd stride: the 64 lanes hit distinct banks
+#pragma unroll 4
+      for (int i = 0; i < ql; ++i) s += r[i];
+      win[(int64_t)b * W + ws + tz] = s;
+    }
+    // the next pass overwrites `tile` (last read before the barrier above) and, after its own barrier, `red`
   }
 }
 
@@ -425,20 +452,22 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
       return e;
   }
   {
-    const int nu = kWT + kWinPairs - 1;
-    const size_t lds2 = ((size_t)nu * Q * kKC + ((Q + 3) & ~3) + (size_t)kWT * Q) * 4;
-    if (lds2 > 160 * 1024) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
+    // LDS per workgroup: the whole 64-window tile when that leaves room for a second workgroup on the CU, otherwise
+    // kWindowLds and the kernel makes passes of 32 / 16 windows for the documents whose queries need it
+    const size_t full = window_pass_bytes(kWT, Q);
+    const size_t lds2 = full < (size_t)kWindowLds ? full : (size_t)kWindowLds;
+    if (window_pass_bytes(8, Q) > lds2) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
     const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
     if (saturation == MM_TKL_SAT_EMBEDDING) {
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
-                         emb, q_mask, qmk.len, params, win, C, Q, W);
+                         emb, q_mask, qmk.len, params, win, C, Q, W, (int)lds2);
     } else {
       if (lds2 > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
-                         emb, q_mask, qmk.len, params, win, C, Q, W);
+                         emb, q_mask, qmk.len, params, win, C, Q, W, (int)lds2);
     }
     if (int e = check_launch("tkl_window_kernel")) return e;
   }

@@ -12,10 +12,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=256)
 ap.add_argument("--D", type=int, default=2048)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--Q", type=int, default=20, help="padded query length (effective lengths are U{3..Q})")
 ap.add_argument("--full", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-B, Q, D, E = a.docs, 20, a.D, 300
+B, Q, D, E = a.docs, a.Q, a.D, 300
 g = torch.Generator(device=dev).manual_seed(3003)
 MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
 m = TKL_sigir20(E, MU, [0.1] * 11, 10, 1, 32, 2000, True, True, "embedding").to(dev).eval()
