@@ -22,6 +22,15 @@
 
 namespace mm {
 
+// TKL: the wavefront that processes packed chunk p publishes its slot-map entry (see KpArgs::slot2p)
+__device__ __forceinline__ void tkl_publish_slot(const KpArgs& a, int64_t p, int blocks, int lane) {
+  if (a.slot2p && lane == 0) {
+    const int sl = a.chunk_slot[p];
+    if (sl >= 0 && sl < a.n_slots) a.slot2p[sl] = (int32_t)((p << 2) | blocks);
+  }
+}
+
+
 // TKL epilogue of one block of a chunk's centre tokens (block t = rows 32t..32t+31 of the 40):
 // per position pair u the K summed activations (ecai-style RBF, masked: sigir20_tkl.py:192-194) and
 // the count of positions with a non-zero activation (feeds `lengths`, :210).
@@ -212,6 +221,7 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
   for (int64_t pair = p0; pair < p1; ++pair) {
     if (TKL) {
       qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
+      tkl_publish_slot(a, pair, (doc_len(pair) + 31) >> 5, lane);
     } else if (a.pair_q) {
       qi = (int64_t)(int)sload_u32(a.pair_q, pair);
     } else {
@@ -424,6 +434,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
   for (int64_t pair = p0; pair < p1; ++pair) {
     if (TKL) {
       qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
+      tkl_publish_slot(a, pair, (doc_len(pair) + 31) >> 5, lane);
     } else if (a.pair_q) {
       qi = (int64_t)(int)sload_u32(a.pair_q, pair);
     } else {
@@ -778,6 +789,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
   for (int64_t pair = p0; pair < p1;) {
     const int crun = run_len(pair);
     const int nb = (40 * crun + 31) >> 5;
+    for (int k = 0; k < crun; ++k) tkl_publish_slot(a, pair + k, 2, lane);  // every pair row of every chunk is written
     const int64_t qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
     if (qi != cur_q) {
       cur_q = qi;
@@ -918,6 +930,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a_
   int len = a.dm.len ? a.dm.len[pair] : D;
   len = len < 0 ? 0 : (len > D ? D : len);
   const int nb = (len + 31) >> 5;
+  if (TKL) tkl_publish_slot(a, pair, nb, lane);
   const int qlen = a.qm.len ? a.qm.len[qi] : Q;
   const char* dbase = (const char*)a.d + (pair * a.d_doc_rows + a.d_row0) * rowb;
   const char* qbase = (const char*)a.q + qi * Q * rowb;
@@ -1058,20 +1071,16 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
 
 bool kp_stream_supported(int Q, int E) { return Q <= 32 && (E == 100 || E == 200 || E == 300); }
 
-// true when TKL stage 1 runs the grouped kernel, which writes every pair of every packed chunk
-bool tkl_stage1_writes_all_pairs(int Q, int E) {
-  return kp_stream_supported(Q, E) && !env().kp_generic && !env().kp_f32mfma;
-}
-
 // TKL stage 1 entry (called from tkl.hip): chunks [P,50,E] -> ps_out [P,20,Q,12]
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* q_len,
                       const int32_t* chunk_slot, int C, const float* mu, const float* sigma, float* ps_out, int64_t P,
-                      int Q, int E, hipStream_t stream) {
+                      int Q, int E, int32_t* slot2p, int64_t n_slots, hipStream_t stream) {
   KpArgs a{};
   a.q = q_ctx; a.d = chunks; a.dm = dm; a.mu = mu; a.sigma = sigma; a.alpha = nullptr; a.w = nullptr;
   a.qm.len = q_len;  // effective query lengths [B] (may be null): pair rows of later tokens are not written
   a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;
   a.d_doc_rows = 50; a.d_row0 = 5; a.chunk_slot = chunk_slot; a.C = C; a.ps_out = ps_out;
+  a.slot2p = slot2p; a.n_slots = n_slots;
   if (!env().kp_generic && kp_stream_supported(Q, E)) return launch_stream<11, true>(a, stream);
   if (P > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "tkl: too many chunks for one launch");
   hipLaunchKernelGGL((kernel_pool_generic_kernel<11, true>), dim3((unsigned)P), dim3(64), 0, stream, a);

@@ -30,6 +30,11 @@ struct KpArgs {
   const int32_t* chunk_slot;
   int C;
   float* ps_out;
+  // slot map of stage 2 (tkl.hip), published by stage 1 itself — one launch less than a separate scatter kernel:
+  // slot2p[chunk_slot[p]] = (p << 2) | number of 32-row blocks whose pair rows this kernel writes for chunk p
+  // (entries of dropped chunks were set to -1 by the preparation launch, earlier in the stream)
+  int32_t* slot2p;
+  int64_t n_slots;
   // variants of the pooling block (same arithmetic family):
   //   dw != nullptr: per document token gate >= 0 multiplying all its activations (TK-Sparse stop-word
   //   vector, cikm20_tk_sparse.py:133-135), [n_pairs, D] float32;

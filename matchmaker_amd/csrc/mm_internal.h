@@ -72,10 +72,9 @@ struct TklParams {            // offsets into the packed float parameter vector 
 
 // kernel_pool.hip exports used by tkl.hip
 bool kp_stream_supported(int Q, int E);
-bool tkl_stage1_writes_all_pairs(int Q, int E);
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* q_len,
                       const int32_t* chunk_slot, int C, const float* mu, const float* sigma, float* ps_out, int64_t P,
-                      int Q, int E, hipStream_t stream);
+                      int Q, int E, int32_t* slot2p, int64_t n_slots, hipStream_t stream);
 
 // kernel_pool128.hip: fp32 MaxSim on the split-bf16 streaming kernel (E = 64n <= 384, 512, 768; Q <= 32), called from maxsim.hip
 bool kp128_maxsim_supported(int Q, int E);

@@ -23,17 +23,25 @@ constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows sta
 constexpr int kWThreads = 512;
 
 
-// Preparation in two launches instead of five (memset + emb + two mask packs + slot map were ~25 us of a 0.3 ms call).
-//
-// tkl_prep_query_kernel — three roles by block range (all independent of each other):
-//   [0, n_fill)               slot2p[...] = -1 (dropped chunk) for the B*C slots;
-//   [n_fill, n_fill + n_emb)  sat_emb_reduce1(q_ctx) (:224): one wavefront per (document, query token) -> emb[b][i];
-//   the rest                  effective query lengths + validity bits of the float query masks (one wavefront per row).
-__global__ void __launch_bounds__(256) tkl_prep_query_kernel(int32_t* __restrict__ slot2p, int64_t BC, int n_fill,
-                                                             const float* __restrict__ q_ctx, const float* __restrict__ prm,
-                                                             float* __restrict__ emb, int64_t BQ, int E, int n_emb,
-                                                             const float* __restrict__ q_mask, int64_t B, int Q,
-                                                             int32_t* __restrict__ qlen_out, uint32_t* __restrict__ qbits_out) {
+// Preparation in ONE launch (round 1: memset + emb + two mask packs + slot map = five, ~25 us of a 0.3 ms call) —
+// tkl_prep_kernel, four roles by block range, all independent of each other:
+//   [0, n_fill)        slot2p[...] = -1 (dropped chunk) for the B*C slots.  The entries of the packed chunks,
+//                      slot2p[slot] = (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2),
+//                      are published by the stage-1 kernel itself (KpArgs::slot2p), later in the stream.  Stage 1 only
+//                      writes the blocks below a chunk's effective length, so pair rows past them are taken as zeros
+//                      by stage 2 instead of being zero-filled in HBM first (that memset of the whole pair buffer was
+//                      255 MB at B = 256 x 2048 tokens);
+//   next n_emb         sat_emb_reduce1(q_ctx) (:224): one wavefront per (document, query token) -> emb[b][i];
+//   next n_q           effective query lengths + validity bits of the float query masks (one wavefront per row);
+//   the rest           one wavefront per packed chunk: effective length + validity bits of its 40 centre tokens
+//                      (columns 5..44 of the [P, 50] mask).
+__global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slot2p, int64_t BC, int n_fill,
+                                                       const float* __restrict__ q_ctx, const float* __restrict__ prm,
+                                                       float* __restrict__ emb, int64_t BQ, int E, int n_emb,
+                                                       const float* __restrict__ q_mask, int64_t B, int Q, int n_q,
+                                                       int32_t* __restrict__ qlen_out, uint32_t* __restrict__ qbits_out,
+                                                       const float* __restrict__ chunk_mask, int64_t P,
+                                                       int32_t* __restrict__ clen_out, uint32_t* __restrict__ cbits_out) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   if (blk < n_fill) {
@@ -53,47 +61,34 @@ __global__ void __launch_bounds__(256) tkl_prep_query_kernel(int32_t* __restrict
     return;
   }
   blk -= n_emb;
-  const int64_t row = (int64_t)blk * 4 + (threadIdx.x >> 6);
-  if (row >= B) return;
-  const int words = (Q + 31) >> 5;
-  const float* m = q_mask + row * Q;
-  int last = 0;
-  for (int base = 0; base < Q; base += 64) {
-    const int j = base + lane;
-    const unsigned long long bal = __ballot(j < Q && m[j < Q ? j : Q - 1] != 0.0f);
-    if (lane == 0) {
-      const int w = base >> 5;
-      qbits_out[row * words + w] = (uint32_t)bal;
-      if (w + 1 < words) qbits_out[row * words + w + 1] = (uint32_t)(bal >> 32);
+  if (blk < n_q) {
+    const int64_t row = (int64_t)blk * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int words = (Q + 31) >> 5;
+    const float* m = q_mask + row * Q;
+    int last = 0;
+    for (int base = 0; base < Q; base += 64) {
+      const int j = base + lane;
+      const unsigned long long bal = __ballot(j < Q && m[j < Q ? j : Q - 1] != 0.0f);
+      if (lane == 0) {
+        const int w = base >> 5;
+        qbits_out[row * words + w] = (uint32_t)bal;
+        if (w + 1 < words) qbits_out[row * words + w + 1] = (uint32_t)(bal >> 32);
+      }
+      if (bal) last = base + 64 - __builtin_clzll(bal);
     }
-    if (bal) last = base + 64 - __builtin_clzll(bal);
+    if (lane == 0) qlen_out[row] = last;
+    return;
   }
-  if (lane == 0) qlen_out[row] = last;
-}
-
-// tkl_prep_chunk_kernel — one wavefront per packed chunk: effective length + validity bits of its 40 centre tokens
-// (columns 5..44 of the [P, 50] mask) and the slot map entry
-//   slot2p[slot] = (packed chunk index << 2) | number of 32-row blocks stage 1 writes for it (0..2);
-// -1 (from tkl_prep_query_kernel, earlier in the stream) = dropped chunk.  Stage 1 only writes the blocks below a
-// chunk's effective length, so pair rows past them are taken as zeros by stage 2 instead of being zero-filled in HBM
-// first (that memset of the whole pair buffer was 255 MB at B = 256 x 2048 tokens).
-__global__ void __launch_bounds__(256) tkl_prep_chunk_kernel(const float* __restrict__ chunk_mask,
-                                                             const int32_t* __restrict__ chunk_slot, int64_t P, int64_t BC,
-                                                             int all_pairs, int32_t* __restrict__ len_out,
-                                                             uint32_t* __restrict__ bits_out, int32_t* __restrict__ slot2p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  blk -= n_q;
+  const int64_t p = (int64_t)blk * 4 + (threadIdx.x >> 6);
   if (p >= P) return;
   const float* m = chunk_mask + p * 50 + 5;
   const unsigned long long bal = __ballot(lane < 40 && m[lane < 40 ? lane : 39] != 0.0f);
   if (lane == 0) {
-    const int len = bal ? 64 - __builtin_clzll(bal) : 0;
-    len_out[p] = len;
-    bits_out[p * 2] = (uint32_t)bal;
-    bits_out[p * 2 + 1] = (uint32_t)(bal >> 32);
-    const int32_t sl = chunk_slot[p];
-    // the grouped stage-1 kernel writes every pair of a chunk; the per-chunk kernels only the blocks below its length
-    if (sl >= 0 && sl < BC) slot2p[sl] = (int32_t)((p << 2) | (all_pairs ? 2 : ((len + 31) >> 5)));
+    clen_out[p] = bal ? 64 - __builtin_clzll(bal) : 0;
+    cbits_out[p * 2] = (uint32_t)bal;
+    cbits_out[p * 2 + 1] = (uint32_t)(bal >> 32);
   }
 }
 
@@ -417,38 +412,36 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   if (!win) win = (float*)tail;
   float* emb = (float*)(tail + align256((size_t)B * W * 4));
   // launch 1: slot map cleared, sat_emb_reduce1(q_ctx), effective query lengths (last real token + 1: query tokens
-  // past them are masked in :248, so stage 1 does not write their pair rows and stage 2 does not evaluate them)
-  PackedMask qmk;
+  // past them are masked in :248, so stage 1 does not write their pair rows and stage 2 does not evaluate them),
+  // chunk masks (effective length + validity bits of the 40 centre tokens)
+  PackedMask qmk, dm;
   {
+    if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
+    const size_t need_dm = packed_mask_bytes(MM_MASK_F32, P, 40);
+    if (left < need_dm) return set_error(MM_EWORKSPACE, "tkl: workspace too small for the chunk masks");
+    int32_t* clen = (int32_t*)ws;
+    uint32_t* cbits = (uint32_t*)(ws + (size_t)P * 4);
     char* qws = (char*)emb + align256((size_t)B * Q * 4);
     int32_t* qlen = (int32_t*)qws;
     uint32_t* qbits = (uint32_t*)(qws + (size_t)B * 4);
     const int n_fill = (int)((B * (int64_t)C + 255) / 256);
     const int n_emb = saturation == MM_TKL_SAT_EMBEDDING ? (int)((B * (int64_t)Q + 3) / 4) : 0;
     const int n_q = (int)((B + 3) / 4);
-    hipLaunchKernelGGL(tkl_prep_query_kernel, dim3((unsigned)(n_fill + n_emb + n_q)), dim3(256), 0, stream, slot2p,
-                       B * (int64_t)C, n_fill, (const float*)q_ctx, params, emb, B * (int64_t)Q, E, n_emb, q_mask, B, Q, qlen, qbits);
-    if (int e = check_launch("tkl_prep_query_kernel")) return e;
+    const int n_chunk = (int)((P + 3) / 4);
+    hipLaunchKernelGGL(tkl_prep_kernel, dim3((unsigned)(n_fill + n_emb + n_q + n_chunk)), dim3(256), 0, stream, slot2p,
+                       B * (int64_t)C, n_fill, (const float*)q_ctx, params, emb, B * (int64_t)Q, E, n_emb, q_mask, B, Q, n_q,
+                       qlen, qbits, chunk_mask, P, clen, cbits);
+    if (int e = check_launch("tkl_prep_kernel")) return e;
     qmk.len = qlen;
     qmk.bits = qbits;
-  }
-  PackedMask dm;
-  if (P > 0) {
-    if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
-    // launch 2: chunk masks (effective length + validity bits of the 40 centre tokens) and the slot map
-    const size_t need_dm = packed_mask_bytes(MM_MASK_F32, P, 40);
-    if (left < need_dm) return set_error(MM_EWORKSPACE, "tkl: workspace too small for the chunk masks");
-    int32_t* clen = (int32_t*)ws;
-    uint32_t* cbits = (uint32_t*)(ws + (size_t)P * 4);
-    ws += need_dm;
-    left -= need_dm;
-    hipLaunchKernelGGL(tkl_prep_chunk_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, chunk_mask, chunk_slot, P,
-                       B * (int64_t)C, tkl_stage1_writes_all_pairs(Q, E) ? 1 : 0, clen, cbits, slot2p);
-    if (int e = check_launch("tkl_prep_chunk_kernel")) return e;
     dm.len = clen;
     dm.bits = cbits;
+  }
+  // launch 2: stage 1 (pair sums of every kept chunk + its slot-map entry)
+  if (P > 0) {
     if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, qmk.len, chunk_slot, C,
-                                  params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, stream))
+                                  params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, slot2p,
+                                  B * (int64_t)C, stream))
       return e;
   }
   {
