@@ -31,14 +31,35 @@ namespace mm {
 // mask row or — bug-compatible, :158 — with the row of the query index.  A wavefront's pairs are consecutive documents of
 // one query, so the query tile stays in registers and the documents stream from L2 / the Infinity Cache (they are read
 // once per query).
-template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, bool INB = false>
+// INB = 2: all-pairs TILED over queries: the NQT register tiles hold NQT DIFFERENT queries (Q <= 32), every document
+// block read from LDS feeds NQT x 8 MFMAs and the documents are read once per query GROUP.  Work map: workgroup
+// (xcd = blockIdx % 8, t, jg) sweeps document slice xcd * T + t of 8T for the query groups jg, jg + Gw, ... — the
+// wavefronts of one XCD stream the same documents for different queries at the same time, so a slice comes through
+// that XCD's L2 once per sweep instead of once per group.
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB = 0>
 __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
-  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  int64_t ppq = a.ppq;
+  int64_t d_first = 0, nd = 1;   // INB == 2: this wavefront's document slice
+  int g0 = 0;                    // INB == 2: first query group (then every inb_gw-th)
+  if (INB == 2) {
+    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int t = rest % a.inb_t;
+    g0 = rest / a.inb_t;
+    const int64_t S = 8 * (int64_t)a.inb_t, si = (int64_t)xcd * a.inb_t + t;
+    d_first = a.inb_bd * si / S;
+    nd = a.inb_bd * (si + 1) / S - d_first;
+    const int G = (int)((a.inb_bq + NQT - 1) / NQT);
+    const int ng = g0 < G ? (G - g0 + a.inb_gw - 1) / a.inb_gw : 0;
+    p0 = 0;                      // virtual pair v = (v / nd)-th group of this wavefront x document d_first + v % nd
+    p1 = (int64_t)ng * nd;
+    ppq = nd;
+  }
   if (p0 >= p1) return;
   const int D = a.D, Q = a.Q;
   const int nblk_tot = (D + 31) >> 5;
@@ -62,8 +83,15 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
 
   const char* dbase = (const char*)a.d;
-  auto doc_row = [&](int64_t p) -> int64_t { return INB ? p % a.inb_bd : p; };
-  auto mask_row = [&](int64_t p) -> int64_t { return INB ? (a.inb_bug ? p / a.inb_bd : p % a.inb_bd) : p; };
+  // (INB == 2: 32-bit arithmetic, made scalar again for the s_load helpers; a slice has < 2^31 virtual pairs)
+  auto doc_row = [&](int64_t p) -> int64_t {
+    if (INB == 2) return d_first + __builtin_amdgcn_readfirstlane((int)p % (int)nd);
+    return INB ? p % a.inb_bd : p;
+  };
+  auto mask_row = [&](int64_t p) -> int64_t {
+    if (INB == 2) return doc_row(p);
+    return INB ? (a.inb_bug ? p / a.inb_bd : p % a.inb_bd) : p;
+  };
   auto doc_len = [&](int64_t p) -> int {
     if (RAG) {
       const int64_t l = sload_i64(a.rag_end, p) - sload_i64(a.rag_begin, p);
@@ -77,11 +105,13 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
   int64_t pp = p0;
   int pt = 0, pn = 0, psl = 0, plen = 0;
   while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) == 0) ++pp;
+  int64_t prow0 = (INB == 2 && pp < p1) ? doc_row(pp) * D : 0;
   int pbuf = 0, cbuf = 0, inflight = 0;
 
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
-      const int64_t row0 = RAG ? sload_i64(a.rag_begin, pp) : doc_row(pp) * D;
+      // (INB == 2: doc_row is a division; done once per document, when the cursor moves)
+      const int64_t row0 = RAG ? sload_i64(a.rag_begin, pp) : (INB == 2 ? prow0 : doc_row(pp) * D);
       const char* g = dbase + (row0 + (int64_t)pt * 32) * RB + psl * 256;
       const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes;
       if (RAG) {
@@ -111,6 +141,7 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
         pt = 0;
         ++pp;
         while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) == 0) ++pp;
+        if (INB == 2 && pp < p1) prow0 = doc_row(pp) * D;
       }
     }
   };
@@ -122,28 +153,45 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
 #pragma unroll
   for (int n = 0; n < NQT; ++n) qvalid[n] = false;
   int64_t cur_q = -1;
-  int64_t qi = p0 / a.ppq;
-  int64_t q_left = a.ppq - (p0 - qi * a.ppq);  // pairs left on this query
+  int64_t qi = p0 / ppq;
+  int64_t q_left = ppq - (p0 - qi * ppq);  // pairs left on this query
   const int qwords = (Q + 31) >> 5;
 
   for (int64_t pair = p0; pair < p1; ++pair) {
     if (q_left == 0) {
       ++qi;
-      q_left = a.ppq;
+      q_left = ppq;
     }
     --q_left;
     if (qi != cur_q) {
       cur_q = qi;
-      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      if (INB == 2) {
+        // tile n = query (g0 + qi * inb_gw) * NQT + n, all of its (<= 32) tokens
 #pragma unroll
-      for (int n = 0; n < NQT; ++n) {
-        const int qt = 32 * n + r;
-        const int qr = qt < Q ? qt : Q - 1;
-        const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
+        for (int n = 0; n < NQT; ++n) {
+          int64_t qq = ((int64_t)g0 + qi * a.inb_gw) * NQT + n;
+          const bool exists = qq < a.inb_bq;
+          qq = exists ? qq : a.inb_bq - 1;
+          const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qq) : Q;
+          const int qr = r < Q ? r : Q - 1;
+          const char* qrow = (const char*)a.q + (qq * Q + qr) * RB;
 #pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
-        qvalid[n] = qt < Q && qt < qlen;
-        if (a.qm.bits && n < qwords) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qi * qwords + n) >> r) & 1u);
+          for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
+          qvalid[n] = exists && r < Q && r < qlen;
+          if (a.qm.bits) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qq) >> r) & 1u);   // Q <= 32: one word per query
+        }
+      } else {
+        const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) {
+          const int qt = 32 * n + r;
+          const int qr = qt < Q ? qt : Q - 1;
+          const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
+#pragma unroll
+          for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
+          qvalid[n] = qt < Q && qt < qlen;
+          if (a.qm.bits && n < qwords) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qi * qwords + n) >> r) & 1u);
+        }
       }
     }
     const int len = doc_len(pair);
@@ -180,10 +228,20 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
 #pragma unroll
       for (int n = 0; n < NQT; ++n) block_max(m[n], acc[n], ex, va, fill, h);
     }
-    float s = 0.0f;
+    if (INB == 2) {
+      const int64_t dj = doc_row(pair);
 #pragma unroll
-    for (int n = 0; n < NQT; ++n) s += finish_pair(m[n], qvalid[n], h);  // tiles in index order: deterministic
-    if (lane == 0) a.out[pair] = s;
+      for (int n = 0; n < NQT; ++n) {
+        const float s = finish_pair(m[n], qvalid[n], h);
+        const int64_t qq = ((int64_t)g0 + qi * a.inb_gw) * NQT + n;
+        if (lane == 0 && qq < a.inb_bq) a.out[qq * a.inb_bd + dj] = s;
+      }
+    } else {
+      float s = 0.0f;
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) s += finish_pair(m[n], qvalid[n], h);  // tiles in index order: deterministic
+      if (lane == 0) a.out[pair] = s;
+    }
   }
 }
 
@@ -440,8 +498,32 @@ static int launch_stream_inb(const MaxsimArgs& a0, hipStream_t stream) {
   return check_launch("maxsim_stream_kernel<all pairs>");
 }
 
+// all pairs tiled over queries (INB = 2): NQT queries per wavefront, XCD-aware (document slice, query group) map
+template <int DT, int NSL, int NQT>
+static int launch_stream_inb_tiled(const MaxsimArgs& a0, hipStream_t stream) {
+  MaxsimArgs a = a0;
+  const int lds = 2 * kBlkBytes;
+  const int64_t G = (a.inb_bq + NQT - 1) / NQT;
+  const int64_t target = (int64_t)kCUs * 4 / 8;                 // wavefronts per XCD
+  a.inb_gw = (int)(G < target ? G : target);                    // query-group lanes per (XCD, slice)
+  int64_t T = target / a.inb_gw;                                 // document slices per XCD
+  const int64_t max_t = (a.inb_bd + 7) / 8;                      // >= 1 document per slice
+  if (T > max_t) T = max_t;
+  if (T < 1) T = 1;
+  a.inb_t = (int)T;
+  const int64_t waves = 8 * T * a.inb_gw;
+  hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, NQT, 2>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  return check_launch("maxsim_stream_kernel<all pairs, tiled>");
+}
+
 template <int DT>
 static int launch_stream_inb_cfg(const MaxsimArgs& a, hipStream_t stream) {
+  // tiled over queries when the query tiles fit the register file (E <= 256), the masks are the documents' own
+  // (bug-compatible masking, colbert.py:158, depends on the query index) and there is more than one query
+  if (a.Q <= 32 && !a.inb_bug && a.inb_bq > 1 && !env().maxsim_inb_untiled) {
+    if (a.E == 128) return launch_stream_inb_tiled<DT, 1, 4>(a, stream);
+    if (a.E == 256) return launch_stream_inb_tiled<DT, 2, 2>(a, stream);
+  }
   switch (a.E / 128) {
     case 1: return launch_stream_inb<DT, 1>(a, stream);
     case 2: return launch_stream_inb<DT, 2>(a, stream);
@@ -555,7 +637,7 @@ extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q
                      (long long)Bq, (long long)Bd);
   if (Bq * Bd == 0) return MM_OK;
   MaxsimArgs a{};
-  a.q = q; a.d = d; a.out = out; a.n_pairs = Bq * Bd; a.ppq = 1; a.inb_bd = Bd; a.inb_bug = bug_compatible ? 1 : 0;
+  a.q = q; a.d = d; a.out = out; a.n_pairs = Bq * Bd; a.ppq = 1; a.inb_bd = Bd; a.inb_bq = Bq; a.inb_bug = bug_compatible ? 1 : 0;
   a.Q = Q; a.D = D; a.E = E;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;

@@ -14,6 +14,8 @@ struct MaxsimArgs {
   int64_t ppq;     // pairs per query (paired mode)
   int64_t inb_bd;  // > 0: all-pairs mode, pair p = (query p / Bd, doc p % Bd)
   int inb_bug;     // all-pairs: mask with the document row of the *query* index (colbert.py:158)
+  int64_t inb_bq;  // all-pairs: number of queries
+  int inb_t, inb_gw;  // all-pairs tiled over queries: document slices per XCD, query-group lanes (maxsim.hip, INB = 2)
   int Q, D, E;
   int64_t pairs_per_wave;
   // ragged (CSR) documents: document p = rows [rag_begin[p], rag_end[p]) of the token matrix `d`

@@ -276,11 +276,15 @@ def test_pair_per_row_layout_with_tokenizer_masks(dtype, Q, D, E):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("Bq,Bd,Q,D,E", [(70, 300, 32, 180, 128), (9, 1100, 38, 200, 128), (33, 33, 30, 64, 768), (5, 2000, 20, 47, 256)])
+@pytest.mark.parametrize("Bq,Bd,Q,D,E", [(70, 300, 32, 180, 128), (9, 1100, 38, 200, 128), (33, 33, 30, 64, 768), (5, 2000, 20, 47, 256),
+                                          (130, 70, 32, 33, 128), (1030, 37, 17, 64, 128), (3, 5, 9, 41, 256), (32, 32, 32, 180, 128)])
 def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
     """forward_inbatch_aggregation (colbert.py:154-162) at teacher-batch sizes: the streaming kernel in all-pairs mode
     (query tile resident, documents of one query consecutive) — holes, empty documents, padded queries, Bq != Bd,
-    Q = 38 (two query tiles), both masking conventions (by document j; by row i as the reference's :158 does)."""
+    Q = 38 (two query tiles), both masking conventions (by document j; by row i as the reference's :158 does).
+    E <= 256 with Q <= 32 and the documents' own masks runs TILED over queries (four / two queries per wavefront, one
+    document slice per XCD): query counts that are no multiple of the tile, more query groups than group lanes (1030),
+    fewer documents than slices (5), the dynamic teacher's own 32 x 32."""
     from matchmaker_amd import ops
     dev = util.require_gpu()
     g = torch.Generator().manual_seed(Bq * 7 + Bd)
@@ -301,5 +305,6 @@ def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
         np.testing.assert_allclose(bug, O.maxsim_inbatch(q.float().numpy(), qm.numpy(), d.float().numpy(), dm.numpy(), bug_compatible=True),
                                    atol=util.TOL_BF16, rtol=1e-4)
     # every row of the matrix equals the paired operator on that query against all documents
-    row = ops.maxsim(q[3:4].to(dev), d.to(dev), qm[3:4].to(dev), dm.to(dev), pairs_per_query=Bd)
-    assert torch.equal(row.cpu(), torch.from_numpy(out[3]))
+    for ri in {min(3, Bq - 1), Bq - 1, Bq // 2}:
+        row = ops.maxsim(q[ri:ri + 1].to(dev), d.to(dev), qm[ri:ri + 1].to(dev), dm.to(dev), pairs_per_query=Bd)
+        assert torch.equal(row.cpu(), torch.from_numpy(out[ri]))
