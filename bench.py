@@ -376,6 +376,46 @@ def extra_tkl(steps, cpu_budget):
     return out
 
 
+def extra_all_pairs(steps, cpu_budget):
+    """forward_inbatch_aggregation (colbert.py:154-162) at a teacher batch far beyond the reference's 32 x 32:
+    1024 queries x 1024 documents, Q=32 / D=180 / dim=128, bf16, the documents' own masks.  MFMA-shaped: every
+    (query, document) pair is a 32 x 180 x 128 product and the documents (47 MB) stay in the Infinity Cache."""
+    import torch
+    from matchmaker_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Bq = Bd = 1024
+    g = torch.Generator(device=dev).manual_seed(1414)
+    q = (torch.randn(Bq, Q, E, generator=g, device=dev) / E ** 0.5).bfloat16()
+    d = (torch.randn(Bd, D, E, generator=g, device=dev) / E ** 0.5).bfloat16()
+    qm = torch.ones(Bq, Q, dtype=torch.long, device=dev)
+    dm = torch.ones(Bd, D, dtype=torch.long, device=dev)     # every position real: the flop count below is what runs
+    fn = lambda: ops.maxsim_inbatch(q, qm, d, dm, bug_compatible=False)
+    ms = gpu_time_ms(fn, steps)
+    flop = 2.0 * Bq * Bd * Q * D * E
+    t = ms * 1e-3
+    out = {"workload": f"all-pairs MaxSim (colbert.py:154-162), {Bq} queries x {Bd} documents, Q={Q}/D={D}/dim={E}, bf16, "
+                       f"all positions real, int64 masks",
+           "dtype": "bf16", "ms": ms, "pairs_per_s": Bq * Bd / t, "flop": flop,
+           "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
+                        "frac": flop / t / MFMA_PEAK_16BIT},
+           "kernel": "maxsim_stream_kernel<all pairs, tiled over queries>: 4 queries per wavefront"}
+    t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
+    out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        n = 64
+        qc, dc, qmc, dmc = q[:n].float().cpu(), d[:n].float().cpu(), qm[:n].cpu(), dm[:n].cpu()
+
+        def run():
+            with torch.no_grad():
+                TP.maxsim_inbatch(qc, qmc, dc, dmc, bug_compatible=False)
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: run, cpu_budget, n * n)
+        out["cpu_baseline"] = {"value": ra, "unit": "pairs/s", "cores": threads, "kind": "port",
+                               "sample": f"{n} x {n} all-pairs blocks (oracle/torch_port.py, fp32), {na} calls in {ta:.1f} s",
+                               "one_thread": {"value": r1, "cores": 1}}
+    return out
+
+
 def extra_dot_topk(steps, cpu_budget):
     """BASELINE.json configs[4], ONE rank's shard: 8,841,823 / 8 passages x dim 768 fp16 against all 6,980 queries,
     exact top-1000 (faiss IndexFlatIP semantics)."""
@@ -592,7 +632,7 @@ def main():
                         extra["dropin_forward"] = {"error": repr(e)}
                     del q, d
                     torch.cuda.empty_cache()
-                    for name, fn in (("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk)):
+                    for name, fn in (("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk)):
                         try:
                             extra[name] = fn(3 if name == "dot_topk" else 10, cpu_b)
                         except Exception as e:

@@ -27,6 +27,25 @@ def maxsim_aggregation(query_vecs, document_vecs):
     return score.sum(-1)                                                                        # :108
 
 
+def maxsim_inbatch(query_vecs, query_mask, document_vecs, document_mask, bug_compatible=False):
+    """ColBERT.forward_inbatch_aggregation — matchmaker/models/colbert.py:154-162: one matrix product over all
+    (query token, document token) pairs, viewed as [Bq, Bd, Q, D].  bug_compatible=True masks score[i, j] with the
+    mask row of index i as :158 does (it needs Bq == Bd); False masks with document j's own row."""
+    Bq, Q, E = query_vecs.shape
+    Bd, D, _ = document_vecs.shape
+    score = torch.mm(query_vecs.reshape(Bq * Q, E), document_vecs.reshape(Bd * D, E).t())      # :154
+    score = score.view(Bq, Q, Bd, D).transpose(1, 2)                                            # :155-156
+    keep = document_mask.bool()
+    if bug_compatible:
+        keep = keep.unsqueeze(1).unsqueeze(1).expand(-1, Bd, Q, -1)                             # :158 (row i)
+    else:
+        keep = keep.unsqueeze(0).unsqueeze(2).expand(Bq, -1, Q, -1)
+    score = score.masked_fill(~keep, -1000)                                                     # :158
+    score = score.max(-1).values                                                                # :159
+    score = score.masked_fill(~query_mask.bool().unsqueeze(1).expand(-1, Bd, -1), 0)            # :160
+    return score.sum(-1)                                                                        # :161
+
+
 def maxsim_forward_backward(q, d, query_mask, document_mask, grad_out):
     """Autograd through maxsim_forward: what loss.backward() (train.py:503-524) sends into the
     encoder outputs.  Returns (score, grad_q, grad_d) as float32 CPU tensors."""
