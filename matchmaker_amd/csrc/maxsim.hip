@@ -36,8 +36,8 @@ namespace mm {
 // (xcd = blockIdx % 8, t, jg) sweeps document slice xcd * T + t of 8T for the query groups jg, jg + Gw, ... — the
 // wavefronts of one XCD stream the same documents for different queries at the same time, so a slice comes through
 // that XCD's L2 once per sweep instead of once per group.
-template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB = 0>
-__global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB>
+__device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
   constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -199,10 +199,13 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
     // ragged documents have no padded positions; an empty one scores like a fully padded one
     const float fill = (RAG ? len == 0 : len < D) ? -1000.0f : neg_inf();
     float m[NQT][16];
+    float m1[NQT];   // INB == 2: one running maximum per lane and tile (block_max1)
 #pragma unroll
-    for (int n = 0; n < NQT; ++n)
+    for (int n = 0; n < NQT; ++n) {
+      m1[n] = fill;
 #pragma unroll
       for (int i = 0; i < 16; ++i) m[n][i] = fill;
+    }
 
     for (int t = 0; t < nb; ++t) {
       f32x16 acc[NQT];
@@ -226,13 +229,16 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, mask_row(pair) * nblk_tot + t) & ex) : ex;
 #pragma unroll
-      for (int n = 0; n < NQT; ++n) block_max(m[n], acc[n], ex, va, fill, h);
+      for (int n = 0; n < NQT; ++n) {
+        if (INB == 2) block_max1(m1[n], acc[n], ex, va, fill, h);
+        else block_max(m[n], acc[n], ex, va, fill, h);
+      }
     }
     if (INB == 2) {
       const int64_t dj = doc_row(pair);
 #pragma unroll
       for (int n = 0; n < NQT; ++n) {
-        const float s = finish_pair(m[n], qvalid[n], h);
+        const float s = finish_pair1(m1[n], qvalid[n], h);
         const int64_t qq = ((int64_t)g0 + qi * a.inb_gw) * NQT + n;
         if (lane == 0 && qq < a.inb_bq) a.out[qq * a.inb_bd + dj] = s;
       }
@@ -243,6 +249,19 @@ __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
       if (lane == 0) a.out[pair] = s;
     }
   }
+}
+
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB = 0>
+__global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
+  maxsim_stream_body<DT, NBUF, NT, NSL, RAG, NQT, INB>(a);
+}
+
+// The tiled all-pairs instantiations are compiled for two wavefronts per SIMD (<= 256 registers): that makes the
+// compiler keep the MFMA accumulators in VGPRs, where the max epilogue can read them — with the whole 512-register file
+// it parks them in AGPRs and spends 64 v_accvgpr_read per block on getting them back.
+template <int DT, int NSL, int NQT>
+__global__ void __launch_bounds__(64, 2) maxsim_allpairs_tiled_kernel(const MaxsimArgs a) {
+  maxsim_stream_body<DT, 2, false, NSL, false, NQT, 2>(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -512,8 +531,8 @@ static int launch_stream_inb_tiled(const MaxsimArgs& a0, hipStream_t stream) {
   if (T < 1) T = 1;
   a.inb_t = (int)T;
   const int64_t waves = 8 * T * a.inb_gw;
-  hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, NQT, 2>), dim3((unsigned)waves), dim3(64), lds, stream, a);
-  return check_launch("maxsim_stream_kernel<all pairs, tiled>");
+  hipLaunchKernelGGL((maxsim_allpairs_tiled_kernel<DT, NSL, NQT>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+  return check_launch("maxsim_allpairs_tiled_kernel");
 }
 
 template <int DT>

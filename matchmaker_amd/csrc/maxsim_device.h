@@ -108,6 +108,31 @@ __device__ __forceinline__ void load_q_frags(const char* base, short8 (&qf)[8]) 
       : "memory");
 }
 
+// The same with ONE running maximum per lane (the 16 rows a lane holds all belong to its query token, and max is
+// exact in any order): 8 v_max3 per block instead of 16 v_max, 1 register instead of 16 — what lets the all-pairs
+// kernel keep four query tiles AND their accumulators in VGPRs.
+__device__ __forceinline__ void block_max1(float& m, const f32x16& acc, uint32_t ex, uint32_t va, float fill, int h) {
+  if (va == 0xffffffffu) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, acc[i]), acc[i + 1]);
+  } else {
+    const uint32_t exs = ex >> (4 * h), vas = va >> (4 * h);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int bit = rowof(i);
+      v[i] = ((vas >> bit) & 1u) ? acc[i] : (((exs >> bit) & 1u) ? -1000.0f : fill);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[i]), v[i + 1]);
+  }
+}
+
+__device__ __forceinline__ float finish_pair1(float m, bool qvalid, int h) {
+  m = fmaxf(m, __shfl_xor(m, 32, 64));  // other half holds the other 16 rows of every block
+  return wave_sum((qvalid && h == 0) ? m : 0.0f);
+}
+
 __device__ __forceinline__ float finish_pair(const float (&m)[16], bool qvalid, int h) {
   float mx = m[0];
 #pragma unroll
