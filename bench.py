@@ -398,7 +398,7 @@ def extra_all_pairs(steps, cpu_budget):
            "dtype": "bf16", "ms": ms, "pairs_per_s": Bq * Bd / t, "flop": flop,
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
-           "kernel": "maxsim_stream_kernel<all pairs, tiled over queries>: 4 queries per wavefront"}
+           "kernel": "maxsim_allpairs_tiled_kernel: 4 queries per wavefront", "profile": "profiles/r02_allpairs_pmc.json"}
     t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
     out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
     if cpu_budget > 0:

@@ -5,7 +5,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from matchmaker_amd import ops
 dev = torch.device("cuda:0")
-for Bq, Bd in ((32, 32), (64, 64), (128, 128), (256, 256), (1024, 1024), (512, 4096)):
+SIZES = ((32, 32), (64, 64), (128, 128), (256, 256), (1024, 1024), (512, 4096))
+if len(sys.argv) == 3:            # one size only (profiling): python tools/bench_inbatch.py 1024 1024
+    SIZES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for Bq, Bd in SIZES:
     q = torch.randn(Bq, 32, 128, device=dev).bfloat16(); d = torch.randn(Bd, 180, 128, device=dev).bfloat16()
     qm = torch.ones(Bq, 32, dtype=torch.long, device=dev); dm = torch.ones(Bd, 180, dtype=torch.long, device=dev)
     for _ in range(3): ops.maxsim_inbatch(q, qm, d, dm)
