@@ -277,7 +277,8 @@ def test_pair_per_row_layout_with_tokenizer_masks(dtype, Q, D, E):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Bq,Bd,Q,D,E", [(70, 300, 32, 180, 128), (9, 1100, 38, 200, 128), (33, 33, 30, 64, 768), (5, 2000, 20, 47, 256),
-                                          (130, 70, 32, 33, 128), (1030, 37, 17, 64, 128), (3, 5, 9, 41, 256), (32, 32, 32, 180, 128)])
+                                          (130, 70, 32, 33, 128), (1030, 37, 17, 64, 128), (3, 5, 9, 41, 256), (32, 32, 32, 180, 128),
+                                          (2, 1, 1, 1, 128), (6, 9, 32, 32, 128), (4, 3, 5, 97, 256)])
 def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
     """forward_inbatch_aggregation (colbert.py:154-162) at teacher-batch sizes: the streaming kernel in all-pairs mode
     (query tile resident, documents of one query consecutive) — holes, empty documents, padded queries, Bq != Bd,
