@@ -518,6 +518,7 @@ static int launch_stream_inb(const MaxsimArgs& a0, hipStream_t stream) {
 }
 
 // all pairs tiled over queries (INB = 2): NQT queries per wavefront, XCD-aware (document slice, query group) map
+constexpr int kNotLaunched = 1;   // (not an MM_* code: those are <= 0)
 template <int DT, int NSL, int NQT>
 static int launch_stream_inb_tiled(const MaxsimArgs& a0, hipStream_t stream) {
   MaxsimArgs a = a0;
@@ -531,7 +532,7 @@ static int launch_stream_inb_tiled(const MaxsimArgs& a0, hipStream_t stream) {
   if (T < 1) T = 1;
   a.inb_t = (int)T;
   // the kernel indexes a wavefront's (query group, document) items with 32 bits
-  if (((G + a.inb_gw - 1) / a.inb_gw) * ((a.inb_bd + 8 * T - 1) / (8 * T) + 1) >= (1LL << 31)) return -1;
+  if (((G + a.inb_gw - 1) / a.inb_gw) * ((a.inb_bd + 8 * T - 1) / (8 * T) + 1) >= (1LL << 31)) return kNotLaunched;
   const int64_t waves = 8 * T * a.inb_gw;
   hipLaunchKernelGGL((maxsim_allpairs_tiled_kernel<DT, NSL, NQT>), dim3((unsigned)waves), dim3(64), lds, stream, a);
   return check_launch("maxsim_allpairs_tiled_kernel");
@@ -542,10 +543,10 @@ static int launch_stream_inb_cfg(const MaxsimArgs& a, hipStream_t stream) {
   // tiled over queries when the query tiles fit the register file (E <= 256), the masks are the documents' own
   // (bug-compatible masking, colbert.py:158, depends on the query index) and there is more than one query
   if (a.Q <= 32 && !a.inb_bug && a.inb_bq > 1 && !env().maxsim_inb_untiled) {
-    int e = -1;
+    int e = kNotLaunched;
     if (a.E == 128) e = launch_stream_inb_tiled<DT, 1, 4>(a, stream);
     if (a.E == 256) e = launch_stream_inb_tiled<DT, 2, 2>(a, stream);
-    if (e != -1) return e;      // -1: not launched (index range), one query per wavefront below
+    if (e != kNotLaunched) return e;      // index range too large for the tiled map: one query per wavefront below
   }
   switch (a.E / 128) {
     case 1: return launch_stream_inb<DT, 1>(a, stream);
