@@ -293,10 +293,13 @@ def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
     d = (torch.randn(Bd, D, E, generator=g) / E ** 0.5).to(dtype)
     ql = torch.randint(1, Q + 1, (Bq,), generator=g)
     dl = torch.randint(0, D + 1, (Bd,), generator=g)
-    dl[0], dl[1] = D, 0
+    dl[0] = D
+    if Bd > 1:
+        dl[1] = 0
     qm = (torch.arange(Q)[None] < ql[:, None]).long()
     dm = (torch.arange(D)[None] < dl[:, None]).long()
-    dm[0, 1] = 0
+    if D > 1:
+        dm[0, 1] = 0
     qm[0, 0] = 0
     out = ops.maxsim_inbatch(q.to(dev), qm.to(dev), d.to(dev), dm.to(dev), bug_compatible=False).cpu().numpy()
     ref = O.maxsim_inbatch(q.float().numpy(), qm.numpy(), d.float().numpy(), dm.numpy(), bug_compatible=False)
