@@ -198,8 +198,11 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
     const int nb = (len + 31) >> 5;
     // ragged documents have no padded positions; an empty one scores like a fully padded one
     const float fill = (RAG ? len == 0 : len < D) ? -1000.0f : neg_inf();
+    // several register tiles (two tiles of one long query, or the queries of the tiled all-pairs mode) keep ONE running
+    // maximum per lane and tile (block_max1): at E = 768 two query tiles are 384 registers of B fragments already
+    constexpr bool ONE = INB == 2 || NQT >= 2;
     float m[NQT][16];
-    float m1[NQT];   // INB == 2: one running maximum per lane and tile (block_max1)
+    float m1[NQT];
 #pragma unroll
     for (int n = 0; n < NQT; ++n) {
       m1[n] = fill;
@@ -230,7 +233,7 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
       const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, mask_row(pair) * nblk_tot + t) & ex) : ex;
 #pragma unroll
       for (int n = 0; n < NQT; ++n) {
-        if (INB == 2) block_max1(m1[n], acc[n], ex, va, fill, h);
+        if (ONE) block_max1(m1[n], acc[n], ex, va, fill, h);
         else block_max(m[n], acc[n], ex, va, fill, h);
       }
     }
@@ -245,7 +248,8 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
     } else {
       float s = 0.0f;
 #pragma unroll
-      for (int n = 0; n < NQT; ++n) s += finish_pair(m[n], qvalid[n], h);  // tiles in index order: deterministic
+      for (int n = 0; n < NQT; ++n)  // tiles in index order: deterministic
+        s += ONE ? finish_pair1(m1[n], qvalid[n], h) : finish_pair(m[n], qvalid[n], h);
       if (lane == 0) a.out[pair] = s;
     }
   }
@@ -507,11 +511,9 @@ static int launch_stream_inb(const MaxsimArgs& a0, hipStream_t stream) {
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  if constexpr (NSL <= 4) {
-    if (a.Q > 32) {
-      hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, 2, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
-      return check_launch("maxsim_stream_kernel<all pairs>");
-    }
+  if (a.Q > 32) {
+    hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, 2, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+    return check_launch("maxsim_stream_kernel<all pairs>");
   }
   hipLaunchKernelGGL((maxsim_stream_kernel<DT, 2, false, NSL, false, 1, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
   return check_launch("maxsim_stream_kernel<all pairs>");
@@ -560,9 +562,7 @@ static int launch_stream_inb_cfg(const MaxsimArgs& a, hipStream_t stream) {
 template <int DT, int NSL, bool RAG>
 static int launch_stream_nsl(const MaxsimArgs& a, hipStream_t stream) {
   const bool nt = env().maxsim_nt != 0;
-  if constexpr (NSL <= 4) {
-    if (a.Q > 32) return launch_stream<DT, 2, true, NSL, RAG, 2>(a, stream);  // two query tiles in registers
-  }
+  if (a.Q > 32) return launch_stream<DT, 2, true, NSL, RAG, 2>(a, stream);  // two query tiles in registers
   if (NSL == 1 && !RAG) {  // the tuning knobs are only instantiated for the headline shape
     switch (env().maxsim_nbuf) {
       case 3: return nt ? launch_stream<DT, 3, true, NSL, false>(a, stream) : launch_stream<DT, 3, false, NSL, false>(a, stream);
@@ -633,7 +633,7 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
   if (pair_kernel) return maxsim_pair_launch(a, dtype, false, stream);
-  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
+  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && Q <= 64 &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
   // fp32 token vectors (ColBERT run with use_fp16 = False): the split-bf16 streaming kernel of kernel_pool128.hip
@@ -668,8 +668,8 @@ extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q
   if (int e = resolve_mask(q_mask, q_mask_kind, Bq, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, Bd, D, &ws, &left, stream, &a.dm)) return e;
   // the streaming kernel in all-pairs mode (query tile resident, documents of one query consecutive: no non-temporal
-  // hint, every document is read once per query); Q > 32 at E = 768 and fp32 stay on the one-wavefront-per-pair kernel
-  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
+  // hint, every document is read once per query); Q > 64 and fp32 stay on the one-wavefront-per-pair kernel
+  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && Q <= 64 &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) {
     a.ppq = Bd;
@@ -699,7 +699,7 @@ extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
-  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && (Q <= 32 || (Q <= 64 && E <= 512)) &&
+  const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && Q <= 64 &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, true>(a, stream) : launch_stream_cfg<MM_F16, true>(a, stream);
   return launch_generic(a, dtype, stream);

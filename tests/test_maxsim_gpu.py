@@ -175,10 +175,11 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, util.TOL_BF16), (torch.float16, util.TOL_BF16)])
 @pytest.mark.parametrize("Q,D,E,ppq", [(38, 180, 128, 7), (64, 200, 128, 1), (33, 47, 256, 3), (40, 100, 512, 2),
-                                       (38, 90, 768, 2)])
+                                       (38, 90, 768, 2), (40, 200, 768, 1), (64, 64, 768, 3), (65, 40, 128, 2)])
 def test_queries_longer_than_one_tile(dtype, tol, Q, D, E, ppq):
-    """Q = 30 + 8 [MASK] tokens (ColBERT query augmentation, independent_reranking_loader.py:106-112) needs two
-    query tiles: streaming kernel with NQT = 2 up to E = 512, generic kernel for E = 768."""
+    """Q = 30 + 8 [MASK] tokens (ColBERT query augmentation, independent_reranking_loader.py:106-112; the published
+    checkpoint's config has query_augment_mask_number: 8 at colbert_compression_dim: 768) needs two query tiles: the
+    streaming kernel with NQT = 2 for every streamed width up to Q = 64; the generic kernel beyond."""
     from matchmaker_amd import ops
     dev = util.require_gpu()
     g = torch.Generator().manual_seed(Q * 17 + E)
@@ -277,7 +278,7 @@ def test_pair_per_row_layout_with_tokenizer_masks(dtype, Q, D, E):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Bq,Bd,Q,D,E", [(70, 300, 32, 180, 128), (9, 1100, 38, 200, 128), (33, 33, 30, 64, 768), (5, 2000, 20, 47, 256),
-                                          (130, 70, 32, 33, 128), (1030, 37, 17, 64, 128), (3, 5, 9, 41, 256), (32, 32, 32, 180, 128),
+                                          (130, 70, 32, 33, 128), (1030, 37, 17, 64, 128), (3, 5, 9, 41, 256), (32, 32, 32, 180, 128), (7, 20, 38, 200, 768),
                                           (2, 1, 1, 1, 128), (6, 9, 32, 32, 128), (4, 3, 5, 97, 256)])
 def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
     """forward_inbatch_aggregation (colbert.py:154-162) at teacher-batch sizes: the streaming kernel in all-pairs mode

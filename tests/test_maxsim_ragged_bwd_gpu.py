@@ -21,7 +21,7 @@ def _store(rng, n_docs, E, dtype, max_len=70, empty=()):
     return tok, begin.astype(np.int64), end.astype(np.int64)
 
 
-@pytest.mark.parametrize("dtype,E,Q,tol", [(torch.float16, 768, 32, util.TOL_BF16), (torch.bfloat16, 128, 32, util.TOL_BF16),
+@pytest.mark.parametrize("dtype,E,Q,tol", [(torch.float16, 768, 32, util.TOL_BF16), (torch.float16, 768, 38, util.TOL_BF16), (torch.bfloat16, 128, 32, util.TOL_BF16),
                                           (torch.float16, 128, 7, util.TOL_BF16), (torch.float32, 128, 32, util.TOL_FP32),
                                           (torch.float32, 24, 40, util.TOL_FP32), (torch.bfloat16, 256, 20, util.TOL_BF16)])
 def test_ragged_matches_per_document_aggregation(dtype, E, Q, tol):

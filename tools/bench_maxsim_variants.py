@@ -71,6 +71,20 @@ if "dropin768" in which:
     report("fp16 drop-in layout at the reference's defaults (colbert_compression_dim 768, Q 32, D 200, autocast fp16)",
            timeit(lambda: ops.maxsim(q7, d7, qm7, dm7, 1)), n, n * ((200 + 32) * 768 * 2 + 8 * 232 + 4))
     del q7, d7, qm7, dm7
+if "published768" in which:
+    # the published ColBERT checkpoint's configuration (config/huggingface_modelhub/.../colbert-distilbert-margin_mse-T2-msmarco.yaml):
+    # colbert_compression_dim 768, max_query_length 30 + query_augment_mask_number 8 -> Q = 38, D = 200, fp16
+    n = 16000
+    for QQ in (38, 40):
+        q7 = torch.randn(n, QQ, 768, device=dev).to(torch.float16)
+        d7 = torch.randn(n, 200, 768, device=dev).to(torch.float16)
+        qm7 = torch.ones(n, QQ, dtype=torch.int64, device=dev); dm7 = torch.ones(n, 200, dtype=torch.int64, device=dev)
+        report(f"fp16 drop-in layout, published ColBERT checkpoint config (dim 768, Q {QQ} = 30 + 8 [MASK], D 200)",
+               timeit(lambda: ops.maxsim(q7, d7, qm7, dm7, 1)), n, n * ((200 + QQ) * 768 * 2 + 8 * (200 + QQ) + 4))
+        qs = q7[: n // 1000].contiguous()
+        report(f"fp16 shared query, same shapes (Q {QQ})",
+               timeit(lambda: ops.maxsim(qs, d7, qm7[: n // 1000], dm7, 1000)), n, n * (200 * 768 * 2 + 8 * 200) )
+        del q7, d7, qm7, dm7
 if "i64mask" in which:
     dm = synth.len_to_mask(d_len, D, torch.int64)
     qm = synth.len_to_mask(q_len, Q, torch.int64)
