@@ -85,6 +85,16 @@ if "published768" in which:
         report(f"fp16 shared query, same shapes (Q {QQ})",
                timeit(lambda: ops.maxsim(qs, d7, qm7[: n // 1000], dm7, 1000)), n, n * (200 * 768 * 2 + 8 * 200) )
         del q7, d7, qm7, dm7
+if "longq128" in which:
+    # [MASK]-augmented queries at the headline width: Q = 40, dim 128, D = 180, pair-per-row (the pair kernel holds one tile)
+    n = 64000
+    for QQ in (32, 40):
+        q7 = torch.randn(n, QQ, 128, device=dev).to(torch.bfloat16)
+        d7 = torch.randn(n, 180, 128, device=dev).to(torch.bfloat16)
+        qm7 = torch.ones(n, QQ, dtype=torch.int64, device=dev); dm7 = torch.ones(n, 180, dtype=torch.int64, device=dev)
+        report(f"bf16 drop-in layout, dim 128, Q {QQ}, D 180",
+               timeit(lambda: ops.maxsim(q7, d7, qm7, dm7, 1)), n, n * ((180 + QQ) * 128 * 2 + 8 * (180 + QQ) + 4))
+        del q7, d7, qm7, dm7
 if "i64mask" in which:
     dm = synth.len_to_mask(d_len, D, torch.int64)
     qm = synth.len_to_mask(q_len, Q, torch.int64)
