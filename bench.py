@@ -376,6 +376,41 @@ def extra_tkl(steps, cpu_budget):
     return out
 
 
+def extra_published_checkpoint(steps, cpu_budget):
+    """The configuration of the reference's PUBLISHED ColBERT checkpoint (config/huggingface_modelhub/sebastian-hofstaetter/
+    colbert-distilbert-margin_mse-T2-msmarco.yaml: colbert_compression_dim 768, max_query_length 30 +
+    query_augment_mask_number 8 -> Q = 38, max_doc_length 200, use_fp16) in eval.py's batch layout (ColBERT._score)."""
+    import torch
+    from matchmaker_amd.colbert import ColBERT
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n, Qp, Dp, Ep = 16000, 38, 200, 768
+    g = torch.Generator(device=dev).manual_seed(768)
+    qp = (torch.randn(n, Qp, Ep, generator=g, device=dev) / Ep ** 0.5).half()
+    dp = (torch.randn(n, Dp, Ep, generator=g, device=dev) / Ep ** 0.5).half()
+    qm = torch.ones(n, Qp, dtype=torch.long, device=dev)
+    dm = torch.ones(n, Dp, dtype=torch.long, device=dev)
+    ms = gpu_time_ms(lambda: ColBERT._score(qp, dp, qm, dm), steps)
+    by = n * ((Dp + Qp) * Ep * 2 + 8 * (Dp + Qp) + 4)
+    gbs = by / (ms * 1e-3) / 1e9
+    out = {"workload": f"{n} pairs in the reference's batch layout, Q={Qp} (30 + 8 [MASK]) / D={Dp} / dim={Ep}, fp16, int64 HF masks",
+           "dtype": "f16", "ms": ms, "pairs_per_s": n / (ms * 1e-3), "algorithmic_bytes": by,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+           "kernel": "pack_mask_kernel + maxsim_stream_kernel with two query tiles (NSL = 6, NQT = 2)"}
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        m = 256
+        qc, dc, qmc, dmc = qp[:m].float().cpu(), dp[:m].float().cpu(), qm[:m].cpu(), dm[:m].cpu()
+
+        def run():
+            with torch.no_grad():
+                TP.maxsim_forward(qc, dc, qmc, dmc)
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: run, cpu_budget, m)
+        out["cpu_baseline"] = {"value": ra, "unit": "pairs/s", "cores": threads, "kind": "port",
+                               "sample": f"{m}-pair batches (oracle/torch_port.maxsim_forward, fp32), {na} calls in {ta:.1f} s",
+                               "one_thread": {"value": r1, "cores": 1}}
+    return out
+
+
 def extra_all_pairs(steps, cpu_budget):
     """forward_inbatch_aggregation (colbert.py:154-162) at a teacher batch far beyond the reference's 32 x 32:
     1024 queries x 1024 documents, Q=32 / D=180 / dim=128, bf16, the documents' own masks.  MFMA-shaped: every
@@ -632,7 +667,7 @@ def main():
                         extra["dropin_forward"] = {"error": repr(e)}
                     del q, d
                     torch.cuda.empty_cache()
-                    for name, fn in (("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk)):
+                    for name, fn in (("published_checkpoint", extra_published_checkpoint), ("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk)):
                         try:
                             extra[name] = fn(3 if name == "dot_topk" else 10, cpu_b)
                         except Exception as e:
