@@ -5,7 +5,7 @@
  * The reference (sebastian-hofstaetter/matchmaker) is pure Python: it has no FFI of its own.
  * Its "operator API" for this path is the nn.Module protocol of SURVEY.md §8(b).  Each entry
  * point below replaces the arithmetic of one reference method; the Python host side
- * (matchmaker_amd/*.py) mirrors the method signatures and binds these symbols with ctypes
+ * (the .py modules of matchmaker_amd/) mirrors the method signatures and binds these symbols with ctypes
  * (INTEGRATION.md shows the stub a matchmaker maintainer would add).
  *
  * Conventions

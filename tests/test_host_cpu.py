@@ -32,6 +32,43 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_I64, _lib.MASK_I64) > 0
 
 
+def test_header_is_plain_c_and_a_c_client_links_the_library(tmp_path):
+    """The drop-in boundary is a C ABI: include/mm_native.h must compile as C (gcc -std=c99, no C++ / torch types) and
+    a C program must link libmm_native.so and call it — here the entry points that need no GPU: the ABI version, the
+    host-side workspace arithmetic, and an argument error reported through mm_last_error()."""
+    import shutil
+    import subprocess
+    from matchmaker_amd import build
+    so = build.build()
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    src = tmp_path / "client.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "mm_native.h"
+int main(void) {
+  if (mm_abi_version() != 1) return 1;
+  if (mm_maxsim_workspace_bytes(10, 1, 32, 180, MM_MASK_I64, MM_MASK_I64) == 0) return 2;
+  if (mm_tkl_workspace_bytes(4, 100, 52, 20, 11) == 0) return 3;
+  /* a null pointer is refused before anything touches the device */
+  int e = mm_maxsim_fwd(NULL, NULL, NULL, MM_MASK_NONE, NULL, MM_MASK_NONE, NULL, 4, 1, 32, 180, 128, MM_BF16, NULL, 0, NULL);
+  if (e != MM_EINVAL) return 4;
+  if (strlen(mm_last_error()) == 0) return 5;
+  printf("c client ok: %s\n", mm_last_error());
+  return 0;
+}
+""")
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(so)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-l:libmm_native.so", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "c client ok" in r.stdout
+
+
 def test_ops_reject_cpu_tensors_loudly():
     from matchmaker_amd import ops, NativeError
     q = torch.zeros(1, 4, 16)
