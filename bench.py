@@ -395,7 +395,8 @@ def extra_published_checkpoint(steps, cpu_budget):
     out = {"workload": f"{n} pairs in the reference's batch layout, Q={Qp} (30 + 8 [MASK]) / D={Dp} / dim={Ep}, fp16, int64 HF masks",
            "dtype": "f16", "ms": ms, "pairs_per_s": n / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "pack_mask_kernel + maxsim_stream_kernel with two query tiles (NSL = 6, NQT = 2)"}
+           "kernel": "pack_mask_kernel + maxsim_stream_kernel with two query tiles (NSL = 6, NQT = 2)",
+           "profile": "profiles/r02_published_pmc.json"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         m = 256

@@ -1,6 +1,6 @@
 #!/bin/bash
 # All rocprofv3 evidence of a round in one go (run on the GPU box from the repo root):
-#   bash tools/profile_round.sh <tag> ["workloads"]   -> gpurun_out/prof_<tag>_{maxsim,dropin,tk,tkl,tklragged,dot,allpairs}/summary.json
+#   bash tools/profile_round.sh <tag> ["workloads"]   -> gpurun_out/prof_<tag>_{maxsim,dropin,tk,tkl,tklragged,dot,allpairs,published}/summary.json
 # Counters are collected in their own passes with --kernel-trace only (never with sys/hip tracing).
 set -u
 TAG=${1:-r02}
@@ -33,5 +33,6 @@ for W in $WL; do
     tklragged) prof tklragged python tools/bench_tkl.py --steps 5;;
     dot) prof dot python tools/bench_dot_topk.py --steps 2;;
     allpairs) prof allpairs python tools/bench_inbatch.py 1024 1024;;
+    published) prof published python tools/bench_maxsim_variants.py published768;;
   esac
 done
