@@ -381,3 +381,32 @@ def test_rerank_helpers_follow_eval_py_and_core_metrics():
         except Exception:
             return                                             # optional dependencies of the reference missing here
         assert mod.unrolled_to_ranked_result(got) == ranked
+
+
+@pytest.mark.parametrize("Bq,Bd,NQT", [(32, 32, 4), (1030, 37, 4), (3, 5, 2), (2, 1, 4), (1024, 1024, 4), (7, 20000, 4), (513, 9, 2),
+                                       (130, 70, 4)])
+def test_tiled_all_pairs_work_map_covers_every_pair_once(Bq, Bd, NQT):
+    """Python mirror of launch_stream_inb_tiled / the INB == 2 prologue of maxsim_stream_body (csrc/maxsim.hip): workgroup
+    (xcd, t, jg) takes document slice xcd * T + t of 8T and the query groups jg, jg + Gw, ...  Every (query, document)
+    pair must be produced exactly once, whatever the sizes."""
+    cus = 256
+    G = (Bq + NQT - 1) // NQT
+    target = cus * 4 // 8
+    gw = min(G, target)
+    T = max(1, min(target // gw, (Bd + 7) // 8))
+    seen = np.zeros((Bq, Bd), dtype=np.int32)
+    for bid in range(8 * T * gw):
+        xcd, rest = bid & 7, bid >> 3
+        t, g0 = rest % T, rest // T
+        S, si = 8 * T, xcd * T + t
+        d_first = Bd * si // S
+        nd = Bd * (si + 1) // S - d_first
+        ng = (G - g0 + gw - 1) // gw if g0 < G else 0
+        for v in range(ng * nd):
+            grp = g0 + (v // nd) * gw
+            doc = d_first + v % nd
+            for n in range(NQT):
+                qq = grp * NQT + n
+                if qq < Bq:
+                    seen[qq, doc] += 1
+    assert seen.min() == 1 and seen.max() == 1
