@@ -82,22 +82,37 @@ struct DotMfma<MM_F16> {
 __device__ __forceinline__ constexpr int drowof(int i) { return (i & 3) + 8 * (i >> 2); }
 
 // 8 x 16 B of one query row slice (256 B): chunks (2kk + h); own vmcnt(0) (prologue only)
+#define MM_DOT_LOADQ(C)                                                                                 \
+  asm volatile(                                                                                         \
+      "global_load_dwordx4 %0, %8, off\n\t"                                                             \
+      "global_load_dwordx4 %1, %8, off offset:32\n\t"                                                   \
+      "global_load_dwordx4 %2, %8, off offset:64\n\t"                                                   \
+      "global_load_dwordx4 %3, %8, off offset:96\n\t"                                                   \
+      "global_load_dwordx4 %4, %8, off offset:128\n\t"                                                  \
+      "global_load_dwordx4 %5, %8, off offset:160\n\t"                                                  \
+      "global_load_dwordx4 %6, %8, off offset:192\n\t"                                                  \
+      "global_load_dwordx4 %7, %8, off offset:224\n\t"                                                  \
+      "s_waitcnt vmcnt(0)"                                                                              \
+      : "=&" C(qf[0]), "=&" C(qf[1]), "=&" C(qf[2]), "=&" C(qf[3]), "=&" C(qf[4]), "=&" C(qf[5]),       \
+        "=&" C(qf[6]), "=&" C(qf[7])                                                                    \
+      : "v"(base)                                                                                       \
+      : "memory")
+// AGPR = true: the fragments are loaded straight into accumulator registers and STAY there — the MFMA reads its B operand
+// from AGPRs directly.  Left to itself the register allocator treats the fragments that do not fit the 256 VGPRs as
+// spills and reloads them with four v_accvgpr_read before every use (192 of the 387 instructions of the K loop).
+template <bool AGPR>
 __device__ __forceinline__ void dot_load_q(const char* base, short8 (&qf)[8]) {
-  asm volatile(
-      "global_load_dwordx4 %0, %8, off\n\t"
-      "global_load_dwordx4 %1, %8, off offset:32\n\t"
-      "global_load_dwordx4 %2, %8, off offset:64\n\t"
-      "global_load_dwordx4 %3, %8, off offset:96\n\t"
-      "global_load_dwordx4 %4, %8, off offset:128\n\t"
-      "global_load_dwordx4 %5, %8, off offset:160\n\t"
-      "global_load_dwordx4 %6, %8, off offset:192\n\t"
-      "global_load_dwordx4 %7, %8, off offset:224\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]), "=&v"(qf[4]), "=&v"(qf[5]), "=&v"(qf[6]),
-        "=&v"(qf[7])
-      : "v"(base)
-      : "memory");
+  if constexpr (AGPR) {
+#define MM_C_A(x) "a"(x)
+    MM_DOT_LOADQ(MM_C_A);
+#undef MM_C_A
+  } else {
+#define MM_C_V(x) "v"(x)
+    MM_DOT_LOADQ(MM_C_V);
+#undef MM_C_V
+  }
 }
+#undef MM_DOT_LOADQ
 
 // NSL LDS-DMA instructions: 4 document rows x 256 B of every 128-dim slice -> 1 KiB of LDS each, the
 // slices 8 KiB apart (m0 walks).  The per-slice source offsets come in VGPRs: an instruction offset
@@ -132,11 +147,11 @@ __device__ __forceinline__ void dot_wait() {
 
 template <int DT, int NSL, int NQT, int MODE, bool PROF = false>
 __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
-  constexpr int NBUF = 3;
+  // Ring of TWO blocks (measured: 15.20 ms against 15.33 ms with three — block b + 1 has the whole of block b's MFMA
+  // loop to land), which leaves LDS for the accumulator parking area of the FILTER epilogue (see below).
+  constexpr int NBUF = 2;
   constexpr int RB = NSL * 256;        // bytes per document row
   constexpr int BLK = 32 * RB;         // bytes per 32-document block
-  constexpr int PER = 2 * NSL;         // LDS-DMA instructions per wavefront per block
-  static_assert(PER * (NBUF - 2) <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -162,6 +177,8 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   float* st_score = (float*)(smem + NBUF * BLK) + w * kStageW;            // [4][kStageW]
   int* st_doc = (int*)(smem + NBUF * BLK + 4 * kStageW * 4) + w * kStageW;  // [4][kStageW]
   int* st_q = (int*)(smem + NBUF * BLK + 8 * kStageW * 4) + w * kStageW;    // [4][kStageW]
+  // accumulator parking: [element e = 16 n + i][lane] floats = NQT x 4 KiB per wavefront (FILTER epilogue)
+  char* park = smem + NBUF * BLK + 12 * kStageW * 4 + w * (NQT * 4096);
   int scnt = 0;  // wave-uniform fill level
   auto flush_wave = [&]() {
     for (int i = lane; i < scnt; i += 64) {
@@ -184,7 +201,10 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     qid[n] = qq < a.nq ? qq : -1;
     const char* qrow = (const char*)a.q + (int64_t)(qq < a.nq ? qq : a.nq - 1) * RB + h * 16;
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) dot_load_q(qrow + sl * 256, qf[n][sl]);
+    for (int sl = 0; sl < NSL; ++sl) {
+      if (NSL == 6 && NQT == 2 && n == 1) dot_load_q<true>(qrow + sl * 256, qf[n][sl]);
+      else dot_load_q<false>(qrow + sl * 256, qf[n][sl]);
+    }
   }
   float tau[NQT];
 #pragma unroll
@@ -224,17 +244,15 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   };
   int slot_i = 0;  // ring slot of block `b`
   if (b_lo < b_hi) issue(b_lo, 0);
-  if (b_lo + 1 < b_hi) issue(b_lo + 1, 1);
 
   for (int64_t b = b_lo; b < b_hi; ++b) {
-    // this wavefront's part of block b has landed once at most the younger block's PER loads pend
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if (PROF) t0 = now();
-    if (b + 1 < b_hi) dot_wait<PER>(); else dot_wait<0>();
+    dot_wait<0>();  // this wavefront's part of block b has landed
     if (PROF) t1 = now();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
     if (PROF) t2 = now();
-    if (b + 2 < b_hi) issue(b + 2, slot_i == 0 ? 2 : slot_i - 1);  // into the slot block b - 1 used
+    if (b + 1 < b_hi) issue(b + 1, slot_i ^ 1);  // into the slot block b - 1 used
 
     if (PROF) t3 = now();
     f32x16 acc[NQT];
@@ -257,7 +275,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, NQT, 0);  // NQT MFMAs of step s
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
     }
-    slot_i = slot_i == NBUF - 1 ? 0 : slot_i + 1;
+    slot_i ^= 1;
     if (PROF) {
       // force the accumulators to be complete before the stamp
       float sink = 0.0f;
@@ -285,60 +303,55 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
               if (d0 + 8 * g4 + e < a.ndocs) dst[8 * g4 + e] = acc[n][4 * g4 + e];
       }
     } else {
-      // one flush opportunity per block keeps the per-element code to: compare, scalar branch, and for
-      // the few survivors popcount + mbcnt + three LDS writes (a full private area falls back to the
-      // direct global append: exact, only slow)
+      // Threshold test without a scalar branch per element: every lane collects the elements that pass in a bit mask
+      // (bit e = 16 n + i), the accumulators are parked in LDS ([e][lane]), and the survivors (~5 per wavefront-block at
+      // the working threshold) are filed by a loop in which every lane takes its lowest pending element per round — one
+      // round for 85 % of the blocks.  (One flush opportunity per block; a full private area falls back to the direct
+      // global append: exact, only slow.)
       if (scnt > kStageW / 2) flush_wave();
       const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
-      auto put = [&](int n, int i, unsigned long long bal, bool pass) {
-        if (bal == 0) return;
-        if (pass) {
+      uint32_t pmask = 0;
+#pragma unroll
+      for (int e = 16 * NQT - 1; e >= 0; --e) {   // highest element first: its bit is shifted up by the ones after it
+        const float v = acc[e >> 4][e & 15];
+        *(float*)(park + (e * 64 + lane) * 4) = v;
+        // pmask = 2 pmask + (v >= tau): the compare's lane bit enters as the carry — two instructions per element
+        asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pmask) : "v"(v), "v"(tau[e >> 4]) : "vcc");
+      }
+      if (!whole) {   // wave-uniform, the shard's last block only: documents past the end do not exist
+        uint32_t exist = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) exist |= (d0 + drowof(i) < a.ndocs) ? (0x00010001u << i) : 0u;
+        pmask &= exist;
+      }
+      while (true) {
+        const bool pend = pmask != 0;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pend);
+        if (bal == 0) break;
+        const int e = pend ? (int)__builtin_ctz(pmask) : 0;
+        const float val = *(const float*)(park + (e * 64 + lane) * 4);
+        int qsel = qid[0];
+#pragma unroll
+        for (int n = 1; n < NQT; ++n) qsel = (e >> 4) == n ? qid[n] : qsel;
+        if (pend) {
           const int pos = scnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          const int doc = (int32_t)((d0 + drowof(i)) * a.stride);
+          const int doc = (int32_t)((d0 + drowof(e & 15)) * a.stride);
           if (pos < kStageW) {
-            st_score[pos] = acc[n][i];
+            st_score[pos] = val;
             st_doc[pos] = doc;
-            st_q[pos] = qid[n];
+            st_q[pos] = qsel;
           } else {
-            const int slot = atomicAdd(a.count + qid[n], 1);
+            const int slot = atomicAdd(a.count + qsel, 1);
             if ((unsigned)slot < (unsigned)a.cap) {
-              a.cand_score[(int64_t)qid[n] * a.cap + slot] = acc[n][i];
-              a.cand_idx[(int64_t)qid[n] * a.cap + slot] = doc;
+              a.cand_score[(int64_t)qsel * a.cap + slot] = val;
+              a.cand_idx[(int64_t)qsel * a.cap + slot] = doc;
             }
           }
         }
         const int np = scnt + __builtin_popcountll(bal);
         scnt = np < kStageW ? np : kStageW;
-      };
-      // all compares of a tile first (each v_cmp leaves its ballot in an SGPR pair), then the scalar
-      // tests: a compare immediately followed by a branch on its result pays the VALU->SALU hazard
-      // and a taken-branch bubble per element (2.5 k cycles per block in the first version)
-      auto tiles = [&](auto whole_c) {
-        constexpr bool W = decltype(whole_c)::value;
-#pragma unroll
-        for (int n = 0; n < NQT; ++n) {
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {  // 8 elements at a time: 8 SGPR pairs + 8 VGPR copies live
-            unsigned long long bal[8];
-            bool pass[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const int i = 8 * half + e;
-              pass[e] = acc[n][i] >= tau[n];
-              if (!W) pass[e] = pass[e] && (d0 + drowof(i) < a.ndocs);
-              bal[e] = __builtin_amdgcn_ballot_w64(pass[e]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long any = 0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) any |= bal[e];
-            if (any == 0) continue;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) put(n, 8 * half + e, bal[e], pass[e]);
-          }
-        }
-      };
-      if (whole) tiles(std::true_type{}); else tiles(std::false_type{});
+        pmask &= pmask - 1;
+      }
     }
     if (PROF) tp[4] += now() - t4;
   }
@@ -481,7 +494,7 @@ template <int DT, int NSL, int NQT, int MODE>
 static int launch_dot(const DotArgs& a0, int nq_launch, int T, hipStream_t stream) {
   DotArgs a = a0;
   constexpr int QPW = 128 * NQT;  // queries per workgroup
-  const int lds = 3 * 32 * NSL * 256 + 4 * kStageW * 12;
+  const int lds = 2 * 32 * NSL * 256 + 4 * kStageW * 12 + 4 * NQT * 4096;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dot_stream_kernel<DT, NSL, NQT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (31.0 * (double)a.stride * (NSL * 256) >= 4294967296.0)
