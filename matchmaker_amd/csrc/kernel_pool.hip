@@ -457,12 +457,16 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
 #pragma unroll
         for (int p = 0; p < kSplitSteps; ++p) {
           split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
+          qhi[s][p] = to_agpr(qhi[s][p]);
+          qlo[s][p] = to_agpr(qlo[s][p]);
           ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
         }
         if (h == 0) ss += sumsq4(raw[12]);  // both halves loaded the parked chunk: count it once
         if (h == (s >> 1)) park[s & 1] = raw[12];
       }
       split8(park[0], park[1], qhiL, qloL);
+      qhiL = to_agpr(qhiL);
+      qloL = to_agpr(qloL);
       ss += __shfl_xor(ss, 32, 64);
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
       const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
@@ -804,12 +808,16 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
 #pragma unroll
         for (int p = 0; p < kSplitSteps; ++p) {
           split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
+          qhi[s][p] = to_agpr(qhi[s][p]);
+          qlo[s][p] = to_agpr(qlo[s][p]);
           ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
         }
         if (h == 0) ss += sumsq4(raw[12]);
         if (h == (s >> 1)) park[s & 1] = raw[12];
       }
       split8(park[0], park[1], qhiL, qloL);
+      qhiL = to_agpr(qhiL);
+      qloL = to_agpr(qloL);
       ss += __shfl_xor(ss, 32, 64);
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
       if (a.qm.len) {

@@ -342,6 +342,15 @@ __device__ __forceinline__ void split8x3(const f32x4& x0, const f32x4& x1, bf16x
 __device__ __forceinline__ float sumsq4(const f32x4& v) { return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
 
 
+// Pin a fragment in accumulator registers: the MFMA reads its B operand from AGPRs directly.  Left to itself the
+// register allocator keeps query fragments in VGPRs, runs out, spills the overflow to AGPRs and reloads it with four
+// v_accvgpr_read before every use (dot_topk.hip: 192 of 387 instructions of the K loop).
+__device__ __forceinline__ bf16x8 to_agpr(bf16x8 v) {
+  bf16x8 r;
+  asm volatile("" : "=a"(r) : "0"(v));
+  return r;
+}
+
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
