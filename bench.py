@@ -22,6 +22,10 @@ replicated per pair, HF int64 masks — what eval.py:108 hands to ColBERT.forwar
 configs on this GPU (`tk` configs[0] shapes at scale, `tkl` configs[2], `dot_topk` one rank's shard of
 configs[4]), each with its own roofline fraction, CPU leg and the rocprof summary it can be checked against.
 
+`--only <leg>` runs ONE leg (headline | dropin_forward | published_checkpoint | all_pairs | tk | tkl | dot_topk |
+maxsim_fp32 | eval_batch) and prints it alone: the command tools/profile_round.sh puts under `rocprofv3 --kernel-trace`, so
+that every fraction in the line can be re-derived from a profile of the very code that produced it.
+
 `--dry` (with `--backend gloo --device cpu`) exercises ONLY the launch + collective plumbing on a machine
 without GPUs (tests/test_bench_launch_cpu.py): scores are fabricated, `value` is null — never a measurement.
 """
@@ -205,7 +209,7 @@ def extra_dropin_forward(q, d, q_len, d_len, steps):
             "dtype": "bf16", "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
             "bytes_per_pair": by // B, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                     "frac": gbs / HBM_PEAK_GBS},
-            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r02_dropin_pmc.json"}
+            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r03_dropin_pmc.json"}
 
 
 def extra_sustained(score_shard, B, seconds=4.0):
@@ -265,7 +269,7 @@ def extra_tk(steps, cpu_budget):
            "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms,
            "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by, "flop": B * (2 * Qt * Dt * Et + 2 * (Qt + Dt) * Et),
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r02_tk_pmc.json"}
+           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r03_tk_pmc.json"}
     del q, d
     torch.cuda.empty_cache()
     try:
@@ -335,7 +339,11 @@ def extra_tkl(steps, cpu_budget):
            "dtype": "fp32 (split-bf16 operands)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
            "kernel": "tkl_stage1_run_kernel + tkl_window_kernel + tkl_region_kernel (whole mm_tkl_fwd call)",
-           "profile": "profiles/r02_tkl_pmc.json"}
+           "profile": "profiles/r03_tklragged_pmc.json"}
+    try:
+        out["exact_f32_mfma"] = tkl_exact_f32_subprocess()
+    except Exception as e:
+        out["exact_f32_mfma"] = {"error": repr(e)}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         n = 4
@@ -376,6 +384,121 @@ def extra_tkl(steps, cpu_budget):
     return out
 
 
+def tkl_exact_f32_subprocess():
+    """TKL with stage 1 on the exact-f32 MFMA kernel (MM_KP_F32MFMA=1 is read once per process -> a child process):
+    the reference's own operand precision (tkl.yaml use_fp16: False) beside the split-bf16 default."""
+    env = dict(os.environ, MM_KP_F32MFMA="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_tkl.py"), "--steps", "5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            j = json.loads(line)
+            return {"kernel": "stage 1 = kernel_pool_stream_kernel<TKL> (v_mfma_f32_32x32x2_f32, exact fp32 operands), stages 2-3 unchanged",
+                    "ms": j["ms"], "docs_per_s": j["docs_per_s"], "GBps": j["GBps_algorithmic"],
+                    "frac": j["GBps_algorithmic"] / HBM_PEAK_GBS}
+    return {"error": (r.stderr or r.stdout)[-300:]}
+
+
+def extra_maxsim_fp32(steps, cpu_budget):
+    """The "fp32 variant" of BASELINE.json configs[1]: ColBERT with use_fp16: False (colbert.py:60 without autocast) —
+    fp32 token vectors, Q=32 / D=180 / dim=128, 1000 candidates per query, on the three-term split-bf16 kernel."""
+    import torch
+    from matchmaker_amd import ops, synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nq = 64
+    q, d, q_len, d_len = synth.colbert_batch(nq, CANDS, Q, D, E, torch.float32, dev, seed=3232, lengths="full")
+    B = nq * CANDS
+    fn = lambda: ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
+    ms = gpu_time_ms(fn, steps)
+    by = B * D * E * 4 + nq * Q * E * 4 + 4 * (B + nq) + 4 * B
+    gbs = by / (ms * 1e-3) / 1e9
+    out = {"workload": f"ColBERT MaxSim, fp32 vectors (use_fp16: False), {nq} queries x {CANDS} candidates, Q={Q}/D={D}/dim={E}, "
+                       f"shared query tile, int32 lengths, all positions real",
+           "dtype": "fp32 (three-term split-bf16 operands x = hi + lo + c, 6 bf16 MFMAs per K step, fp32 accumulation)",
+           "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+           "kernel": "kernel_pool_split128_kernel<MX> (csrc/kernel_pool128.hip)", "profile": "profiles/r03_maxsimfp32_trace.json"}
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        n = 1000
+        qc = q[:1].cpu().expand(n, -1, -1).contiguous()
+        dc = d[:n].cpu()
+        qm, dm = torch.ones(n, Q, dtype=torch.long), torch.ones(n, D, dtype=torch.long)
+
+        def run():
+            with torch.no_grad():
+                TP.maxsim_forward(qc, dc, qm, dm)
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: run, cpu_budget, n)
+        out["cpu_baseline"] = {"value": ra, "unit": "pairs/s", "cores": threads, "kind": "port", "single_thread_value": r1,
+                               "sample": f"{n}-pair forward calls (oracle/torch_port.maxsim_forward, fp32), {na} calls in {ta:.1f} s"}
+    return out
+
+
+def extra_eval_batch(steps, cpu_budget):
+    """eval.py-sized calls: `batch_size_eval: 512` pairs per model.forward (config/train/defaults.yaml:115, eval.py:108),
+    pair-per-row, in the layouts the reference hands over.  Per shape: device time per call (HIP events), wall time per
+    call completed (back-to-back calls, one sync at the end), host time per call ISSUED (the Python + ctypes + launch
+    path, GPU running behind), and the HBM fraction of the completed rate.  The calls rotate through enough distinct
+    batches to exceed the 256 MB Infinity Cache, so every call streams from HBM as in a real evaluation run."""
+    import torch
+    from matchmaker_amd import ops
+    from matchmaker_amd.colbert import ColBERT
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Bc = 512
+    g = torch.Generator(device=dev).manual_seed(512)
+    res = {}
+
+    def run(name, n_batches, make, call, bytes_per_call, n_calls=400):
+        batches = [make() for _ in range(n_batches)]
+        for b in batches:
+            call(b)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+        for i, (a, b) in enumerate(ev):
+            a.record(); call(batches[i % n_batches]); b.record()
+        torch.cuda.synchronize()
+        dev_us = 1e3 * sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+        t0 = time.perf_counter()
+        for i in range(n_calls):
+            call(batches[i % n_batches])
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_done = time.perf_counter() - t0
+        us_done, us_host = 1e6 * t_done / n_calls, 1e6 * t_issue / n_calls
+        gbs = bytes_per_call / (us_done * 1e-6) / 1e9
+        gbs_dev = bytes_per_call / (dev_us * 1e-6) / 1e9
+        res[name] = {"pairs_per_call": Bc, "distinct_batches": n_batches, "bytes_per_call": bytes_per_call,
+                     "us_per_call_device": dev_us, "us_per_call_completed": us_done, "us_per_call_host_issue": us_host,
+                     "pairs_per_s": Bc / (us_done * 1e-6),
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                  "frac_device_time_only": gbs_dev / HBM_PEAK_GBS}}
+        del batches
+        torch.cuda.empty_cache()
+
+    def colbert_batch_maker(Qc, Dc, Ec, dt):
+        def make():
+            q = (torch.randn(Bc, Qc, Ec, generator=g, device=dev) / Ec ** 0.5).to(dt)
+            d = (torch.randn(Bc, Dc, Ec, generator=g, device=dev) / Ec ** 0.5).to(dt)
+            return q, d, torch.ones(Bc, Qc, dtype=torch.long, device=dev), torch.ones(Bc, Dc, dtype=torch.long, device=dev)
+        return make
+
+    run("colbert_dim128_bf16", 16, colbert_batch_maker(Q, D, E, torch.bfloat16), lambda b: ColBERT._score(*b),
+        Bc * ((D + Q) * E * 2 + 8 * (D + Q) + 4))
+    run("colbert_published_dim768_fp16", 3, colbert_batch_maker(38, 200, 768, torch.float16), lambda b: ColBERT._score(*b),
+        Bc * ((200 + 38) * 768 * 2 + 8 * (200 + 38) + 4))
+    prm = [torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev), torch.ones(11, device=dev),
+           torch.linspace(-0.014, 0.014, 11, device=dev)]
+
+    def tk_make():
+        return (torch.randn(Bc, 20, 300, generator=g, device=dev), torch.randn(Bc, 200, 300, generator=g, device=dev),
+                torch.ones(Bc, 20, device=dev), torch.ones(Bc, 200, device=dev))
+    run("tk_dim300_fp32", 4, tk_make, lambda b: ops.kernel_pool(b[0], b[1], b[2], b[3], *prm, pairs_per_query=1),
+        Bc * ((200 + 20) * 300 * 4 + 4 * (200 + 20) + 4))
+    return {"workload": "512 pairs per call (defaults.yaml:115 batch_size_eval), pair-per-row, int64 HF masks (ColBERT) / float masks (TK); "
+                        "config-2 shapes, the published checkpoint's shapes (Q=38 / D=200 / dim=768 fp16), TK Q=20 / D=200 / dim=300",
+            "shapes": res}
+
+
 def extra_published_checkpoint(steps, cpu_budget):
     """The configuration of the reference's PUBLISHED ColBERT checkpoint (config/huggingface_modelhub/sebastian-hofstaetter/
     colbert-distilbert-margin_mse-T2-msmarco.yaml: colbert_compression_dim 768, max_query_length 30 +
@@ -396,7 +519,7 @@ def extra_published_checkpoint(steps, cpu_budget):
            "dtype": "f16", "ms": ms, "pairs_per_s": n / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
            "kernel": "pack_mask_kernel + maxsim_stream_kernel with two query tiles (NSL = 6, NQT = 2)",
-           "profile": "profiles/r02_published_pmc.json"}
+           "profile": "profiles/r03_published_pmc.json"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         m = 256
@@ -434,7 +557,7 @@ def extra_all_pairs(steps, cpu_budget):
            "dtype": "bf16", "ms": ms, "pairs_per_s": Bq * Bd / t, "flop": flop,
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
-           "kernel": "maxsim_allpairs_tiled_kernel: 4 queries per wavefront", "profile": "profiles/r02_allpairs_pmc.json"}
+           "kernel": "maxsim_allpairs_tiled_kernel: 4 queries per wavefront", "profile": "profiles/r03_allpairs_pmc.json"}
     t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
     out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
     if cpu_budget > 0:
@@ -479,7 +602,7 @@ def extra_dot_topk(steps, cpu_budget):
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
            "kernel": "dot_stream_kernel (sample + filter) + sample_tau_kernel + topk_rows_kernel (whole mm_dot_topk_fwd call, wall clock)",
-           "profile": "profiles/r02_dot_pmc.json"}
+           "profile": "profiles/r03_dot_pmc.json"}
     if cpu_budget > 0:
         nqc, nc = 64, 1 << 16
         qc, cc = q[:nqc].float().cpu(), c[:nc].float().cpu()
@@ -494,6 +617,10 @@ def extra_dot_topk(steps, cpu_budget):
                                          f"definition; faiss is absent here), {na} calls in {ta:.1f} s ({threads} threads) / {n1} in "
                                          f"{t1:.1f} s (1 thread)"}
     return out
+
+
+LEGS = (("eval_batch", extra_eval_batch), ("maxsim_fp32", extra_maxsim_fp32), ("published_checkpoint", extra_published_checkpoint),
+        ("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk))
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -512,6 +639,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the per-step all-gather even with one rank (exercises the "
                          "RCCL path on a single-GPU box)")
+    ap.add_argument("--only", default=None,
+                    choices=["headline", "dropin_forward", "published_checkpoint", "all_pairs", "tk", "tkl", "dot_topk",
+                             "maxsim_fp32", "eval_batch"],
+                    help="run ONE leg and print it alone (the command that is put under rocprofv3 --kernel-trace)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses device 0 (RCCL test of the N > 1 path on a single-GPU box; RCCL may refuse it)")
     ap.add_argument("--dry", action="store_true",
                     help="launch + collective plumbing only (fabricated scores, value = null); for GPU-less machines")
     args = ap.parse_args()
@@ -532,10 +665,24 @@ def main():
     backend = args.backend or ("gloo" if args.device == "cpu" else "nccl")
     if args.device == "cuda":
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", 0 if args.one_device else local_rank)
         torch.cuda.set_device(dev)
     else:
         dev = torch.device("cpu")
+    if args.only and args.only != "headline":
+        assert world == 1 and dev.type == "cuda", "--only legs are single-GPU measurements"
+        from matchmaker_amd import _lib
+        _lib.lib()
+        cpu_b = 0.0 if args.no_cpu_baseline else 3.0
+        legs = dict(LEGS)
+        if args.only == "dropin_forward":
+            from matchmaker_amd import synth
+            q, d, q_len, d_len = synth.colbert_batch(args.queries, CANDS, Q, D, E, torch.bfloat16, dev, seed=4004, lengths=args.lengths)
+            res = extra_dropin_forward(q, d, q_len, d_len, max(5, args.steps // 2))
+        else:
+            res = legs[args.only](3 if args.only == "dot_topk" else max(args.steps // 2, 5), cpu_b)
+        print(json.dumps({"only": args.only, "result": res}), flush=True)
+        return
     use_dist = world > 1 or args.force_dist
     if use_dist:
         # the GPU boxes export NCCL_DEBUG=VERSION and RCCL prints to STDOUT (its banner would follow the JSON line, once
@@ -594,6 +741,9 @@ def main():
     t = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if use_ev else None
 
+    gather_matches = None
+    if use_dist and not args.dry:      # the gathered tensor's slice of this rank must BE its local scores
+        gather_matches = bool(torch.equal(gathered[rank * B:(rank + 1) * B], s))
     tt = torch.tensor([t], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -615,7 +765,9 @@ def main():
                     ver = "unknown"
             coll = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "version": ver, "world_size": world,
                     "op": "all_gather_into_tensor of fp32 scores, once per step, inside the timed region",
-                    "bytes_per_rank": 4 * B, "bytes_total": 4 * B * world}
+                    "bytes_per_rank": 4 * B, "bytes_total": 4 * B * world,
+                    "gathered_slice_equals_local_scores": gather_matches,
+                    "devices": "all ranks on device 0 (--one-device)" if args.one_device else "one device per rank"}
         out = {
             "metric": "query-doc pairs scored/sec (ColBERT MaxSim, Q32/D180/dim128)",
             "value": None if args.dry else total_pairs / t, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -633,6 +785,25 @@ def main():
             out["note"] = "launch/collective plumbing check only: scores fabricated, nothing measured"
             out["all_gather_verified"] = gather_ok
         else:
+            # the timed scores themselves, checked in-process against the oracle on one sampled query (checker only)
+            try:
+                import numpy as np
+                from oracle import np_oracle as O
+                from matchmaker_amd import synth as _synth
+                qi = nq // 2
+                got = s[qi * CANDS:(qi + 1) * CANDS].float().cpu().numpy()
+                ref = O.maxsim_paired(np.repeat(q[qi:qi + 1].float().cpu().numpy(), CANDS, axis=0),
+                                      d[qi * CANDS:(qi + 1) * CANDS].float().cpu().numpy(),
+                                      _synth.len_to_mask(q_len[qi:qi + 1].cpu(), Q).numpy().repeat(CANDS, axis=0),
+                                      _synth.len_to_mask(d_len[qi * CANDS:(qi + 1) * CANDS].cpu(), D).numpy())
+                err = float(np.abs(got - ref).max())
+                out["self_check"] = {"query": qi, "pairs": CANDS, "max_abs_err_vs_oracle": err, "tolerance": 1e-2,
+                                     "ok": bool(err <= 1e-2),
+                                     "same_order_as_oracle": bool((np.argsort(-got, kind="stable") == np.argsort(-ref, kind="stable")).mean() > 0.99)}
+                if err > 1e-2:
+                    out["value"] = None      # a fast kernel whose results differ from the reference's is not a measurement
+            except Exception as e:
+                out["self_check"] = {"error": repr(e)}
             ab = algorithmic_bytes(nq, CANDS)
             achieved = ab / (kern_ms * 1e-3) / 1e9
             flop = 2.0 * B * Q * D * E
@@ -668,7 +839,7 @@ def main():
                         extra["dropin_forward"] = {"error": repr(e)}
                     del q, d
                     torch.cuda.empty_cache()
-                    for name, fn in (("published_checkpoint", extra_published_checkpoint), ("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk)):
+                    for name, fn in LEGS:
                         try:
                             extra[name] = fn(3 if name == "dot_topk" else 10, cpu_b)
                         except Exception as e:

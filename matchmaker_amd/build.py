@@ -53,7 +53,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as ex:
             list(ex.map(compile_one, todo))
     objs = [_obj(s) for s in srcs]
-    if force or todo or _newer(LIB, objs):
+    relink = bool(force or todo or _newer(LIB, objs))
+    # unambiguous in the build log: the objects / .so are git-ignored but ship with the snapshot, so whether a
+    # call compiled anything depends on mtimes
+    print(f"[matchmaker_amd.build] recompiled {len(todo)} of {len(srcs)} TUs"
+          + (f" ({', '.join(os.path.basename(t) for t in todo)})" if todo and len(todo) < len(srcs) else "")
+          + f"; {'relinked' if relink else 'kept'} {os.path.relpath(LIB, os.path.join(HERE, '..'))}"
+          + (" [--force]" if force else ""), flush=True)
+    if relink:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print("[matchmaker_amd.build]", " ".join(cmd), flush=True)

@@ -386,6 +386,7 @@ extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* ch
                           float* grad_q, float* grad_chunks, float* grad_params, int64_t B, int64_t P, int C, int Q, int E,
                           int K, int saturation, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0) return MM_OK;  // an empty batch has empty gradients (as the other operators: nothing to launch)
   if (!q_ctx || !q_mask || !params || !win_scores || !grad_out || !grad_q || !grad_params)
     return set_error(MM_EINVAL, "tkl_bwd: null pointer");
   if (P > 0 && (!chunks || !chunk_mask || !chunk_slot || !grad_chunks)) return set_error(MM_EINVAL, "tkl_bwd: null chunk pointer");

@@ -112,8 +112,24 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
     return out
 
 
+def _check_ranges(doc_begin: torch.Tensor, doc_end: torch.Tensor, n_rows: int):
+    """A stale doc_infos range (another store's, or past the token matrix) would make the LDS-DMA stream read out of
+    bounds silently.  A device reduction + one blocking D2H read: callers that validated their ranges when they built
+    them (token_store.TokenStore does, on the host copy of doc_infos) pass check_ranges=False and keep the launch
+    stream free of synchronisation."""
+    if torch.cuda.is_current_stream_capturing():
+        raise NativeError("maxsim_ragged: range validation needs a D2H read; validate outside graph capture and pass "
+                          "check_ranges=False")
+    lo, hi = int(doc_begin.min()), int(torch.maximum(doc_begin, doc_end).max())
+    bad = int((doc_begin > doc_end).sum())
+    if lo < 0 or hi > n_rows or bad:
+        raise NativeError(f"maxsim_ragged: document ranges [{lo}, {hi}) leave the {n_rows}-row token matrix"
+                          + (f" ({bad} ranges have begin > end)" if bad else ""))
+
+
 def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor, doc_end: torch.Tensor,
-                  q_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1) -> torch.Tensor:
+                  q_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1,
+                  check_ranges: bool = True) -> torch.Tensor:
     """Unpadded MaxSim over a resident token store (the ColBERT retrieval aggregate,
     matchmaker/dense_retrieval.py:398-412 + colbert.py:100-112, in ONE launch).
 
@@ -142,12 +158,8 @@ def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor
     out = torch.empty(B, dtype=torch.float32, device=dev)
     if B == 0:
         return out
-    if not torch.cuda.is_current_stream_capturing():
-        # a stale doc_infos range (another store's, or past the token matrix) would make the LDS-DMA stream read
-        # out of bounds silently: one small D2H per call, skipped under graph capture
-        lo, hi = int(doc_begin.min()), int(torch.maximum(doc_begin, doc_end).max())
-        if lo < 0 or hi > tokens.shape[0]:
-            raise NativeError(f"maxsim_ragged: document ranges [{lo}, {hi}) leave the {tokens.shape[0]}-row token matrix")
+    if check_ranges:
+        _check_ranges(doc_begin, doc_end, tokens.shape[0])
     with torch.cuda.device(dev):
         wsb = L.mm_maxsim_ragged_workspace_bytes(B, pairs_per_query, Q, qk)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
@@ -447,6 +459,8 @@ def tkl_bwd(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor,
     gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
     gc = torch.empty((P, 50, E), dtype=torch.float32, device=dev)
     gp = torch.empty((B, NP), dtype=torch.float32, device=dev)
+    if B == 0:
+        return gq, gc.zero_(), torch.zeros(NP, dtype=torch.float32, device=dev)
     L = _lib.lib()
     with torch.cuda.device(dev):
         wsb = L.mm_tkl_bwd_workspace_bytes(B, C)

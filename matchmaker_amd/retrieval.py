@@ -34,13 +34,15 @@ class FlatIPIndexer:
         self._topk = topk_fn if topk_fn is not None else ops.dot_topk
         self._merge = merge_fn if merge_fn is not None else ops.topk_merge
         self.token_dim = config["token_dim"]
-        self.use_fp16 = config.get("faiss_use_fp16", True)
+        # base_index.py:14 derives fp16 storage from config["token_dtype"] == "float16"; `faiss_use_fp16` (not a reference
+        # key) is kept as an explicit override only
+        self.use_fp16 = config.get("faiss_use_fp16", config.get("token_dtype", "float16") == "float16")
         if not self.use_fp16:
             # faiss keeps fp32 vectors AND fp32 queries when useFloat16 is off (faiss_indices.py:58-61); this index
             # stores fp16 vectors and rounds the queries to fp16 as well, so near-tie rankings could differ from
             # an fp32 IndexFlatIP.  Refuse instead of silently changing the arithmetic.
-            raise ops.NativeError("FlatIPIndexer stores float16 vectors and rounds queries to float16 (faiss "
-                                  "useFloat16 semantics): set faiss_use_fp16: True, or keep faiss for an fp32 index")
+            raise ops.NativeError("FlatIPIndexer stores float16 vectors and rounds queries to float16 (faiss useFloat16 "
+                                  "semantics): set token_dtype: float16 (base_index.py:14), or keep faiss for an fp32 index")
         self.dtype = torch.float16
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())  # noqa: E501
         self.group = group

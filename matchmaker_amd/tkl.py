@@ -232,6 +232,10 @@ class TKL_sigir20(nn.Module):
         sizes = [(o_dense, K, K), (o_km, K, self.kernel_mult.numel()),
                  (o_sat + 0, 2, 2), (o_sat + 2, 1, 1), (o_sat + 3, 2, 2), (o_sat + 5, 1, 1), (o_sat + 6, 2, 2), (o_sat + 8, 1, 1),
                  (o_sat + 9, 2, 2), (o_sat + 11, 2, 2), (o_cs, 15, 15), (o_emb, E, E)]
+        # parameters the active saturation never reads keep .grad = None as in the reference (optimizers skip them, DDP's
+        # unused-parameter bookkeeping matches): kernel_mult under "embedding", the saturation layers under "log"
+        live = {id(p) for p in self._scoring_parameters()}
+        sizes = [n if id(t) in live else None for t, n in zip(scoring, sizes)]
         return scoring, sizes
 
     def _scoring_parameters(self):

@@ -29,6 +29,10 @@ class TokenStore:
         self._index = {s: i for i, s in enumerate(self.seq_ids)}
         self._begin = np.asarray(begin, dtype=np.int64)   # global row ranges per document
         self._end = np.asarray(end, dtype=np.int64)
+        # validated once, on the host copy of doc_infos: the scoring calls then skip the per-call device check
+        if self._begin.size and (self._begin.min() < 0 or self._end.max() > tokens.shape[0] or (self._begin > self._end).any()):
+            raise ops.NativeError(f"TokenStore: document ranges leave the {tokens.shape[0]}-row token matrix "
+                                  "(doc_infos of another store?)")
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -93,7 +97,7 @@ class TokenStore:
             bb[i, :n], ee[i, :n] = b[off: off + n], e[off: off + n]
             off += n
         q = query_vecs.to(self.tokens.dtype)
-        scores = ops.maxsim_ragged(q, self.tokens, bb.view(-1), ee.view(-1), None, pairs_per_query=C).view(nq, C)
+        scores = ops.maxsim_ragged(q, self.tokens, bb.view(-1), ee.view(-1), None, pairs_per_query=C, check_ranges=False).view(nq, C)
         scores = scores.cpu()
         return [[(candidates[i][j], float(scores[i, j])) for j in range(counts[i])] for i in range(nq)]
 

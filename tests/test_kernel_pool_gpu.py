@@ -76,7 +76,7 @@ def test_kernel_pool_random(Q, D, E, ppq, nq):
 
 def test_kernel_pool_config1_scale_properties():
     """Config-1 shapes at batch scale (1000 candidates): determinism, permutation equivariance, and
-    invariance to positive rescaling of any token vector (cosine)."""
+    invariance to positive rescaling of any token vector (cosine), and all 2,000 pairs against the fp64 oracle."""
     from matchmaker_amd import ops
     dev = util.require_gpu()
     g = torch.Generator(device=dev).manual_seed(9)
@@ -94,13 +94,17 @@ def test_kernel_pool_config1_scale_properties():
     assert torch.equal(outp, out[perm])
     outs = ops.kernel_pool(q * 4.0, d * 0.5, q_len, d_len, *p, pairs_per_query=C)   # powers of two: exact
     assert torch.equal(outs, out)
-    # sampled oracle check
-    sel = torch.tensor([0, 1, 499, 999, 1000, 1999])
-    ref = O.tk_kernel_pool(q.cpu().numpy()[sel.numpy() // C], d[sel.to(dev)].cpu().numpy(),
-                           (np.arange(Q)[None] < q_len.cpu().numpy()[sel.numpy() // C][:, None]),
-                           (np.arange(D)[None] < d_len[sel.to(dev)].cpu().numpy()[:, None]),
-                           MU, SIGMA, p[2].cpu().numpy(), p[3].cpu().numpy(), dtype=np.float64)
-    np.testing.assert_allclose(out[sel.to(dev)].cpu().numpy(), ref, atol=util.TOL_FP32)
+    # EVERY pair against the fp64 evaluation of ecai20_tk.py:105-124 (torch port on CPU tensors, one candidate list per call)
+    from oracle import torch_port as TP
+    f = lambda t: t.detach().cpu().double()
+    for i in range(nq):
+        sl = slice(i * C, (i + 1) * C)
+        qm = (torch.arange(Q)[None] < int(q_len[i])).double().expand(C, -1).contiguous()
+        dm = (torch.arange(D)[None] < d_len[sl].cpu()[:, None]).double()
+        with torch.no_grad():
+            ref = TP.tk_kernel_pool(f(q[i:i + 1]).expand(C, -1, -1).contiguous(), f(d[sl]), qm, dm, f(p[0]).view(1, 1, 1, -1),
+                                    f(p[1]).view(1, 1, 1, -1), f(p[2]).view(1, 1, -1), f(p[3]).view(1, -1)).numpy()
+        np.testing.assert_allclose(out[sl].cpu().numpy(), ref, atol=util.TOL_FP32)
 
 
 @pytest.mark.parametrize("B,Q,D,E", [(4, 20, 200, 300), (3, 30, 47, 64), (2, 5, 3, 8), (3, 33, 70, 128),

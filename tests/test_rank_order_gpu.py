@@ -19,6 +19,7 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 KS = (1, 10, 100, 1000)
+MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
 
 
 def _oracle_query(qn, dn, qm, dm, split=False):
@@ -138,3 +139,188 @@ def test_rank_order_through_colbert_forward_as_eval_drives_it(use_fp16):
         assert ranked[f"q{i}"] == [f"d{i * C + j}" for j in np.argsort(-got, kind="stable")]
     frac = util.rank_report(f"colbert_forward_{'fp16' if use_fp16 else 'fp32'}", rows)
     assert frac >= 0.99
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# TK / TKL: "identical top-k rank order versus the reference" for the kernel-pooling models
+# (core_metrics.py:502-511 over the scores of ecai20_tk.py:105-124 / sigir20_tkl.py:254-286).
+# The fp32 / fp64 oracles are oracle/torch_port.py on CPU tensors (the reference's own torch statements; pinned on
+# the golden vectors) — multi-threaded, so every pair / document of the lists below is compared, not a sample.
+# ---------------------------------------------------------------------------------------------------------------
+def _tk_lists(nq, C, Q, D, E, seed):
+    """MSMARCO-ish lists: query lengths U{3..Q}, passage lengths N(70, 25) clipped to [8, D]; half of the candidates
+    carry planted exact copies of query tokens (cos = 1 -> the mu = 1.0 kernel), a quarter near matches."""
+    from matchmaker_amd import synth
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(nq, Q, E, generator=g)
+    d = torch.randn(nq * C, D, E, generator=g)
+    q_len = torch.randint(3, Q + 1, (nq,), generator=g).to(torch.int32)
+    d_len = synth.msmarco_doc_lengths(nq * C, D, g).to(torch.int32)
+    kind = torch.randint(0, 4, (nq * C,), generator=g)                 # 0, 1: exact; 2: near; 3: none
+    n_plant = torch.randint(1, 4, (nq * C,), generator=g)
+    for p in range(nq * C):
+        if kind[p] == 3:
+            continue
+        i = p // C
+        for _ in range(int(n_plant[p])):
+            tq = int(torch.randint(0, int(q_len[i]), (1,), generator=g))
+            td = int(torch.randint(0, int(d_len[p]), (1,), generator=g))
+            v = q[i, tq] * (0.5 + float(torch.rand(1, generator=g)))                   # any positive scale: same cosine
+            d[p, td] = v if kind[p] < 2 else v + 0.35 * torch.randn(E, generator=g)
+    return q, d, q_len, d_len
+
+
+def _tk_oracles(q, d, q_len, d_len, C, alpha, w):
+    """(fp32, fp64) scores of every pair through the torch port of ecai20_tk.py:105-124, one candidate list per call."""
+    from oracle import torch_port as TP
+    nq, Q, _ = q.shape
+    D = d.shape[1]
+    o32, o64 = [], []
+    for i in range(nq):
+        qm = (torch.arange(Q)[None] < q_len[i]).float().expand(C, -1).contiguous()
+        dm = (torch.arange(D)[None] < d_len[i * C:(i + 1) * C, None]).float()
+        for dt, dst in ((torch.float32, o32), (torch.float64, o64)):
+            f = lambda t: t.to(dt)
+            with torch.no_grad():
+                dst.append(TP.tk_kernel_pool(f(q[i:i + 1]).expand(C, -1, -1).contiguous(), f(d[i * C:(i + 1) * C]), f(qm), f(dm),
+                                             f(torch.tensor(MU)).view(1, 1, 1, -1), f(torch.full((11,), 0.1)).view(1, 1, 1, -1),
+                                             f(alpha).view(1, 1, -1), f(w).view(1, -1)).numpy())
+    return np.concatenate(o32), np.concatenate(o64)
+
+
+def run_tk_rank(name, nq=16, C=1000):
+    """Also the entry point of the MM_KP_F32MFMA=1 child process (the switch is read once per process)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    Q, D, E = 20, 200, 300
+    q, d, q_len, d_len = _tk_lists(nq, C, Q, D, E, seed=2020)
+    alpha = torch.ones(11)
+    w = torch.linspace(-0.014, 0.014, 11)
+    mu, sg = torch.tensor(MU), torch.full((11,), 0.1)
+    out = ops.kernel_pool(q.to(dev), d.to(dev), q_len.to(dev), d_len.to(dev), mu.to(dev), sg.to(dev), alpha.to(dev), w.to(dev),
+                          pairs_per_query=C).cpu().numpy()
+    # the drop-in's layout (query replicated per pair, float masks) must give the same scores
+    sel = slice(0, 2 * C)
+    qm = (torch.arange(Q)[None] < q_len[:2, None]).float().repeat_interleave(C, 0)
+    dm = (torch.arange(D)[None] < d_len[sel, None]).float()
+    out_pp = ops.kernel_pool(q[:2].repeat_interleave(C, 0).contiguous().to(dev), d[sel].to(dev), qm.to(dev), dm.to(dev), mu.to(dev),
+                             sg.to(dev), alpha.to(dev), w.to(dev), pairs_per_query=1).cpu().numpy()
+    np.testing.assert_allclose(out_pp, out[sel], atol=2e-6, rtol=0)
+    r32, r64 = _tk_oracles(q, d, q_len, d_len, C, alpha, w)
+    np.testing.assert_allclose(out, r64, atol=util.TOL_FP32)               # every pair, not a sample
+    rows = []
+    for i in range(nq):
+        sl = slice(i * C, (i + 1) * C)
+        a = float(np.abs(out[sl] - r64[sl]).max())
+        b = float(np.abs(r32[sl] - r64[sl]).max())
+        # the device is an fp32-class evaluation of the same sums: its error is bounded against the reference's own
+        # fp32 error (x16: split-bf16 operands carry 2^-17, the exact-f32 kernel stays near 1x), and the tie policy
+        # uses whichever is larger
+        assert a <= 16 * b + 1e-6, f"{name} query {i}: device {a:.3e} vs fp32 oracle {b:.3e} away from the fp64 scores"
+        rows.append(util.rank_parity(out[sl], r32[sl], r64[sl], KS, noise=2.0 * max(a, b), label=f"{name} query {i}"))
+        rows[-1]["err_ref"] = b
+    frac = util.rank_report(name, rows)
+    print(f"[rank parity] {name}: device/fp32-oracle error ratio max {max(r['err'] / max(r['err_ref'], 1e-30) for r in rows):.2f}")
+    assert frac >= 0.99, f"{name}: only {frac:.4f} of the rank positions are decided"
+    same = sum(r["identical_positions_vs_fp32_sort"] for r in rows) / sum(r["n"] for r in rows)
+    assert same >= 0.99, f"{name}: only {same:.4f} of the positions equal the stable sort of the fp32 oracle"
+    return rows
+
+
+def _child(fn_name, label, env_extra):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", f"from tests.test_rank_order_gpu import {fn_name}; {fn_name}({label!r})"], cwd=root,
+                       env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_rank_order_tk_split_bf16():
+    run_tk_rank("tk_split_bf16")
+
+
+def test_rank_order_tk_exact_f32_mfma():
+    _child("run_tk_rank", "tk_exact_f32_mfma", {"MM_KP_F32MFMA": "1"})
+
+
+def run_tkl_rank(name, nq=4, C=64):
+    """nq queries x C long documents (config-3 shapes: D = 2048, lengths U{50..2048}, E = 300, Q = 20) through
+    ops.tkl_score on pre-contextualised chunks.  The document score sums 15 window scores picked by three arg-max
+    rounds (sigir20_tkl.py:262-286): when two windows of a document tie within the arithmetic noise the reference's own
+    fp32 and fp64 evaluations pick different regions, so documents whose fp32 / fp64 oracles disagree by more than the
+    window-level noise allows are reported as `unstable` and left out of the ranking lists (expected: none or a few)."""
+    from matchmaker_amd import ops
+    from matchmaker_amd.tkl import TKL_sigir20, chunk_documents
+    from oracle import torch_port as TP
+    dev = util.require_gpu()
+    B, Q, D, E = nq * C, 20, 2048, 300
+    g = torch.Generator().manual_seed(3030)
+    m = TKL_sigir20(E, MU, [0.1] * 11, 10, 1, 32, 2000, True, True, "embedding").eval()
+    with torch.no_grad():
+        m.chunk_scoring.copy_(torch.rand(m.chunk_scoring.shape, generator=g) + 0.5)
+    qq = torch.randn(nq, Q, E, generator=g)
+    q_len_q = torch.randint(3, Q + 1, (nq,), generator=g)
+    q = qq.repeat_interleave(C, 0)
+    q_len = q_len_q.repeat_interleave(C, 0)
+    d = torch.randn(B, D, E, generator=g)
+    d_len = torch.randint(50, D + 1, (B,), generator=g)
+    for b in range(B):                                    # planted exact / near matches at random positions
+        for _ in range(int(torch.randint(0, 12, (1,), generator=g))):
+            tq = int(torch.randint(0, int(q_len[b]), (1,), generator=g))
+            td = int(torch.randint(0, int(d_len[b]), (1,), generator=g))
+            d[b, td] = q[b, tq] * 1.7 + (0.3 * torch.randn(E, generator=g) if torch.rand(1, generator=g) < 0.5 else 0.0)
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D)[None] < d_len[:, None]).float()
+    q_ctx = q * qm.unsqueeze(-1)
+    chunks, cmask, slot, Cc = chunk_documents(d * dm.unsqueeze(-1), dm)
+    params = m.pack_params()
+    score, win = ops.tkl_score(q_ctx.to(dev), chunks.to(dev), cmask.to(dev), slot.to(dev), qm.to(dev), params.to(dev), B, Cc, 11,
+                               "embedding", return_windows=True)
+    score, win = score.cpu().numpy(), win.cpu().numpy()
+    sd = {k: v for k, v in m.state_dict().items()}
+    prm = {k: torch.as_tensor(np.asarray(v)).reshape(-1) for k, v in O.tkl_params_from_state(sd).items()}
+    packed = torch.zeros(B * Cc, dtype=torch.bool)
+    packed[slot.long()] = True
+    centre, cm = chunks[:, 5:-5].contiguous(), cmask[:, 5:-5].float().contiguous()
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        sc, wn = [], []
+        for b0 in range(0, B, 16):                        # 16 documents per oracle call (memory)
+            b1 = min(B, b0 + 16)
+            keep = (slot.long() // Cc >= b0) & (slot.long() // Cc < b1)
+            with torch.no_grad():
+                s_, w_ = TP.tkl_scoring(q_ctx[b0:b1].to(dt), centre[keep].to(dt), cm[keep].to(dt), packed[b0 * Cc:b1 * Cc], b1 - b0,
+                                        qm[b0:b1].to(dt), {k: v.to(dt) for k, v in prm.items()}, "embedding")
+            sc.append(s_.numpy()); wn.append(w_.numpy())
+        ref[dt] = (np.concatenate(sc), np.concatenate(wn))
+    (s32, w32), (s64, w64) = ref[torch.float32], ref[torch.float64]
+    W = win.shape[1]
+    np.testing.assert_allclose(win, w64[:, :W], atol=util.TOL_FP32, rtol=1e-5)      # every window of every document
+    np.testing.assert_allclose(score, s64, atol=util.TOL_FP32, rtol=1e-5)           # every document
+    assert ((win == 0) == (w64[:, :W] == 0)).all(), "empty windows must be exactly 0 on both sides (:248, :257)"
+    aw = float(np.abs(win - w64[:, :W]).max())
+    bw = float(np.abs(w32[:, :W] - w64[:, :W]).max())
+    # a document is stable when 15 windows x the window noise bounds both evaluations' document score error
+    lim = 15 * 1.5 * 2.0 * max(aw, bw)
+    stable = (np.abs(s32 - s64) <= lim) & (np.abs(score - s64) <= lim)
+    rows = []
+    for i in range(nq):
+        idx = np.arange(i * C, (i + 1) * C)[stable[i * C:(i + 1) * C]]
+        a = float(np.abs(score[idx] - s64[idx]).max())
+        b = float(np.abs(s32[idx] - s64[idx]).max())
+        rows.append(util.rank_parity(score[idx], s32[idx], s64[idx], (1, 10, len(idx)), noise=2.0 * max(a, b), label=f"{name} query {i}"))
+    frac = util.rank_report(name, rows)
+    print(f"[rank parity] {name}: window error device {aw:.3e} / fp32 oracle {bw:.3e}; unstable documents {int((~stable).sum())} of {B}")
+    assert (~stable).sum() <= B // 20, f"{name}: {int((~stable).sum())} of {B} documents differ beyond the window noise"
+    assert aw <= 16 * bw + 1e-6
+    assert frac >= 0.98, f"{name}: only {frac:.4f} of the rank positions are decided"
+    return rows
+
+
+def test_rank_order_tkl_split_bf16():
+    run_tkl_rank("tkl_split_bf16")
+
+
+def test_rank_order_tkl_exact_f32_mfma():
+    _child("run_tkl_rank", "tkl_exact_f32_mfma", {"MM_KP_F32MFMA": "1"})

@@ -82,8 +82,12 @@ def test_tkl_random_vs_oracle(B, Q, D, E, sat):
 
 
 def test_tkl_config3_scale_properties():
-    """BASELINE.json config 3 (D=2048, E=300): determinism, permutation equivariance over documents,
-    sampled oracle comparison."""
+    """BASELINE.json config 3 (D=2048, E=300): determinism and BIT-EQUAL permutation equivariance of the scoring
+    operator on pre-contextualised chunks (a permutation regroups the packed chunks into different runs and
+    wavefronts: nothing numeric may depend on that), and every document AND every window against the fp64 oracle."""
+    from matchmaker_amd import ops
+    from matchmaker_amd.tkl import chunk_documents
+    from oracle import torch_port as TP
     dev = util.require_gpu()
     B, Q, D, E = 48, 20, 2048, 300
     gen = torch.Generator(device=dev).manual_seed(3003)
@@ -94,18 +98,41 @@ def test_tkl_config3_scale_properties():
     d_len = torch.randint(50, D + 1, (B,), generator=gen, device=dev)
     qm = (torch.arange(Q, device=dev)[None] < q_len[:, None]).float()
     dm = (torch.arange(D, device=dev)[None] < d_len[:, None]).float()
+    params = m.pack_params()
+
+    def score(qx, dx, qmx, dmx):
+        q_ctx = qx * qmx.unsqueeze(-1)
+        chunks, cmask, slot, C = chunk_documents(dx * dmx.unsqueeze(-1), dmx)
+        s, w = ops.tkl_score(q_ctx, chunks, cmask, slot, qmx, params, B, C, 11, "embedding", return_windows=True)
+        return s, w, (q_ctx, chunks, cmask, slot, C)
+
+    s1, w1, (q_ctx, chunks, cmask, slot, C) = score(q, d, qm, dm)
+    s2, w2, _ = score(q, d, qm, dm)
+    assert torch.equal(s1, s2) and torch.equal(w1, w2)
+    perm = torch.randperm(B, device=dev)
+    sp, wp, _ = score(q[perm], d[perm], qm[perm], dm[perm])
+    assert torch.equal(wp, w1[perm]), "window scores depend on how the packed chunks are grouped"
+    assert torch.equal(sp, s1[perm])
     with torch.no_grad():
-        s1 = m.forward(q, d, qm, dm)
-        s2 = m.forward(q, d, qm, dm)
-        assert torch.equal(s1, s2)
-        perm = torch.randperm(B, device=dev)
-        sp = m.forward(q[perm], d[perm], qm[perm], dm[perm])
-    torch.testing.assert_close(sp, s1[perm], rtol=0, atol=1e-5)
-    sel = [0, 13, 47]
-    params = O.tkl_params_from_state({k: v.cpu() for k, v in m.state_dict().items()})
-    ref = O.tkl_forward_bypass(q[sel].cpu().numpy(), d[sel].cpu().numpy(), qm[sel].cpu().numpy(),
-                               dm[sel].cpu().numpy(), params, "embedding", dtype=np.float64)
-    np.testing.assert_allclose(s1[sel].cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+        assert torch.equal(m.forward(q, d, qm, dm), s1)          # the drop-in's forward = the operator
+    # every document / window vs the fp64 evaluation of sigir20_tkl.py:180-286 (torch port on CPU tensors)
+    prm = {k: torch.as_tensor(np.asarray(v)).reshape(-1).double()
+           for k, v in O.tkl_params_from_state({k: v.cpu() for k, v in m.state_dict().items()}).items()}
+    packed = torch.zeros(B * C, dtype=torch.bool)
+    packed[slot.long().cpu()] = True
+    centre, cm = chunks[:, 5:-5].cpu().double().contiguous(), cmask[:, 5:-5].cpu().double().contiguous()
+    sc, wn = [], []
+    for b0 in range(0, B, 16):
+        b1 = min(B, b0 + 16)
+        keep = ((slot.long() // C >= b0) & (slot.long() // C < b1)).cpu()
+        with torch.no_grad():
+            s_, w_ = TP.tkl_scoring(q_ctx[b0:b1].cpu().double(), centre[keep], cm[keep], packed[b0 * C:b1 * C], b1 - b0,
+                                    qm[b0:b1].cpu().double(), prm, "embedding")
+        sc.append(s_.numpy()); wn.append(w_.numpy())
+    W = w1.shape[1]
+    np.testing.assert_allclose(w1.cpu().numpy(), np.concatenate(wn)[:, :W], atol=util.TOL_FP32, rtol=1e-5)
+    np.testing.assert_allclose(s1.cpu().numpy(), np.concatenate(sc), atol=util.TOL_FP32, rtol=1e-5)
+
 
 
 def test_tk_and_tkl_full_models_wire_native_pooling_correctly():
