@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
         float* T = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *(f32x4*)(T + r * 32 + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
+          *(f32x4*)(T + r * kTS + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
                                                        (acc[4 * g + 2] * rq) * rdr[4 * g + 2], (acc[4 * g + 3] * rq) * rdr[4 * g + 3]};
         const float* lwrow = W ? wbuf + 32 * t : nullptr;
         rbf_redistributed_rows<K, W>(rrows, pk2, T, lwrow, rtk, rsub, va, rbf);
@@ -701,7 +701,7 @@ __device__ __forceinline__ void tkl_block_run(float* ps_run, float* stage, int l
   }
 }
 
-template <int NS, int K, int NBUF, bool NT>
+template <int NS, int K, int NBUF, bool NT, bool COS>
 __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
   static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -754,6 +754,13 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
   int prun = run_len(pp), pn = (40 * prun + 31) >> 5, pt = 0, ps = 0;
   uint32_t vrun[kSliceInstr];
   int pbuf = 0, cbuf = 0, inflight = 0;
+  // The epilogue's global stores share the in-order vmcnt queue with the LDS-DMA slices.  Counting only slices made
+  // the first wait of every block (queue: [slice a][slice b][16 stores][slice c], wait for a with vmcnt(2 x 13))
+  // also wait for slice b — one slice of prefetch depth lost per block.  `pre` = slices in the queue older than the
+  // last store burst, `nst` = stores of that burst: the count of operations younger than the oldest slice is
+  // 13 (inflight - 1) + nst while pre > 0, and the burst has retired before any younger slice once pre == 0.
+  // (Counting too FEW younger operations only waits longer; counting too many would read a slice before it landed.)
+  int pre = 0, nst = 0;
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
       if (ps == 0) {  // source offsets of block pt of the run: virtual row i -> chunk i / 40, row 5 + i % 40
@@ -834,7 +841,13 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         top_up();
-        wait_slices(inflight - 1);
+        if (pre > 0) {
+          wait_vm(kSliceInstr * (inflight - 1) + nst);
+          --pre;
+        } else {
+          nst = 0;
+          wait_slices(inflight - 1);
+        }
         const char* buf = smem + cbuf * kSliceBytes;
         f32x4 x[13];
 #pragma unroll
@@ -909,9 +922,33 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       }
       const int rows_blk = 40 * crun - i0 < 32 ? 40 * crun - i0 : 32;
       if (rows_blk < 32) va &= (1u << rows_blk) - 1u;
-      // staging area: the ring slot this block's last slice just left (free until the next top_up())
-      float* stage = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
-      tkl_block_run<K>(ps_run, stage, lane, Q, qlim, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+      if constexpr (COS) {
+        // virtual row iv of the run = position iv of the packed chunk sequence (40 rows per chunk): one linear index
+        if (r < qlim) {
+          float* dst = a.cos_out + ((pair * 40 + 32 * t + 4 * h) * (int64_t)Q + r);
+          const uint32_t vbits = va >> (4 * h);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (rowof(i) < rows_blk) {  // wave-uniform: rows_blk is a multiple of 8 and rowof(i) + 4h stays in rowof(i)'s group of 8
+              const float c = (acc[i] * rq) * rdr[i];
+              dst[rowof(i) * Q] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+            }
+          }
+        }
+        if (qlim > 0) {  // (a wavefront with no active lane issues no stores)
+          nst = rows_blk / 2;  // (an older burst still in the queue, NS = 1, is left uncounted: fewer counted = a longer wait, never a shorter one)
+          pre = inflight;
+        }
+      } else {
+        // staging area: the ring slot this block's last slice just left (free until the next top_up())
+        float* stage = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
+        tkl_block_run<K>(ps_run, stage, lane, Q, qlim, t, rows_blk, r, h, acc, rdr, rq, va >> (4 * h), rbf);
+        if (qlim > 0) {
+          const int burst = ((3 * qlim + 63) >> 6) * (rows_blk / 2);      // tkl_block_run: one store per pair row and 64-lane pass
+          nst = burst;
+          pre = inflight;
+        }
+      }
     }
     pair += crun;
   }
@@ -1059,12 +1096,21 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   // No non-temporal hint on these K-sliced streams: the 400-B row pieces of neighbouring slices share cache
   // lines, and with `nt` the shared lines came from HBM twice (FETCH_SIZE 1.22 x the padded bytes, 1.08 x without).
   if constexpr (TKL) {  // grouped runs of chunks (tkl_stage1_run_kernel)
+    if (a.cos_out) {
+      if (a.E == 100)
+        hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, false, true>), grid, block, lds, stream, a);
+      else if (a.E == 200)
+        hipLaunchKernelGGL((tkl_stage1_run_kernel<2, K, NBUF, false, true>), grid, block, lds, stream, a);
+      else
+        hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, false, true>), grid, block, lds, stream, a);
+      return check_launch("tkl_stage1_run_kernel<cos>");
+    }
     if (a.E == 100)
-      hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, false, false>), grid, block, lds, stream, a);
     else if (a.E == 200)
-      hipLaunchKernelGGL((tkl_stage1_run_kernel<2, K, NBUF, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<2, K, NBUF, false, false>), grid, block, lds, stream, a);
     else
-      hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, false, false>), grid, block, lds, stream, a);
     return check_launch("tkl_stage1_run_kernel");
   } else {
     if (a.E == 100)
@@ -1079,11 +1125,15 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
 
 bool kp_stream_supported(int Q, int E) { return Q <= 32 && (E == 100 || E == 200 || E == 300); }
 
+// the cosine hand-off exists on the grouped-run kernel only (the exact-f32 A/B kernel and the generic kernel emit pair sums)
+bool tkl_cos_supported(int Q, int E) { return !env().kp_generic && !env().kp_f32mfma && !env().tkl_pairsums && kp_stream_supported(Q, E); }
+
 // TKL stage 1 entry (called from tkl.hip): chunks [P,50,E] -> ps_out [P,20,Q,12]
 int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, const int32_t* q_len,
                       const int32_t* chunk_slot, int C, const float* mu, const float* sigma, float* ps_out, int64_t P,
-                      int Q, int E, int32_t* slot2p, int64_t n_slots, hipStream_t stream) {
+                      int Q, int E, int32_t* slot2p, int64_t n_slots, hipStream_t stream, float* cos_out) {
   KpArgs a{};
+  a.cos_out = cos_out;
   a.q = q_ctx; a.d = chunks; a.dm = dm; a.mu = mu; a.sigma = sigma; a.alpha = nullptr; a.w = nullptr;
   a.qm.len = q_len;  // effective query lengths [B] (may be null): pair rows of later tokens are not written
   a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;

@@ -35,6 +35,12 @@ struct KpArgs {
   // (entries of dropped chunks were set to -1 by the preparation launch, earlier in the stream)
   int32_t* slot2p;
   int64_t n_slots;
+  // TKL, cosine hand-off (tkl_stage1_run_kernel<COS>): instead of the pair sums stage 1 stores the scaled, masked
+  // cosines themselves, cos_out[(p * 40 + position) * Q + query token] (masked position: 1e5, which underflows every
+  // kernel to exactly 0), and the window kernel evaluates the RBF kernels while it stages its tile — 4 bytes per
+  // (position, token) across HBM instead of 24, and the transcendental work runs on sixteen thin wavefronts per CU
+  // instead of one fat wavefront per SIMD
+  float* cos_out;
   // variants of the pooling block (same arithmetic family):
   //   dw != nullptr: per document token gate >= 0 multiplying all its activations (TK-Sparse stop-word
   //   vector, cikm20_tk_sparse.py:133-135), [n_pairs, D] float32;
@@ -192,14 +198,22 @@ __device__ __forceinline__ void rbf_rows(f32x2 (&pk2)[kMaxK / 2], const float (&
   }
 }
 
-// read this lane's ROWS values of the transposed tile T[token][32 rows] (and of the gate vector) and evaluate them:
+// Token stride of the transposed tile in floats.  With 32 the 3-lanes-per-token form (ROWS = 11, single-float reads
+// at T[t * 32 + 11 s + j]) put all even tokens on one bank and all odd tokens on another: ~10-way conflicts,
+// SQ_LDS_BANK_CONFLICT = 198.9 M cycles per dispatch in profiles/r02_tk_pmc.json (~444 cycles per 32-row block).
+// 36 keeps the rows 16-byte aligned (the f32x4 writes of the MFMA layout and the ROWS = 4 / 8 reads) and spreads
+// the tokens: 36 t mod 64 walks the multiples of 4 with period 16, and the row-group offsets 0 / 11 / 22 fall
+// into different classes mod 4, so at most two of the 63 lanes share a bank.
+constexpr int kTS = 36;
+
+// read this lane's ROWS values of the transposed tile T[token][kTS >= 32 rows] (and of the gate vector) and evaluate them:
 // lane = (token t, row group s), rows s * ROWS .. s * ROWS + ROWS - 1 (rows >= 32 do not exist: their bits are 0).
 // ROWS need not divide 32: a 20-token query puts 3 lanes on a token (11 + 11 + 10 rows).
 template <int K, bool W, int ROWS>
 __device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow, int t, int s,
                                                   uint32_t va, const Rbf& rbf) {
   const int row0 = s * ROWS;
-  const float* src = T + t * 32 + row0;
+  const float* src = T + t * kTS + row0;
   float c[ROWS], lw[ROWS];
   if constexpr (ROWS % 4 == 0) {
 #pragma unroll
@@ -215,7 +229,7 @@ __device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
       const int rr = row0 + j < 32 ? row0 + j : 31;      // stay inside the tile / the gate row; the bit of a row >= 32 is 0
-      c[j] = T[t * 32 + rr];
+      c[j] = T[t * kTS + rr];
       if (W) lw[j] = lwrow[rr];
     }
   }

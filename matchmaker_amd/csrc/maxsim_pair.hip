@@ -20,77 +20,6 @@
 
 namespace mm {
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n.  n >= 63 needs no wait: fewer than 63 vector-memory loads can
-// be outstanding with these rings (<= 4 units x 11 instructions), so anything that far back has landed.
-__device__ __forceinline__ void wait_vm(int n) {
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
-    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
-    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
-    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
-    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
-    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
-    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
-    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
-    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
-    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
-    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
-    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
-    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
-    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
-    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
-    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
-    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
-    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
-    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
-    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
-    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
-    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
-    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
-    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
-    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
-    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
-    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
-    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
-    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
-    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
-    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
-    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
-    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
-    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
-    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
-    default: break;
-  }
-}
-
 constexpr int kMaskRaw = 3072;     // raw int64 image of one pair's masks: document [0, 2048) (D <= 256), query [2048, 3072)
 constexpr int kMaskEntry = 12;     // dwords per converted entry: len, qbits, 8 validity words, 2 pad
 constexpr int kMaskEntries = 8;    // producer runs at most NBUF + 1 pairs ahead of the consumer

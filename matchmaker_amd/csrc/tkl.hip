@@ -192,7 +192,11 @@ constexpr int kWindowLds = MM_WIN_LDS;     // two workgroups per CU: one stages 
 
 // One workgroup = kWT consecutive windows of one document, in passes of wt = 64 / 32 / 16 windows — the largest that
 // fits the workgroup's LDS at the document's effective query length.
-template <int SAT>
+// COS: `ps` holds stage 1's scaled, masked cosines cos[(p * 40 + position) * Q + token] (KpArgs::cos_out) and the pair
+// rows of the tile are EVALUATED here while they are staged (RBF kernels of the two positions of a pair + the
+// non-zero count, the arithmetic of kernel_pool.hip's tkl_block_run), instead of being read back from a 6x larger
+// pair-sum buffer.
+template <int SAT, bool COS>
 __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* __restrict__ ps, const int32_t* __restrict__ slot2p,
                                                          const float* __restrict__ emb_g,
                                                          const float* __restrict__ q_mask,
@@ -247,37 +251,123 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
     // All row loads of a batch of kStage elements are issued before the first LDS store, so a thread pays
     // one memory latency per batch (a tile of Q = 20 is ONE batch); the kernel was 67 % s_waitcnt when every
     // element did its own dependent slot -> chunk -> row chain.
-    const int row4 = rowf / 4;
-    const int total4 = nu * row4;
-    constexpr int kStage = 10;
-    for (int base = tz; base < total4; base += kWThreads * kStage) {
-      int pidx[kStage];
-      int off[kStage];
-  #pragma unroll
-      for (int s = 0; s < kStage; ++s) {
-        const int idx = base + kWThreads * s;
-        pidx[s] = -1;
-        off[s] = 0;
-        if (idx < total4) {
-          const int j = idx / row4, v = idx - j * row4;
-          const int ug = ws + j;
-          const int c = ug / kU, uu = ug - c * kU;
-          off[s] = uu * srcf + v * 4;
-          const int info = cinfo[c - c0];                                // c - c0 <= (19 + kWT + 14) / 20 < 8
-          // rows of unwritten blocks are zeros
-          if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;
+    if constexpr (COS) {
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      // RBF constants in the packed exp2 form of kp_device.h (pack_rbf): exp(-(c - mu)^2 / (2 s^2)) = exp2(-(c sq - mu sq)^2);
+      // wave-uniform, kept in scalar registers
+      f32x2 sq2[kKC / 2], msq2[kKC / 2];
+#pragma unroll
+      for (int kp = 0; kp < kKC / 2; ++kp) {
+        float sq[2], msq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = 2 * kp + u;
+          if (k < kK) {
+            const float sg = prm[TklParams::sigma() + k];
+            const float c2 = -1.4426950408889634f / (2.0f * sg * sg);
+            sq[u] = sqrtf(-c2);
+            msq[u] = prm[TklParams::mu() + k] * sq[u];
+          } else {
+            sq[u] = 0.0f;
+            msq[u] = 1.0e3f;      // the dummy 12th kernel: exp2(-(0 c - 1e3)^2) = 0 for every c
+          }
+          sq[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sq[u])));
+          msq[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, msq[u])));
+        }
+        sq2[kp] = f32x2{sq[0], sq[1]};
+        msq2[kp] = f32x2{msq[0], msq[1]};
+      }
+      // item = (pair row j of the tile, query token i), token fastest: the two cosine rows of a pair are read in
+      // runs of ql consecutive floats and the tile is written contiguously.  All loads of a batch are issued before
+      // the first evaluation (one memory latency per batch; a 64-window tile at ql = 20 is one batch).
+      const int items = nu * ql;
+      constexpr int kStageC = 4;
+      for (int base = tz; base < items; base += kWThreads * kStageC) {
+        float ca[kStageC], cb[kStageC];
+        bool have[kStageC];
+#pragma unroll
+        for (int s = 0; s < kStageC; ++s) {
+          const int idx = base + kWThreads * s;
+          have[s] = false;
+          ca[s] = cb[s] = 1.0e5f;
+          if (idx < items) {
+            const int j = idx / ql, i = idx - j * ql;
+            const int ug = ws + j;
+            const int c = ug / kU, uu = ug - c * kU;
+            const int info = cinfo[c - c0];                              // c - c0 <= (19 + kWT + 14) / 20 < 8
+            if (info >= 0) {
+              const float* src = ps + ((int64_t)(info >> 2) * 40 + 2 * uu) * Q + i;
+              ca[s] = src[0];
+              cb[s] = src[Q];
+              have[s] = true;
+            }
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < kStageC; ++s) {
+          const int idx = base + kWThreads * s;
+          if (idx < items) {
+            f32x2 o2[kKC / 2];
+#pragma unroll
+            for (int kp = 0; kp < kKC / 2; ++kp) o2[kp] = f32x2{0.0f, 0.0f};
+            float cnt = 0.0f;
+            if (have[s]) {
+#pragma unroll
+              for (int half = 0; half < 2; ++half) {
+                const float c = half ? cb[s] : ca[s];
+                const f32x2 cc = {c, c};
+                f32x2 any2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int kp = 0; kp < kKC / 2; ++kp) {
+                  const f32x2 sv = cc * sq2[kp] - msq2[kp];
+                  const f32x2 av = -(sv * sv);
+                  const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+                  o2[kp] += e;
+                  any2 += e;
+                }
+                cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;        // (:210)
+              }
+            }
+            f32x4* dst = (f32x4*)(tile + (size_t)idx * kKC);             // idx = j * ql + i: row j, token i
+            dst[0] = f32x4{o2[0][0], o2[0][1], o2[1][0], o2[1][1]};
+            dst[1] = f32x4{o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
+            dst[2] = f32x4{o2[4][0], o2[4][1], o2[5][0], cnt};
+          }
         }
       }
-      f32x4 val[kStage];
-  #pragma unroll
-      for (int s = 0; s < kStage; ++s) {
-        val[s] = f32x4{0, 0, 0, 0};
-        if (pidx[s] >= 0) val[s] = *(const f32x4*)(ps + (int64_t)pidx[s] * kU * srcf + off[s]);
-      }
-  #pragma unroll
-      for (int s = 0; s < kStage; ++s) {
-        const int idx = base + kWThreads * s;
-        if (idx < total4) *(f32x4*)(tile + (size_t)idx * 4) = val[s];
+    } else {
+      const int row4 = rowf / 4;
+      const int total4 = nu * row4;
+      constexpr int kStage = 10;
+      for (int base = tz; base < total4; base += kWThreads * kStage) {
+        int pidx[kStage];
+        int off[kStage];
+    #pragma unroll
+        for (int s = 0; s < kStage; ++s) {
+          const int idx = base + kWThreads * s;
+          pidx[s] = -1;
+          off[s] = 0;
+          if (idx < total4) {
+            const int j = idx / row4, v = idx - j * row4;
+            const int ug = ws + j;
+            const int c = ug / kU, uu = ug - c * kU;
+            off[s] = uu * srcf + v * 4;
+            const int info = cinfo[c - c0];                                // c - c0 <= (19 + kWT + 14) / 20 < 8
+            // rows of unwritten blocks are zeros
+            if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;
+          }
+        }
+        f32x4 val[kStage];
+    #pragma unroll
+        for (int s = 0; s < kStage; ++s) {
+          val[s] = f32x4{0, 0, 0, 0};
+          if (pidx[s] >= 0) val[s] = *(const f32x4*)(ps + (int64_t)pidx[s] * kU * srcf + off[s]);
+        }
+    #pragma unroll
+        for (int s = 0; s < kStage; ++s) {
+          const int idx = base + kWThreads * s;
+          if (idx < total4) *(f32x4*)(tile + (size_t)idx * 4) = val[s];
+        }
       }
     }
     __syncthreads();
@@ -437,11 +527,13 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     dm.len = clen;
     dm.bits = cbits;
   }
-  // launch 2: stage 1 (pair sums of every kept chunk + its slot-map entry)
+  // launch 2: stage 1 (scaled cosines — or, on the A/B paths, pair sums — of every kept chunk + its slot-map entry).
+  // The cosine buffer [P * 40, Q] lives in the pair-sum region of the workspace (a sixth of its size).
+  const bool use_cos = tkl_cos_supported(Q, E);
   if (P > 0) {
     if (int e = tkl_stage1_stream((const float*)q_ctx, (const float*)chunks, dm, qmk.len, chunk_slot, C,
                                   params + TklParams::mu(), params + TklParams::sigma(), ps, P, Q, E, slot2p,
-                                  B * (int64_t)C, stream))
+                                  B * (int64_t)C, stream, use_cos ? ps : nullptr))
       return e;
   }
   {
@@ -451,16 +543,17 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     const size_t lds2 = full < (size_t)kWindowLds ? full : (size_t)kWindowLds;
     if (window_pass_bytes(8, Q) > lds2) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
     const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
+    auto launch = [&](auto kern) {
+      if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(kern, grid2, dim3(kWThreads), lds2, stream, (const float*)ps, (const int32_t*)slot2p, (const float*)emb, q_mask,
+                         (const int32_t*)qmk.len, params, win, C, Q, W, (int)lds2);
+    };
     if (saturation == MM_TKL_SAT_EMBEDDING) {
-      if (lds2 > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_EMBEDDING>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
-                         emb, q_mask, qmk.len, params, win, C, Q, W, (int)lds2);
+      if (use_cos) launch(tkl_window_kernel<MM_TKL_SAT_EMBEDDING, true>);
+      else launch(tkl_window_kernel<MM_TKL_SAT_EMBEDDING, false>);
     } else {
-      if (lds2 > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)tkl_window_kernel<MM_TKL_SAT_LOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(tkl_window_kernel<MM_TKL_SAT_LOG>, grid2, dim3(kWThreads), lds2, stream, ps, slot2p,
-                         emb, q_mask, qmk.len, params, win, C, Q, W, (int)lds2);
+      if (use_cos) launch(tkl_window_kernel<MM_TKL_SAT_LOG, true>);
+      else launch(tkl_window_kernel<MM_TKL_SAT_LOG, false>);
     }
     if (int e = check_launch("tkl_window_kernel")) return e;
   }
