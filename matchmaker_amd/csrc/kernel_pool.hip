@@ -740,12 +740,16 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       sload4_u32(a.chunk_slot, p, sl);
       const int b0 = (int)sl[0] / a.C;
       int n = 1;
-      while (n < 4 && p + n < p1 && (int)sl[n] / a.C == b0) ++n;
+      while (n < 4 && p + n < p1 && (int)sl[n] / a.C == b0 && (!COS || (int)sl[n] == (int)sl[0] + n)) ++n;
       return n;
     }
-    const int b0 = (int)sload_u32(a.chunk_slot, p) / a.C;
+    const int s0 = (int)sload_u32(a.chunk_slot, p), b0 = s0 / a.C;
     int n = 1;
-    while (n < 4 && p + n < p1 && (int)sload_u32(a.chunk_slot, p + n) / a.C == b0) ++n;
+    while (n < 4 && p + n < p1) {
+      const int sn = (int)sload_u32(a.chunk_slot, p + n);
+      if (sn / a.C != b0 || (COS && sn != s0 + n)) break;
+      ++n;
+    }
     return n;
   };
 
@@ -801,7 +805,8 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
     const int crun = run_len(pair);
     const int nb = (40 * crun + 31) >> 5;
     for (int k = 0; k < crun; ++k) tkl_publish_slot(a, pair + k, 2, lane);  // every pair row of every chunk is written
-    const int64_t qi = (int64_t)((int)sload_u32(a.chunk_slot, pair) / a.C);
+    const int slot0 = (int)sload_u32(a.chunk_slot, pair);
+    const int64_t qi = (int64_t)(slot0 / a.C);
     if (qi != cur_q) {
       cur_q = qi;
       const int qr = r < Q ? r : Q - 1;
@@ -857,6 +862,12 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
         }
         x[12] = *(const f32x4*)(buf + l_off);
         __builtin_amdgcn_sched_barrier(0);
+        if (COS && (a.dbg & 2)) {  // removal experiment: the slice is consumed, nothing is computed
+          acc_hh[0] += x[0][0] + x[5][1] + x[12][2];
+          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+          --inflight;
+          continue;
+        }
         bf16x8 ah, al;
         split8(x[0], x[1], ah, al);
 #pragma unroll
@@ -913,7 +924,9 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       const int i0 = 32 * t;
       const int c0 = (i0 * 205) >> 13, r0 = i0 - 40 * c0;
       uint32_t va;
-      {
+      if (COS && (a.dbg & 4)) {
+        va = 0xffffffffu;
+      } else {
         const uint32_t w0 = sload_u32(a.dm.bits, (pair + c0) * 2), w1 = sload_u32(a.dm.bits, (pair + c0) * 2 + 1);
         const unsigned long long b0 = ((unsigned long long)(w1 & 0xffu) << 32) | w0;
         va = (uint32_t)(b0 >> r0);
@@ -923,20 +936,29 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       const int rows_blk = 40 * crun - i0 < 32 ? 40 * crun - i0 : 32;
       if (rows_blk < 32) va &= (1u << rows_blk) - 1u;
       if constexpr (COS) {
-        // virtual row iv of the run = position iv of the packed chunk sequence (40 rows per chunk): one linear index
-        if (r < qlim) {
-          float* dst = a.cos_out + ((pair * 40 + 32 * t + 4 * h) * (int64_t)Q + r);
-          const uint32_t vbits = va >> (4 * h);
+        // Cosine rows are indexed by chunk SLOT (b * C + c): cos_out[(slot * 40 + position) * Q + token].  The chunks of a
+        // run sit in consecutive slots, so virtual row iv of the run is row slot0 * 40 + iv and the block's rows_blk x Q
+        // values are ONE contiguous span.  Written lane-by-token straight from the accumulators that was 16 store
+        // instructions of <= 2 x 80 B each per block, and every one of them queues behind the LDS-DMA stream (measured by
+        // removal: 21 us of stage 1's 160 on config 3's full documents); the tile is transposed through the ring slot the
+        // block just freed and leaves as ceil(rows_blk * Q / 256) full-width 16-B stores (3 at Q = 20) — all Q columns,
+        // the ones past the query's effective length are never read.
+        float* T = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
+        const int n4 = (rows_blk * Q) >> 2;                    // rows_blk % 8 == 0
+        if (!(a.dbg & 1)) {
+          if (r < Q) {
+            const uint32_t vbits = va >> (4 * h);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            if (rowof(i) < rows_blk) {  // wave-uniform: rows_blk is a multiple of 8 and rowof(i) + 4h stays in rowof(i)'s group of 8
-              const float c = (acc[i] * rq) * rdr[i];
-              dst[rowof(i) * Q] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+            for (int i = 0; i < 16; ++i) {
+              if (rowof(i) < rows_blk) {  // wave-uniform
+                const float c = (acc[i] * rq) * rdr[i];
+                T[(rowof(i) + 4 * h) * Q + r] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;   // masked: every kernel underflows to 0
+              }
             }
           }
-        }
-        if (qlim > 0) {  // (a wavefront with no active lane issues no stores)
-          nst = rows_blk / 2;  // (an older burst still in the queue, NS = 1, is left uncounted: fewer counted = a longer wait, never a shorter one)
+          f32x4* dst = (f32x4*)(a.cos_out + ((int64_t)slot0 * 40 + 32 * t) * Q);
+          for (int l = lane; l < n4; l += 64) dst[l] = ((const f32x4*)T)[l];
+          nst = (n4 + 63) >> 6;
           pre = inflight;
         }
       } else {
@@ -1134,6 +1156,7 @@ int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, co
                       int Q, int E, int32_t* slot2p, int64_t n_slots, hipStream_t stream, float* cos_out) {
   KpArgs a{};
   a.cos_out = cos_out;
+  a.dbg = env().kp_dbg;
   a.q = q_ctx; a.d = chunks; a.dm = dm; a.mu = mu; a.sigma = sigma; a.alpha = nullptr; a.w = nullptr;
   a.qm.len = q_len;  // effective query lengths [B] (may be null): pair rows of later tokens are not written
   a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;
@@ -1157,6 +1180,7 @@ static int launch_k(const KpArgs& a0, hipStream_t stream) {
     hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false, true>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
     return check_launch("kernel_pool_generic_kernel<gated>");
   }
+  if (stream_ok && K == 11 && !env().kp_f32mfma && kp_wg_supported(a)) return kp_wg_launch(a, stream);
   if (stream_ok) return launch_stream<K, false>(a, stream);
   if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
   hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false>), dim3((unsigned)a.n_pairs, (unsigned)(a.n_md > 0 ? a.n_mblk : 1)), dim3(64), 0,

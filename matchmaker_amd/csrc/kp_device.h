@@ -41,6 +41,7 @@ struct KpArgs {
   // (position, token) across HBM instead of 24, and the transcendental work runs on sixteen thin wavefronts per CU
   // instead of one fat wavefront per SIMD
   float* cos_out;
+  int dbg;  // MM_KP_DBG (measurement by removal, TKL stage 1 only): 1 = no cosine stores, 2 = no split / MFMA, 4 = no mask words
   // variants of the pooling block (same arithmetic family):
   //   dw != nullptr: per document token gate >= 0 multiplying all its activations (TK-Sparse stop-word
   //   vector, cikm20_tk_sparse.py:133-135), [n_pairs, D] float32;
@@ -142,9 +143,15 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
 // which turns the pk_mul of the square into a pk_fma: the gate costs no instruction.
 // KP0..KP1: the kernel pairs this call evaluates, G0..G1: the 8-row groups (a K-split workgroup shares the
 // epilogue between its two waves either by kernel pairs or by rows).
-template <int K, bool W = false, int KP0 = 0, int KP1 = (K + 1) / 2, int G0 = 0, int G1 = 4>
+// the packed constants alone (kernel_pool_wg.hip fetches them from LDS per block instead of holding a whole Rbf)
+struct RbfPk {
+  f32x2 sq2[kMaxK / 2];
+  f32x2 msq2[kMaxK / 2];
+};
+
+template <int K, bool W = false, int KP0 = 0, int KP1 = (K + 1) / 2, int G0 = 0, int G1 = 4, typename R = Rbf>
 __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
-                                          uint32_t va, int h, const Rbf& rbf, const float* lw = nullptr) {
+                                          uint32_t va, int h, const R& rbf, const float* lw = nullptr) {
   // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
   // 4g..4g+3 hold rows 8g..8g+7 (both lane halves), so a group with no real row is skipped as a
   // whole (the last block of a document: D = 200 -> 8 of 32 rows) and a group of 8 real rows needs
@@ -180,8 +187,8 @@ __device__ __forceinline__ float gate_log2(float g) { return __builtin_amdgcn_lo
 // (c[j]: scaled cosines; bit j of `bits`: row j is a real token; lw: log2 gates of those rows when W).
 // Used when the query is short: a Q-token tile keeps only Q of 32 lanes busy in rbf_block, so the tile is
 // transposed through LDS and NP = 32 / ROWS lanes share each query token.
-template <int K, bool W, int ROWS>
-__device__ __forceinline__ void rbf_rows(f32x2 (&pk2)[kMaxK / 2], const float (&c)[ROWS], uint32_t bits, const Rbf& rbf,
+template <int K, bool W, int ROWS, typename R = Rbf>
+__device__ __forceinline__ void rbf_rows(f32x2 (&pk2)[kMaxK / 2], const float (&c)[ROWS], uint32_t bits, const R& rbf,
                                          const float (&lw)[ROWS]) {
 #pragma unroll
   for (int j = 0; j < ROWS; ++j) {
@@ -209,9 +216,15 @@ constexpr int kTS = 36;
 // read this lane's ROWS values of the transposed tile T[token][kTS >= 32 rows] (and of the gate vector) and evaluate them:
 // lane = (token t, row group s), rows s * ROWS .. s * ROWS + ROWS - 1 (rows >= 32 do not exist: their bits are 0).
 // ROWS need not divide 32: a 20-token query puts 3 lanes on a token (11 + 11 + 10 rows).
-template <int K, bool W, int ROWS>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// `loaded()` runs after this lane's values have been read from T and before they are evaluated (the workgroup kernel hands
+// the ring slot that holds T back to its producer there)
+template <int K, bool W, int ROWS, typename Hook = NoHook, typename R = Rbf>
 __device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow, int t, int s,
-                                                  uint32_t va, const Rbf& rbf) {
+                                                  uint32_t va, const R& rbf, Hook loaded = Hook()) {
   const int row0 = s * ROWS;
   const float* src = T + t * kTS + row0;
   float c[ROWS], lw[ROWS];
@@ -238,6 +251,7 @@ __device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const
     for (int j = 0; j < ROWS; ++j) lw[j] = 0.0f;
   }
   const uint32_t bits = (row0 < 32 ? (va >> row0) : 0u) & ((ROWS == 32) ? 0xffffffffu : ((1u << ROWS) - 1u));
+  loaded();
   rbf_rows<K, W, ROWS>(pk2, c, bits, rbf, lw);
 }
 
@@ -252,15 +266,15 @@ __device__ __forceinline__ int redist_rows(int qn) {
   return 11;                   // 17 .. 21 tokens: 3 lanes per token, +1.3 % at Q = 20
 }
 
-template <int K, bool W>
+template <int K, bool W, typename Hook = NoHook, typename R = Rbf>
 __device__ __forceinline__ void rbf_redistributed_rows(int rows, f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow,
-                                                       int t, int s, uint32_t va, const Rbf& rbf) {
+                                                       int t, int s, uint32_t va, const R& rbf, Hook loaded = Hook()) {
   switch (rows) {
-    case 1: rbf_redistributed<K, W, 1>(pk2, T, lwrow, t, s, va, rbf); break;
-    case 2: rbf_redistributed<K, W, 2>(pk2, T, lwrow, t, s, va, rbf); break;
-    case 4: rbf_redistributed<K, W, 4>(pk2, T, lwrow, t, s, va, rbf); break;
-    case 8: rbf_redistributed<K, W, 8>(pk2, T, lwrow, t, s, va, rbf); break;
-    default: rbf_redistributed<K, W, 11>(pk2, T, lwrow, t, s, va, rbf); break;
+    case 1: rbf_redistributed<K, W, 1>(pk2, T, lwrow, t, s, va, rbf, loaded); break;
+    case 2: rbf_redistributed<K, W, 2>(pk2, T, lwrow, t, s, va, rbf, loaded); break;
+    case 4: rbf_redistributed<K, W, 4>(pk2, T, lwrow, t, s, va, rbf, loaded); break;
+    case 8: rbf_redistributed<K, W, 8>(pk2, T, lwrow, t, s, va, rbf, loaded); break;
+    default: rbf_redistributed<K, W, 11>(pk2, T, lwrow, t, s, va, rbf, loaded); break;
   }
 }
 
@@ -368,6 +382,10 @@ __device__ __forceinline__ bf16x8 to_agpr(bf16x8 v) {
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+
+// kernel_pool_wg.hip: shared-query lists at E = 300, two wavefronts per SIMD (query tile in LDS)
+bool kp_wg_supported(const KpArgs& a);
+int kp_wg_launch(const KpArgs& a, hipStream_t stream);
 
 // kernel_pool128.hip: streaming kernels for E = 64n <= 384 (Q <= 32)
 bool kp128_supported(int Q, int D, int E, bool gated);

@@ -225,6 +225,33 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
     const int c = c0 + tid;
     cinfo[tid] = c < C ? slot2p[(int64_t)b * C + c] : -1;
   }
+  // COS: the cosine rows are indexed by chunk slot, so their addresses do not depend on the lookups: the first batch of
+  // the first pass is requested BEFORE the barrier and both latencies run in parallel (a row of a dropped chunk was
+  // never written; its values are discarded below)
+  constexpr int kStageC = 4;
+  float ca[kStageC], cb[kStageC];
+  int cl[kStageC];
+  auto issue_cos = [&](int ws_, int base_) {
+    const int items_ = nu * ql;
+#pragma unroll
+    for (int s = 0; s < kStageC; ++s) {
+      const int idx = base_ + kWThreads * s;
+      cl[s] = -1;
+      ca[s] = cb[s] = 1.0e5f;
+      if (idx < items_) {
+        const int j = idx / ql, i = idx - j * ql;
+        const int ug = ws_ + j;
+        const int c = ug / kU, uu = ug - c * kU;
+        if (c < C) {
+          const float* src = ps + (((int64_t)b * C + c) * 40 + 2 * uu) * Q + i;
+          ca[s] = src[0];
+          cb[s] = src[Q];
+          cl[s] = c - c0;                                                // <= (19 + kWT + 14) / 20 < 8
+        }
+      }
+    }
+  };
+  if constexpr (COS) issue_cos(w0, tid);
   __syncthreads();
   // a tile none of whose chunks exists (padding past the document's end) is all zeros: every window is empty and
   // scores exactly 0 (:248) — half of all tiles with config 3's U{50..2048} document lengths; so is every window of
@@ -281,28 +308,8 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
       // runs of ql consecutive floats and the tile is written contiguously.  All loads of a batch are issued before
       // the first evaluation (one memory latency per batch; a 64-window tile at ql = 20 is one batch).
       const int items = nu * ql;
-      constexpr int kStageC = 4;
       for (int base = tz; base < items; base += kWThreads * kStageC) {
-        float ca[kStageC], cb[kStageC];
-        bool have[kStageC];
-#pragma unroll
-        for (int s = 0; s < kStageC; ++s) {
-          const int idx = base + kWThreads * s;
-          have[s] = false;
-          ca[s] = cb[s] = 1.0e5f;
-          if (idx < items) {
-            const int j = idx / ql, i = idx - j * ql;
-            const int ug = ws + j;
-            const int c = ug / kU, uu = ug - c * kU;
-            const int info = cinfo[c - c0];                              // c - c0 <= (19 + kWT + 14) / 20 < 8
-            if (info >= 0) {
-              const float* src = ps + ((int64_t)(info >> 2) * 40 + 2 * uu) * Q + i;
-              ca[s] = src[0];
-              cb[s] = src[Q];
-              have[s] = true;
-            }
-          }
-        }
+        if (!(ws == w0 && base < kWThreads)) issue_cos(ws, base);        // (the first batch is already in flight)
 #pragma unroll
         for (int s = 0; s < kStageC; ++s) {
           const int idx = base + kWThreads * s;
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
 #pragma unroll
             for (int kp = 0; kp < kKC / 2; ++kp) o2[kp] = f32x2{0.0f, 0.0f};
             float cnt = 0.0f;
-            if (have[s]) {
+            if (cl[s] >= 0 && cinfo[cl[s]] >= 0) {
 #pragma unroll
               for (int half = 0; half < 2; ++half) {
                 const float c = half ? cb[s] : ca[s];
@@ -460,6 +467,12 @@ __global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// stage 1 -> stage 2 hand-off region: pair sums [P, 20, Q, 12] (A/B paths) or the slot-indexed cosine rows [B * C * 40, Q]
+static size_t handoff_bytes(int64_t B, int64_t P, int C, int Q) {
+  const size_t pairs = (size_t)P * kU * Q * kKC * 4, cosr = (size_t)B * C * 40 * Q * 4;
+  return align256(pairs > cosr ? pairs : cosr);
+}
+
 }  // namespace mm
 
 using namespace mm;
@@ -467,7 +480,7 @@ using namespace mm;
 extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int K) {
   if (B <= 0 || P < 0 || C <= 0 || Q <= 0 || K != kK) return 0;
   const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
-  return align256((size_t)B * C * 4) + align256((size_t)P * kU * Q * kKC * 4) +
+  return align256((size_t)B * C * 4) + handoff_bytes(B, P, C, Q) +
          packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4) +
          packed_mask_bytes(MM_MASK_F32, B, Q);  // + the packed query mask (effective lengths)
 }
@@ -494,7 +507,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   int32_t* slot2p = (int32_t*)ws;
   ws += align256((size_t)B * C * 4);
   float* ps = (float*)ws;
-  const size_t ps_bytes = align256((size_t)P * kU * Q * kKC * 4);
+  const size_t ps_bytes = handoff_bytes(B, P, C, Q);
   ws += ps_bytes;
   size_t left = workspace_bytes - (size_t)(ws - (char*)workspace);
   float* win = win_scores;

@@ -267,3 +267,59 @@ def test_multi_block_pooling_equals_the_sum_of_single_launches(E, D):
                                     w[i * n + j].numpy(), dtype=np.float64)
     assert torch.equal(got, want)           # same kernels, same (i, t) summation order
     np.testing.assert_allclose(got.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+@pytest.mark.parametrize("Q", [20, 32, 9])
+def test_shared_query_lists_on_the_workgroup_kernel(Q):
+    """Candidate lists of >= 64 pairs per query at E = 300 run on kernel_pool_wg_kernel (two wavefronts per SIMD, the
+    query tile in LDS, 15-chunk slices): every pair vs the fp64 oracle, per-kernel outputs, dense masks with holes,
+    empty documents, queries of every epilogue class (MFMA layout, 11 / 8 / 4 / 2 / 1 rows per lane), a list that is
+    not a multiple of the wavefront count, and bit-equality with the one-wavefront-per-SIMD kernel's layout-independent
+    properties (determinism, permutation equivariance)."""
+    from matchmaker_amd import ops
+    from oracle import torch_port as TP
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(300 + Q)
+    nq, C, D, E = 6, 333, 200, 300
+    q = torch.randn(nq, Q, E, generator=g)
+    d = torch.randn(nq * C, D, E, generator=g)
+    q_len = torch.tensor([Q, min(Q, 17), min(Q, 12), min(Q, 7), 3, 1])
+    d_len = torch.randint(0, D + 1, (nq * C,), generator=g)
+    d_len[:5] = torch.tensor([0, 1, 31, 32, 200])
+    for p_ in range(0, nq * C, 3):                                     # planted exact / near matches
+        i = p_ // C
+        if d_len[p_] > 0:
+            d[p_, int(torch.randint(0, int(d_len[p_]), (1,), generator=g))] = q[i, int(torch.randint(0, int(q_len[i]), (1,), generator=g))] * 2.0
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D)[None] < d_len[:, None]).float()
+    dm[7, 3] = 0.0
+    dm[400, 0] = 0.0                                                   # holes: per-position validity bits
+    qm[1, 0] = 0.0
+    alpha = torch.rand(11, generator=g) + 0.5
+    w = torch.randn(11, generator=g) * 0.2
+    mu, sg = torch.tensor(MU), torch.tensor(SIGMA)
+    t = lambda x: x.to(dev)
+    out, pk = ops.kernel_pool(t(q), t(d), t(qm), t(dm), t(mu), t(sg), t(alpha), t(w), pairs_per_query=C, return_per_kernel=True)
+    out2 = ops.kernel_pool(t(q), t(d), t(qm), t(dm), t(mu), t(sg), t(alpha), t(w), pairs_per_query=C)
+    assert torch.equal(out, out2)
+    f = lambda x: x.double()
+    refs, refpk = [], []
+    for i in range(nq):
+        sl = slice(i * C, (i + 1) * C)
+        qi = f(q[i:i + 1]).expand(C, -1, -1).contiguous()
+        cos = TP.cosine_matrix(qi, f(d[sl])).unsqueeze(-1)
+        act = torch.exp(-torch.pow(cos - f(mu).view(1, 1, 1, -1), 2) / (2 * torch.pow(f(sg).view(1, 1, 1, -1), 2))) * f(dm[sl]).unsqueeze(1).unsqueeze(-1)
+        lg = torch.log(torch.clamp(act.sum(2) * f(alpha).view(1, 1, -1), min=1e-10)) * f(qm[i]).view(1, -1, 1)
+        refpk.append(lg.sum(1))
+        refs.append(lg.sum(1) @ f(w))
+    ref, ref_pk = torch.cat(refs).numpy(), torch.cat(refpk).numpy()
+    np.testing.assert_allclose(pk.cpu().numpy(), ref_pk, atol=5e-3, rtol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=util.TOL_FP32)
+    # permutation inside every list: bit-equal (nothing may depend on which wavefront scores a pair)
+    perm = torch.cat([torch.randperm(C, generator=g) + i * C for i in range(nq)])
+    outp = ops.kernel_pool(t(q), t(d[perm].contiguous()), t(qm), t(dm[perm].contiguous()), t(mu), t(sg), t(alpha), t(w), pairs_per_query=C)
+    assert torch.equal(outp.cpu(), out.cpu()[perm])
+    # the same pairs in the pair-per-row layout (one-wavefront-per-SIMD kernel): same arithmetic class
+    rep = ops.kernel_pool(t(q.repeat_interleave(C, 0).contiguous()), t(d), t(qm.repeat_interleave(C, 0).contiguous()), t(dm), t(mu), t(sg),
+                          t(alpha), t(w), pairs_per_query=1)
+    np.testing.assert_allclose(rep.cpu().numpy(), out.cpu().numpy(), rtol=2e-6, atol=2e-5)

@@ -205,7 +205,7 @@ def run_tk_rank(name, nq=16, C=1000):
     dm = (torch.arange(D)[None] < d_len[sel, None]).float()
     out_pp = ops.kernel_pool(q[:2].repeat_interleave(C, 0).contiguous().to(dev), d[sel].to(dev), qm.to(dev), dm.to(dev), mu.to(dev),
                              sg.to(dev), alpha.to(dev), w.to(dev), pairs_per_query=1).cpu().numpy()
-    np.testing.assert_allclose(out_pp, out[sel], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(out_pp, out[sel], atol=2e-5, rtol=0)     # (another kernel: K order differs)
     r32, r64 = _tk_oracles(q, d, q_len, d_len, C, alpha, w)
     np.testing.assert_allclose(out, r64, atol=util.TOL_FP32)               # every pair, not a sample
     rows = []
