@@ -68,6 +68,37 @@ __global__ void __launch_bounds__(256) pack_mask_kernel(const T* __restrict__ ma
   if (lane == 0) len_out[row] = last;
 }
 
+// The same for the query AND the document masks of one call in ONE launch (eval.py-sized calls of 512 pairs are
+// launch-bound on the host side: every launch saved is ~4 us of the ~20 us a call costs).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_mask2_kernel(const T* __restrict__ m0, int64_t rows0, int L0, int words0,
+                                                         int32_t* __restrict__ len0, uint32_t* __restrict__ bits0, int nblk0,
+                                                         const T* __restrict__ m1, int64_t rows1, int L1, int words1,
+                                                         int32_t* __restrict__ len1, uint32_t* __restrict__ bits1) {
+  const int lane = threadIdx.x & 63;
+  const bool second = (int)blockIdx.x >= nblk0;
+  const int64_t row = (int64_t)(second ? blockIdx.x - nblk0 : blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t rows = second ? rows1 : rows0;
+  if (row >= rows) return;
+  const int L = second ? L1 : L0, words = second ? words1 : words0;
+  const T* m = (second ? m1 : m0) + row * L;
+  int32_t* len_out = second ? len1 : len0;
+  uint32_t* bits_out = second ? bits1 : bits0;
+  int last = 0;
+  for (int base = 0; base < L; base += 64) {
+    const int j = base + lane;
+    const bool v = (j < L) && (m[j] != T(0));
+    const unsigned long long b = __ballot(v);
+    if (lane == 0) {
+      const int w = base >> 5;
+      bits_out[row * words + w] = (uint32_t)b;
+      if (w + 1 < words) bits_out[row * words + w + 1] = (uint32_t)(b >> 32);
+    }
+    if (b) last = base + 64 - __builtin_clzll(b);
+  }
+  if (lane == 0) len_out[row] = last;
+}
+
 size_t packed_mask_bytes(int kind, int64_t rows, int L) {
   if (kind == MM_MASK_U8 || kind == MM_MASK_I64 || kind == MM_MASK_F32) {
     const int words = (L + 31) / 32;
@@ -116,6 +147,39 @@ int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, siz
     default:
       return set_error(MM_EINVAL, "unknown mask kind %d", kind);
   }
+}
+
+int resolve_mask_pair(const void* m0, int kind0, int64_t rows0, int L0, PackedMask* out0, const void* m1, int kind1,
+                      int64_t rows1, int L1, PackedMask* out1, char** ws, size_t* ws_left, hipStream_t stream) {
+  const bool dense0 = kind0 == MM_MASK_U8 || kind0 == MM_MASK_I64 || kind0 == MM_MASK_F32;
+  if (!(dense0 && kind1 == kind0 && m0 && m1)) {  // not two dense masks of one element type: one at a time
+    if (int e = resolve_mask(m0, kind0, rows0, L0, ws, ws_left, stream, out0)) return e;
+    return resolve_mask(m1, kind1, rows1, L1, ws, ws_left, stream, out1);
+  }
+  const size_t need0 = packed_mask_bytes(kind0, rows0, L0), need1 = packed_mask_bytes(kind1, rows1, L1);
+  if (!*ws || *ws_left < need0 + need1)
+    return set_error(MM_EWORKSPACE, "workspace too small for mask packing: need %zu more bytes, have %zu", need0 + need1, *ws_left);
+  const int words0 = (L0 + 31) / 32, words1 = (L1 + 31) / 32;
+  int32_t* len0 = (int32_t*)*ws;
+  uint32_t* bits0 = (uint32_t*)(*ws + (size_t)rows0 * 4);
+  int32_t* len1 = (int32_t*)(*ws + need0);
+  uint32_t* bits1 = (uint32_t*)(*ws + need0 + (size_t)rows1 * 4);
+  *ws += need0 + need1;
+  *ws_left -= need0 + need1;
+  const int nblk0 = (int)((rows0 + 3) / 4), nblk1 = (int)((rows1 + 3) / 4);
+  const dim3 grid((unsigned)(nblk0 + nblk1)), block(256);
+  if (kind0 == MM_MASK_U8)
+    hipLaunchKernelGGL(pack_mask2_kernel<uint8_t>, grid, block, 0, stream, (const uint8_t*)m0, rows0, L0, words0, len0, bits0, nblk0,
+                       (const uint8_t*)m1, rows1, L1, words1, len1, bits1);
+  else if (kind0 == MM_MASK_I64)
+    hipLaunchKernelGGL(pack_mask2_kernel<int64_t>, grid, block, 0, stream, (const int64_t*)m0, rows0, L0, words0, len0, bits0, nblk0,
+                       (const int64_t*)m1, rows1, L1, words1, len1, bits1);
+  else
+    hipLaunchKernelGGL(pack_mask2_kernel<float>, grid, block, 0, stream, (const float*)m0, rows0, L0, words0, len0, bits0, nblk0,
+                       (const float*)m1, rows1, L1, words1, len1, bits1);
+  out0->len = len0; out0->bits = bits0;
+  out1->len = len1; out1->bits = bits1;
+  return check_launch("pack_mask2_kernel");
 }
 
 }  // namespace mm

@@ -334,7 +334,29 @@ constexpr int kSplitSteps = 6;  // full 16-wide K steps per 100-float slice
 
 // this lane's 12 chunks of one query-row slice (base = row + slice*400 + h*32) + the parked chunk 24
 // (left = row + slice*400 + 384); own vmcnt(0): runs once per query
+template <bool WAIT = true>
 __device__ __forceinline__ void load_q_slice_split(const char* base, const char* left, f32x4 (&qr)[13]) {
+  if constexpr (!WAIT) {
+    asm volatile(
+        "global_load_dwordx4 %0, %13, off\n\t"
+        "global_load_dwordx4 %1, %13, off offset:16\n\t"
+        "global_load_dwordx4 %2, %13, off offset:64\n\t"
+        "global_load_dwordx4 %3, %13, off offset:80\n\t"
+        "global_load_dwordx4 %4, %13, off offset:128\n\t"
+        "global_load_dwordx4 %5, %13, off offset:144\n\t"
+        "global_load_dwordx4 %6, %13, off offset:192\n\t"
+        "global_load_dwordx4 %7, %13, off offset:208\n\t"
+        "global_load_dwordx4 %8, %13, off offset:256\n\t"
+        "global_load_dwordx4 %9, %13, off offset:272\n\t"
+        "global_load_dwordx4 %10, %13, off offset:320\n\t"
+        "global_load_dwordx4 %11, %13, off offset:336\n\t"
+        "global_load_dwordx4 %12, %14, off"
+        : "=&v"(qr[0]), "=&v"(qr[1]), "=&v"(qr[2]), "=&v"(qr[3]), "=&v"(qr[4]), "=&v"(qr[5]), "=&v"(qr[6]),
+          "=&v"(qr[7]), "=&v"(qr[8]), "=&v"(qr[9]), "=&v"(qr[10]), "=&v"(qr[11]), "=&v"(qr[12])
+        : "v"(base), "v"(left)
+        : "memory");
+    return;
+  }
   asm volatile(
       "global_load_dwordx4 %0, %13, off\n\t"
       "global_load_dwordx4 %1, %13, off offset:16\n\t"
@@ -356,6 +378,18 @@ __device__ __forceinline__ void load_q_slice_split(const char* base, const char*
       : "memory");
 }
 
+
+// one vmcnt(0) for the loads of load_q_slice_split<false>: every register is an in/out operand, so no use of the data
+// can be scheduled above the wait (an asm load's destination counts as written when its statement ends)
+#define MM_Q13(A) "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]), "+v"(A[8]), "+v"(A[9]), "+v"(A[10]), "+v"(A[11]), "+v"(A[12])
+template <int NS>
+__device__ __forceinline__ void wait_q_slices(f32x4 (&raw)[NS][13]) {
+  if constexpr (NS == 1) asm volatile("s_waitcnt vmcnt(0)" : MM_Q13(raw[0])::"memory");
+  if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0)" : MM_Q13(raw[0]), MM_Q13(raw[1])::"memory");
+  if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(0)" : MM_Q13(raw[0]), MM_Q13(raw[1]), MM_Q13(raw[2])::"memory");
+  if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(0)" : MM_Q13(raw[0]), MM_Q13(raw[1]), MM_Q13(raw[2]), MM_Q13(raw[3])::"memory");
+}
+#undef MM_Q13
 
 template <int NS, int K, int NBUF, bool NT, bool TKL, bool W = false>
 __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in) {
@@ -450,19 +484,23 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
       const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
       float ss = 0.0f;
       f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+      // all 13 NS loads of the tile are in flight together: one memory round trip per query, not NS
+      f32x4 raw[NS][13];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        load_q_slice_split<false>(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw[s]);
+      wait_q_slices<NS>(raw);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        f32x4 raw[13];
-        load_q_slice_split(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw);
 #pragma unroll
         for (int p = 0; p < kSplitSteps; ++p) {
-          split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
+          split8(raw[s][2 * p], raw[s][2 * p + 1], qhi[s][p], qlo[s][p]);
           qhi[s][p] = to_agpr(qhi[s][p]);
           qlo[s][p] = to_agpr(qlo[s][p]);
-          ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
+          ss += sumsq4(raw[s][2 * p]) + sumsq4(raw[s][2 * p + 1]);
         }
-        if (h == 0) ss += sumsq4(raw[12]);  // both halves loaded the parked chunk: count it once
-        if (h == (s >> 1)) park[s & 1] = raw[12];
+        if (h == 0) ss += sumsq4(raw[s][12]);  // both halves loaded the parked chunk: count it once
+        if (h == (s >> 1)) park[s & 1] = raw[s][12];
       }
       split8(park[0], park[1], qhiL, qloL);
       qhiL = to_agpr(qhiL);
@@ -730,7 +768,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
   const uint32_t l_off = (uint32_t)(r * (kSC * 16) + 24 * 16);
 
   Rbf rbf;
-  load_rbf<K>(a.mu, a.sigma, nullptr, nullptr, rbf);
+  if constexpr (!COS) load_rbf<K>(a.mu, a.sigma, nullptr, nullptr, rbf);   // (the cosine hand-off evaluates no kernels here)
 
   const char* dbase = (const char*)a.d;
   // run of up to 4 consecutive packed chunks of one document starting at chunk p (inside [p, p1))
@@ -813,19 +851,23 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
       float ss = 0.0f;
       f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+      // all 13 NS loads of the tile are in flight together: one memory round trip per query, not NS
+      f32x4 raw[NS][13];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        load_q_slice_split<false>(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw[s]);
+      wait_q_slices<NS>(raw);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        f32x4 raw[13];
-        load_q_slice_split(qrow + s * (kSC * 16) + h * 32, qrow + s * (kSC * 16) + 24 * 16, raw);
 #pragma unroll
         for (int p = 0; p < kSplitSteps; ++p) {
-          split8(raw[2 * p], raw[2 * p + 1], qhi[s][p], qlo[s][p]);
+          split8(raw[s][2 * p], raw[s][2 * p + 1], qhi[s][p], qlo[s][p]);
           qhi[s][p] = to_agpr(qhi[s][p]);
           qlo[s][p] = to_agpr(qlo[s][p]);
-          ss += sumsq4(raw[2 * p]) + sumsq4(raw[2 * p + 1]);
+          ss += sumsq4(raw[s][2 * p]) + sumsq4(raw[s][2 * p + 1]);
         }
-        if (h == 0) ss += sumsq4(raw[12]);
-        if (h == (s >> 1)) park[s & 1] = raw[12];
+        if (h == 0) ss += sumsq4(raw[s][12]);
+        if (h == (s >> 1)) park[s & 1] = raw[s][12];
       }
       split8(park[0], park[1], qhiL, qloL);
       qhiL = to_agpr(qhiL);
@@ -936,27 +978,29 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       const int rows_blk = 40 * crun - i0 < 32 ? 40 * crun - i0 : 32;
       if (rows_blk < 32) va &= (1u << rows_blk) - 1u;
       if constexpr (COS) {
-        // Cosine rows are indexed by chunk SLOT (b * C + c): cos_out[(slot * 40 + position) * Q + token].  The chunks of a
-        // run sit in consecutive slots, so virtual row iv of the run is row slot0 * 40 + iv and the block's rows_blk x Q
-        // values are ONE contiguous span.  Written lane-by-token straight from the accumulators that was 16 store
-        // instructions of <= 2 x 80 B each per block, and every one of them queues behind the LDS-DMA stream (measured by
-        // removal: 21 us of stage 1's 160 on config 3's full documents); the tile is transposed through the ring slot the
-        // block just freed and leaves as ceil(rows_blk * Q / 256) full-width 16-B stores (3 at Q = 20) — all Q columns,
-        // the ones past the query's effective length are never read.
+        // Cosine rows are indexed by document and position: document b owns cos_out[b * C * 40 * Q ...], and inside it the
+        // row of position n = c * 40 + p (chunk c, centre token p) starts at n * ql with ql = the query's effective
+        // length — only the ql real tokens are stored.  The chunks of a run sit in consecutive slots, so the block's
+        // rows_blk x ql values are ONE contiguous span.  Written lane-by-token straight from the accumulators that was 16
+        // store instructions of <= 2 x 80 B per block; the tile is transposed through the ring slot the block just freed
+        // and leaves as ceil(rows_blk * ql / 256) full-width 16-B stores (<= 3).  Measured by removal, the stores cost
+        // ~20 us of stage 1's 160 on config 3's full documents whatever their shape or cache policy (ordinary, nt,
+        // sc0 sc1: 257.7 / 259.0 / 260.4 us per call): it is the write traffic inside the read stream, so fewer bytes
+        // is what helps (no columns past ql: 24.5 MB instead of 42.6).
         float* T = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
-        const int n4 = (rows_blk * Q) >> 2;                    // rows_blk % 8 == 0
-        if (!(a.dbg & 1)) {
-          if (r < Q) {
+        const int n4 = (rows_blk * qlim) >> 2;                 // rows_blk % 8 == 0
+        if (!(a.dbg & 1) && qlim > 0) {
+          if (r < qlim) {
             const uint32_t vbits = va >> (4 * h);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               if (rowof(i) < rows_blk) {  // wave-uniform
                 const float c = (acc[i] * rq) * rdr[i];
-                T[(rowof(i) + 4 * h) * Q + r] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;   // masked: every kernel underflows to 0
+                T[(rowof(i) + 4 * h) * qlim + r] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;   // masked: every kernel underflows to 0
               }
             }
           }
-          f32x4* dst = (f32x4*)(a.cos_out + ((int64_t)slot0 * 40 + 32 * t) * Q);
+          f32x4* dst = (f32x4*)(a.cos_out + qi * ((int64_t)a.C * 40 * Q) + ((int64_t)(slot0 - (int)qi * a.C) * 40 + 32 * t) * qlim);
           for (int l = lane; l < n4; l += 64) dst[l] = ((const f32x4*)T)[l];
           nst = (n4 + 63) >> 6;
           pre = inflight;
@@ -1225,8 +1269,7 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
   a.dw = d_gate; a.clamp_min = clamp_min; a.pair_q = pair_query;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
-  if (int e = resolve_mask(q_mask, q_mask_kind, q_rows, Q, &ws, &left, stream, &a.qm)) return e;
-  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (int e = resolve_mask_pair(q_mask, q_mask_kind, q_rows, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
   if (K == 11) return launch_k<11>(a, stream);
   // any other kernel count (the lists in tk_kernels_mu / knrm_kernels are configuration): the generic kernel with
   // run-time K
@@ -1286,8 +1329,7 @@ extern "C" int mm_kernel_pool_multi_fwd(const void* const* q_list, int n_q, cons
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   const int64_t q_rows = (n_pairs + pairs_per_query - 1) / pairs_per_query;
-  if (int e = resolve_mask(q_mask, q_mask_kind, q_rows, Q, &ws, &left, stream, &a.qm)) return e;
-  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (int e = resolve_mask_pair(q_mask, q_mask_kind, q_rows, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
   const size_t need = (size_t)a.n_mblk * (size_t)n_pairs * 4;
   if (!ws || left < need) return set_error(MM_EWORKSPACE, "kernel_pool_multi: workspace needs %zu more bytes", need);
   float* partial = (float*)ws;

@@ -36,7 +36,8 @@ struct KpArgs {
   int32_t* slot2p;
   int64_t n_slots;
   // TKL, cosine hand-off (tkl_stage1_run_kernel<COS>): instead of the pair sums stage 1 stores the scaled, masked
-  // cosines themselves, cos_out[(p * 40 + position) * Q + query token] (masked position: 1e5, which underflows every
+  // cosines themselves, cos_out[b * C * 40 * Q + (c * 40 + position) * ql + query token] (ql = the query's effective
+  // length: only real tokens are stored; masked position: 1e5, which underflows every
   // kernel to exactly 0), and the window kernel evaluates the RBF kernels while it stages its tile — 4 bytes per
   // (position, token) across HBM instead of 24, and the transcendental work runs on sixteen thin wavefronts per CU
   // instead of one fat wavefront per SIMD
@@ -116,17 +117,56 @@ __device__ __forceinline__ float sload_f32(const float* base, int idx) {
   return __builtin_bit_cast(float, sload_u32(base, idx));
 }
 
+// K wave-uniform floats through the scalar cache with ONE wait (a wait per value made the 44 parameter loads of a
+// wavefront's prologue a chain of 44 scalar-cache round trips — microseconds before the first LDS-DMA was issued,
+// which shows on eval.py-sized calls and on TKL's short stage-1 launches)
+template <int K>
+__device__ __forceinline__ void sload_vec(const float* base, float (&out)[kMaxK]) {
+  static_assert(K == 11, "instantiated for the reference's 11 kernels");
+  uint32_t v[11];
+  asm volatile(
+      "s_load_dword %0, %11, 0x0\n\t"
+      "s_load_dword %1, %11, 0x4\n\t"
+      "s_load_dword %2, %11, 0x8\n\t"
+      "s_load_dword %3, %11, 0xc\n\t"
+      "s_load_dword %4, %11, 0x10\n\t"
+      "s_load_dword %5, %11, 0x14\n\t"
+      "s_load_dword %6, %11, 0x18\n\t"
+      "s_load_dword %7, %11, 0x1c\n\t"
+      "s_load_dword %8, %11, 0x20\n\t"
+      "s_load_dword %9, %11, 0x24\n\t"
+      "s_load_dword %10, %11, 0x28\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]), "=&s"(v[3]), "=&s"(v[4]), "=&s"(v[5]), "=&s"(v[6]), "=&s"(v[7]), "=&s"(v[8]),
+        "=&s"(v[9]), "=&s"(v[10])
+      : "s"(base));
+#pragma unroll
+  for (int k = 0; k < 11; ++k) out[k] = __builtin_bit_cast(float, v[k]);
+}
+
 // Kernel parameters are wave-uniform: fetch them through the scalar cache (SGPRs, no vmcnt traffic
 // that would make the compiler drain the LDS-DMA queue inside the block loop).
 template <int K>
 __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, const float* alpha, const float* w, Rbf& rbf) {
+  float sg[kMaxK];
+  if constexpr (K == 11) {
+    sload_vec<K>(sigma, sg);
+    sload_vec<K>(mu, rbf.mu);
+    if (alpha) sload_vec<K>(alpha, rbf.alpha);
+    if (w) sload_vec<K>(w, rbf.w);
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const float sg = sload_f32(sigma, k);
-    rbf.mu[k] = sload_f32(mu, k);
-    rbf.c2[k] = -1.4426950408889634f / (2.0f * sg * sg);
-    rbf.alpha[k] = alpha ? sload_f32(alpha, k) : 1.0f;
-    rbf.w[k] = w ? sload_f32(w, k) : 0.0f;
+    if constexpr (K != 11) {
+      sg[k] = sload_f32(sigma, k);
+      rbf.mu[k] = sload_f32(mu, k);
+      rbf.alpha[k] = alpha ? sload_f32(alpha, k) : 1.0f;
+      rbf.w[k] = w ? sload_f32(w, k) : 0.0f;
+    } else {
+      if (!alpha) rbf.alpha[k] = 1.0f;
+      if (!w) rbf.w[k] = 0.0f;
+    }
+    rbf.c2[k] = -1.4426950408889634f / (2.0f * sg[k] * sg[k]);
   }
   pack_rbf<K>(rbf);
 }

@@ -630,8 +630,7 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
     a.dm64 = (const int64_t*)d_mask;
     return maxsim_pair_launch(a, dtype, true, stream);
   }
-  if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;
-  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (int e = resolve_mask_pair(q_mask, q_mask_kind, nq, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
   if (pair_kernel) return maxsim_pair_launch(a, dtype, false, stream);
   const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && Q <= 64 &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);

@@ -61,6 +61,10 @@ size_t packed_mask_bytes(int kind, int64_t rows, int L);
 int resolve_mask(const void* mask, int kind, int64_t rows, int L, char** ws, size_t* ws_left,
                  hipStream_t stream, PackedMask* out, int64_t row_stride = 0, int col0 = 0);
 
+// Both masks of a call: two dense masks of one element type are packed by ONE launch (else one resolve_mask each).
+int resolve_mask_pair(const void* m0, int kind0, int64_t rows0, int L0, PackedMask* out0, const void* m1, int kind1,
+                      int64_t rows1, int L1, PackedMask* out1, char** ws, size_t* ws_left, hipStream_t stream);
+
 constexpr int kK = 11;   // RBF kernels of TK / TKL (tk.yaml:18-19, tkl.yaml)
 constexpr int kKC = 12;  // K + the non-zero-count channel of TKL's pair sums
 

@@ -20,7 +20,8 @@ namespace mm {
 constexpr int kU = 20;        // position pairs per chunk
 constexpr int kWinPairs = 15; // 30 positions, stride 2
 constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows staged: kWT + 14)
-constexpr int kWThreads = 512;
+constexpr int kWThreads = 256;
+constexpr int kTokGroup = 10;  // query tokens per window workgroup (see tkl_window_kernel)
 
 
 // Preparation in ONE launch (round 1: memset + emb + two mask packs + slot map = five, ~25 us of a 0.3 ms call) —
@@ -186,13 +187,13 @@ __host__ __device__ inline size_t window_pass_bytes(int wt, int ql) {
   return ((size_t)(wt + kWinPairs - 1) * ql * kKC + ((ql + 3) & ~3) + (size_t)wt * (ql | 1)) * 4 + 32;
 }
 #ifndef MM_WIN_LDS
-#define MM_WIN_LDS (80 * 1024)      // -D overrides for A/B builds only
+#define MM_WIN_LDS (40 * 1024 - 512)      // -D overrides for A/B builds only
 #endif
-constexpr int kWindowLds = MM_WIN_LDS;     // two workgroups per CU: one stages its rows while the other evaluates
+constexpr int kWindowLds = MM_WIN_LDS;     // four workgroups per CU (a 64-window tile of 10 tokens: 40,336 B)
 
 // One workgroup = kWT consecutive windows of one document, in passes of wt = 64 / 32 / 16 windows — the largest that
 // fits the workgroup's LDS at the document's effective query length.
-// COS: `ps` holds stage 1's scaled, masked cosines cos[(p * 40 + position) * Q + token] (KpArgs::cos_out) and the pair
+// COS: `ps` holds stage 1's scaled, masked cosines (KpArgs::cos_out: per document, rows of ql real tokens) and the pair
 // rows of the tile are EVALUATED here while they are staged (RBF kernels of the two positions of a pair + the
 // non-zero count, the arithmetic of kernel_pool.hip's tkl_block_run), instead of being read back from a 6x larger
 // pair-sum buffer.
@@ -207,8 +208,19 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   const int b = blockIdx.y;
   const int w0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
+  // Token groups: workgroup z evaluates query tokens [kTokGroup z, kTokGroup (z + 1)) of its 64 windows and writes a partial
+  // window score (summed over ITS tokens) to plane z of `win`; the region kernel adds the planes in order.  A tile of
+  // 10 tokens is 37 KiB of LDS instead of 75: FOUR independent 256-thread workgroups per CU instead of two of 512 —
+  // the kernel is a chain of latencies (lookups, cosine rows, barrier, evaluation, barrier), and the number of tiles
+  // in flight per CU is what hides them.
+  const int t0 = blockIdx.z * kTokGroup;
+  win += (int64_t)blockIdx.z * gridDim.y * W;
+  q_mask += t0;
   int ql = q_len ? q_len[b] : Q;                      // effective query length (rows of later tokens do not exist)
   ql = ql < 0 ? 0 : (ql > Q ? Q : ql);
+  const int qfull = ql;                               // row stride of this document's cosine rows (stage 1 stores real tokens only)
+  ql = ql - t0 < kTokGroup ? ql - t0 : kTokGroup;     // this group's tokens (local index i = token t0 + i)
+  if (ql <= 0) return;                                // no token of this group is real: the region kernel skips the plane
   int wt = kWT;
   while (wt > 4 && window_pass_bytes(wt, ql) > (size_t)lds_bytes) wt >>= 1;
   const int nu = wt + kWinPairs - 1;                  // pair rows needed by one pass
@@ -243,9 +255,9 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
         const int ug = ws_ + j;
         const int c = ug / kU, uu = ug - c * kU;
         if (c < C) {
-          const float* src = ps + (((int64_t)b * C + c) * 40 + 2 * uu) * Q + i;
+          const float* src = ps + (int64_t)b * C * 40 * Q + ((int64_t)c * 40 + 2 * uu) * qfull + t0 + i;
           ca[s] = src[0];
-          cb[s] = src[Q];
+          cb[s] = src[qfull];
           cl[s] = c - c0;                                                // <= (19 + kWT + 14) / 20 < 8
         }
       }
@@ -261,12 +273,12 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
     const int cb = (w0 + kWT + kWinPairs - 2) / kU - c0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) live = live || (c <= cb && cinfo[c] >= 0);
-    if (!live || ql == 0) {
+    if (!live) {
       if (tid < kWT && w0 + tid < W) win[(int64_t)b * W + w0 + tid] = 0.0f;
       return;
     }
   }
-  if (SAT == MM_TKL_SAT_EMBEDDING && tid < ql) emb[tid] = emb_g[(int64_t)b * Q + tid];
+  if (SAT == MM_TKL_SAT_EMBEDDING && tid < ql) emb[tid] = emb_g[(int64_t)b * Q + t0 + tid];
   const float* sp = prm + TklParams::sat();
   for (int ws = w0; ws < w0 + kWT && ws < W; ws += wt) {
     // the thread index is re-materialised per pass: with everything derived from it loop-invariant the compiler
@@ -358,7 +370,7 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
             const int j = idx / row4, v = idx - j * row4;
             const int ug = ws + j;
             const int c = ug / kU, uu = ug - c * kU;
-            off[s] = uu * srcf + v * 4;
+            off[s] = uu * srcf + t0 * kKC + v * 4;
             const int info = cinfo[c - c0];                                // c - c0 <= (19 + kWT + 14) / 20 < 8
             // rows of unwritten blocks are zeros
             if (info >= 0 && uu < 16 * (info & 3)) pidx[s] = info >> 2;
@@ -404,8 +416,9 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
 // One 256-thread workgroup per document: region top-k over the window scores (:254-286).  (One wavefront per
 // document spent 16 us on sixteen dependent 4-byte loads per lane; four wavefronts load the ~1,000 scores of a
 // 2,048-token document in four rounds and share the arg-max.)
-__global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict__ win, const float* __restrict__ prm,
-                                                         float* __restrict__ out, int W) {
+__global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict__ part, int n_planes, int64_t plane,
+                                                         const int32_t* __restrict__ q_len, float* __restrict__ win,
+                                                         const float* __restrict__ prm, float* __restrict__ out, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float rv[4];
   __shared__ int ri[4];
@@ -413,8 +426,20 @@ __global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict
   const int Wp = W < 3 ? 3 : W;                                        // :254-255
   float* orig = (float*)smem;                                          // [Wp]
   float* work = orig + Wp;                                             // [Wp]
+  // window score = sum over the token groups' planes in order (:249); planes whose tokens are all past the query's
+  // effective length were never written and count as zeros.  The sum is also the window-score output (win).
+  int np = n_planes;
+  if (q_len) {
+    const int ql = q_len[b];
+    np = ql <= 0 ? 0 : (ql + kTokGroup - 1) / kTokGroup;
+    np = np < n_planes ? np : n_planes;
+  }
   for (int w = tid; w < Wp; w += 256) {
-    float s = w < W ? win[(int64_t)b * W + w] : 0.0f;
+    float s = 0.0f;
+    if (w < W) {
+      for (int g = 0; g < np; ++g) s += part[g * plane + (int64_t)b * W + w];
+      if (win != part || np != 1) win[(int64_t)b * W + w] = s;
+    }
     if (s == 0.0f) s = -9900.0f;                                       // :257
     orig[w] = s;
     work[w] = s;
@@ -482,7 +507,8 @@ extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int
   const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
   return align256((size_t)B * C * 4) + handoff_bytes(B, P, C, Q) +
          packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4) +
-         packed_mask_bytes(MM_MASK_F32, B, Q);  // + the packed query mask (effective lengths)
+         packed_mask_bytes(MM_MASK_F32, B, Q) +  // + the packed query mask (effective lengths)
+         align256((size_t)((Q + kTokGroup - 1) / kTokGroup) * B * W * 4);  // + the token groups' partial window scores
 }
 
 extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
@@ -518,6 +544,8 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   // past them are masked in :248, so stage 1 does not write their pair rows and stage 2 does not evaluate them),
   // chunk masks (effective length + validity bits of the 40 centre tokens)
   PackedMask qmk, dm;
+  float* planes = nullptr;                              // [n_planes][B][W] partial window scores of the token groups
+  const int n_planes = (Q + kTokGroup - 1) / kTokGroup;
   {
     if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
     const size_t need_dm = packed_mask_bytes(MM_MASK_F32, P, 40);
@@ -525,6 +553,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     int32_t* clen = (int32_t*)ws;
     uint32_t* cbits = (uint32_t*)(ws + (size_t)P * 4);
     char* qws = (char*)emb + align256((size_t)B * Q * 4);
+    planes = (float*)(qws + packed_mask_bytes(MM_MASK_F32, B, Q));
     int32_t* qlen = (int32_t*)qws;
     uint32_t* qbits = (uint32_t*)(qws + (size_t)B * 4);
     const int n_fill = (int)((B * (int64_t)C + 255) / 256);
@@ -552,14 +581,17 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   {
     // LDS per workgroup: the whole 64-window tile when that leaves room for a second workgroup on the CU, otherwise
     // kWindowLds and the kernel makes passes of 32 / 16 windows for the documents whose queries need it
-    const size_t full = window_pass_bytes(kWT, Q);
+    const int qg = Q < kTokGroup ? Q : kTokGroup;                   // tokens per workgroup
+    const size_t full = window_pass_bytes(kWT, qg);
     const size_t lds2 = full < (size_t)kWindowLds ? full : (size_t)kWindowLds;
-    if (window_pass_bytes(8, Q) > lds2) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
-    const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B);
+    if (window_pass_bytes(8, qg) > lds2) return set_error(MM_EUNSUPPORTED, "tkl: Q=%d too large for the window kernel's LDS tile", Q);
+    if (n_planes > 65535 || B > 65535) return set_error(MM_EUNSUPPORTED, "tkl: grid limits (B=%lld, Q=%d)", (long long)B, Q);
+    const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B, (unsigned)n_planes);
+    float* wdst = n_planes > 1 ? planes : win;                         // one group: its plane IS the window-score output
     auto launch = [&](auto kern) {
       if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, grid2, dim3(kWThreads), lds2, stream, (const float*)ps, (const int32_t*)slot2p, (const float*)emb, q_mask,
-                         (const int32_t*)qmk.len, params, win, C, Q, W, (int)lds2);
+                         (const int32_t*)qmk.len, params, wdst, C, Q, W, (int)lds2);
     };
     if (saturation == MM_TKL_SAT_EMBEDDING) {
       if (use_cos) launch(tkl_window_kernel<MM_TKL_SAT_EMBEDDING, true>);
@@ -571,6 +603,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     if (int e = check_launch("tkl_window_kernel")) return e;
   }
   const int Wp = W < 3 ? 3 : W;
-  hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(256), (size_t)Wp * 8, stream, win, params, out, W);
+  hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(256), (size_t)Wp * 8, stream,
+                     (const float*)(n_planes > 1 ? planes : win), n_planes, (int64_t)B * W, (const int32_t*)qmk.len, win, params, out, W);
   return check_launch("tkl_region_kernel");
 }

@@ -79,6 +79,34 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+# Mask-packing workspaces of the scoring calls, one per (device, stream): calls on one stream are ordered, so the
+# next call may reuse the buffer; eval.py-sized calls (512 pairs) are host-bound and a torch.empty per call is ~2 us
+# of their ~15.  Not used under graph capture (a captured graph must not reference a buffer a later call may replace).
+_WS = {}
+
+
+def _workspace(dev, nbytes: int):
+    if nbytes == 0:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        if len(_WS) > 64:
+            _WS.clear()
+        t = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _WS[key] = t
+    return t
+
+
+def _vec(t: torch.Tensor) -> torch.Tensor:
+    """float32 contiguous 1-D view of a small parameter tensor (no copy, no dispatch when it already is one)."""
+    if t.dtype is torch.float32 and t.dim() == 1 and t.is_contiguous() and not t.requires_grad:
+        return t
+    return t.detach().reshape(-1).to(torch.float32).contiguous()
+
+
 def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = None,
            d_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1) -> torch.Tensor:
     """ColBERT MaxSim (matchmaker/models/colbert.py:68-75; unmasked: :100-112).
@@ -105,7 +133,7 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
     q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
     with torch.cuda.device(dev):
         wsb = L.mm_maxsim_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        ws = _workspace(dev, wsb)
         rc = L.mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), B, pairs_per_query,
                              Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
     _lib.check(rc, "mm_maxsim_fwd")
@@ -270,8 +298,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     else:
         pq = None
     K = mu.numel()
-    f = lambda t: t.detach().reshape(-1).to(torch.float32).contiguous()
-    mu, sigma, alpha, w = f(mu), f(sigma), f(alpha), f(w)
+    mu, sigma, alpha, w = _vec(mu), _vec(sigma), _vec(alpha), _vec(w)
     if not (sigma.numel() == alpha.numel() == w.numel() == K):
         raise NativeError("kernel_pool: mu/sigma/alpha/w must all have K elements")
     qm, qp, qk = _mask(q_mask, nq, Q, "q_mask")
@@ -284,7 +311,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
         q, d, E = _pad_rows(q, d, 4)
         with torch.cuda.device(dev):
             wsb = L.mm_kernel_pool_workspace_bytes(max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+            ws = _workspace(dev, wsb)
             rc = L.mm_kernel_pool_ex_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
                                          gate.data_ptr() if gate is not None else None,
                                          pq.data_ptr() if pq is not None else None, nq, mu.data_ptr(),
@@ -499,10 +526,11 @@ def dot_topk(queries: torch.Tensor, corpus: torch.Tensor, k: int, max_rounds: in
     if N == 0:
         return out_s.fill_(float("-inf")), out_i.fill_(-1)
 
-    def run(q, scale):
+    def run(q, scale, s=None, i=None):
         n = q.shape[0]
-        s = torch.empty((n, k), dtype=torch.float32, device=dev)
-        i = torch.empty((n, k), dtype=torch.int64, device=dev)
+        if s is None:
+            s = torch.empty((n, k), dtype=torch.float32, device=dev)
+            i = torch.empty((n, k), dtype=torch.int64, device=dev)
         st = torch.empty(n, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             wsb = L.mm_dot_topk_workspace_bytes(N, n, k)
@@ -512,12 +540,10 @@ def dot_topk(queries: torch.Tensor, corpus: torch.Tensor, k: int, max_rounds: in
         _lib.check(rc, "mm_dot_topk_fwd")
         return s, i, st
 
-    s, i, st = run(queries, 1.0)
-    out_s.copy_(s)
-    out_i.copy_(i)
-    bad = torch.nonzero(st != 0).flatten().tolist()   # one small D2H: the exactness check
-    if not bad:
+    _, _, st = run(queries, 1.0, out_s, out_i)        # straight into the caller's tensors (no 84 MB staging copy)
+    if int(st.max()) == 0:                            # one 4-byte D2H: the exactness check of the status vector
         return out_s, out_i
+    bad = torch.nonzero(st != 0).flatten().tolist()
     # rare path: bisect the threshold scale per query (status 1 = too few survivors -> larger m,
     # status 2 = candidate list overflowed -> smaller m)
     codes = st[bad].tolist()
