@@ -550,6 +550,15 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
         }
         x[12] = *(const f32x4*)(buf + l_off);
         __builtin_amdgcn_sched_barrier(0);
+        // The slice is in registers: its slot goes back to the producer NOW, before the split / MFMA work, so that three
+        // slices instead of two are in flight while this one is computed (the kernel waits on memory most of the time
+        // with one wavefront per SIMD).  Not after a block's LAST slice: the epilogue borrows that slot as scratch.
+        const bool early = s + 1 < NS;
+        if (early) {
+          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+          --inflight;
+          top_up();
+        }
         bf16x8 ah, al;
         split8(x[0], x[1], ah, al);
 #pragma unroll
@@ -579,8 +588,10 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
         const f32x4 xl = x[12];
         if (h == 0) ss2 += f32x2{xl[0] * xl[0] + xl[1] * xl[1], xl[2] * xl[2] + xl[3] * xl[3]};
         if (h == (s >> 1)) park[s & 1] = xl;
-        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
-        --inflight;
+        if (!early) {
+          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+          --inflight;
+        }
       }
       {
         bf16x8 ah, al;
@@ -910,6 +921,12 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
           --inflight;
           continue;
         }
+        const bool early = s + 1 < NS;   // as in kernel_pool_split_kernel: the slot goes back before the split / MFMA work
+        if (early) {
+          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+          --inflight;
+          top_up();
+        }
         bf16x8 ah, al;
         split8(x[0], x[1], ah, al);
 #pragma unroll
@@ -939,8 +956,10 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
         const f32x4 xl = x[12];
         if (h == 0) ss2 += f32x2{xl[0] * xl[0] + xl[1] * xl[1], xl[2] * xl[2] + xl[3] * xl[3]};
         if (h == (s >> 1)) park[s & 1] = xl;
-        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
-        --inflight;
+        if (!early) {
+          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+          --inflight;
+        }
       }
       {
         bf16x8 ah, al;

@@ -100,6 +100,23 @@ def _workspace(dev, nbytes: int):
     return t
 
 
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on(dev):
+    """Device guard for the native call: torch's context manager costs ~2-3 us per call, which is visible on 512-pair
+    calls; nothing to guard when `dev` already is the current device (the single-GPU-per-process case)."""
+    return _NOCTX if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def _vec(t: torch.Tensor) -> torch.Tensor:
     """float32 contiguous 1-D view of a small parameter tensor (no copy, no dispatch when it already is one)."""
     if t.dtype is torch.float32 and t.dim() == 1 and t.is_contiguous() and not t.requires_grad:
@@ -131,7 +148,7 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
     if B == 0:
         return out
     q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
-    with torch.cuda.device(dev):
+    with _on(dev):
         wsb = L.mm_maxsim_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
         ws = _workspace(dev, wsb)
         rc = L.mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), B, pairs_per_query,
@@ -309,7 +326,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
     if B:
         q, d, E = _pad_rows(q, d, 4)
-        with torch.cuda.device(dev):
+        with _on(dev):
             wsb = L.mm_kernel_pool_workspace_bytes(max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
             ws = _workspace(dev, wsb)
             rc = L.mm_kernel_pool_ex_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
