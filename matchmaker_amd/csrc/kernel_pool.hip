@@ -391,17 +391,28 @@ __device__ __forceinline__ void wait_q_slices(f32x4 (&raw)[NS][13]) {
 }
 #undef MM_Q13
 
-template <int NS, int K, int NBUF, bool NT, bool TKL, bool W = false>
-__global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in) {
+// WPP = 2 (eval.py-sized calls: fewer pairs than wavefront slots, defaults.yaml:115 batch_size_eval 512): TWO
+// wavefronts per pair — wavefront w of the 128-thread workgroup streams the pair's blocks w, w + 2, ... through its own
+// ring, the kernel sums of the two meet in LDS once per pair and wavefront 0 pools.  A 200-token document is 4 + 3
+// blocks instead of 7 in a row on one wavefront while half of the chip's wavefront slots idle.
+template <int NS, int K, int NBUF, bool NT, bool TKL, bool W = false, int WPP = 1>
+__global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArgs a_in) {
   static_assert(!(TKL && W), "the gate is a TK-Sparse feature");
+  static_assert(WPP == 1 || (WPP == 2 && !TKL && !W), "two wavefronts per pair: plain TK pooling only");
   const KpArgs a = kp_block_args(a_in);
   static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int lane = threadIdx.x & 63;
+  const int wv = WPP > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;   // wave-uniform for the compiler too
+  constexpr int kWaveLds = NBUF * kSliceBytes + 128;
+  char* smem = smem_all + (WPP > 1 ? wv * kWaveLds : 0);
+  // WPP = 2: wavefront 1's partial kernel sums, [64 lanes][12], in the head of ITS ring — idle by then, because a
+  // two-wavefront workgroup scores exactly one pair (two rings + scratch beside them would be 83 KB: one workgroup per CU)
+  float* comb = (float*)(smem_all + kWaveLds);
   const int r = lane & 31, h = lane >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
-  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
-  if (p0 >= p1) return;
+  const int64_t p0 = (int64_t)blockIdx.x * (WPP > 1 ? 1 : a.pairs_per_wave);
+  const int64_t p1 = WPP > 1 ? p0 + 1 : ((p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs);
+  if (p0 >= p1 || p0 >= a.n_pairs) return;
   constexpr int E = 100 * NS;
   constexpr int RB = E * 4;  // row bytes
   const int D = a.D, Q = a.Q;
@@ -433,8 +444,8 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
   };
 
   int64_t pp = p0;
-  int pt = 0, ps = 0, pn = 0;
-  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pt = wv, ps = 0, pn = 0;                          // this wavefront's blocks of a pair: wv, wv + WPP, ...
+  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) <= wv) ++pp;
   int pbuf = 0, cbuf = 0, inflight = 0;
   auto top_up = [&]() {
     while (pp < p1 && inflight < NBUF) {
@@ -444,10 +455,11 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
       ++inflight;
       if (++ps == NS) {
         ps = 0;
-        if (++pt == pn) {
-          pt = 0;
+        pt += WPP;
+        if (pt >= pn) {
+          pt = wv;
           ++pp;
-          while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+          while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) <= wv) ++pp;
         }
       }
     }
@@ -531,7 +543,7 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
       for (int j = lane; j < 32 * nb; j += 64) wbuf[j] = j < D ? gate_log2(gw[j]) : -INFINITY;
     }
 
-    for (int t = 0; t < nb; ++t) {
+    for (int t = wv; t < nb; t += WPP) {
       f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
       f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
       f32x2 ss2 = {0.0f, 0.0f};
@@ -641,7 +653,26 @@ __global__ void __launch_bounds__(64) kernel_pool_split_kernel(const KpArgs a_in
         rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
       }
     }
-    if (!TKL) {
+    if constexpr (WPP == 2) {
+      // both wavefronts hold partial sums in the same lane layout: wavefront 1 hands its twelve to wavefront 0 through LDS.
+      // Barriers that wait for LDS only (a __syncthreads() would drain the LDS-DMA prefetch of the next pair with vmcnt(0)).
+      if (wv == 1) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+          *(f32x4*)(comb + lane * 12 + 4 * v) = f32x4{pk2[2 * v][0], pk2[2 * v][1], pk2[2 * v + 1][0], pk2[2 * v + 1][1]};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (wv == 0) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          const f32x4 o = *(const f32x4*)(comb + lane * 12 + 4 * v);
+          pk2[2 * v] += f32x2{o[0], o[1]};
+          pk2[2 * v + 1] += f32x2{o[2], o[3]};
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // comb may be rewritten for the next pair
+    }
+    if (!TKL && wv == 0) {
       float pk[kMaxK];
       if (np > 2) {  // np consecutive lanes hold the partial sums of one query token
 #pragma unroll
@@ -921,7 +952,10 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
           --inflight;
           continue;
         }
-        const bool early = s + 1 < NS;   // as in kernel_pool_split_kernel: the slot goes back before the split / MFMA work
+        // as in kernel_pool_split_kernel: the slot goes back before the split / MFMA work — after EVERY slice with the cosine
+        // hand-off, whose epilogue needs no scratch (three slices in flight throughout: 159.8 -> 149.3 us with two of three
+        // slices released early, config 3's full documents)
+        const bool early = COS || s + 1 < NS;
         if (early) {
           cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
           --inflight;
@@ -999,29 +1033,26 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       if constexpr (COS) {
         // Cosine rows are indexed by document and position: document b owns cos_out[b * C * 40 * Q ...], and inside it the
         // row of position n = c * 40 + p (chunk c, centre token p) starts at n * ql with ql = the query's effective
-        // length — only the ql real tokens are stored.  The chunks of a run sit in consecutive slots, so the block's
-        // rows_blk x ql values are ONE contiguous span.  Written lane-by-token straight from the accumulators that was 16
-        // store instructions of <= 2 x 80 B per block; the tile is transposed through the ring slot the block just freed
-        // and leaves as ceil(rows_blk * ql / 256) full-width 16-B stores (<= 3).  Measured by removal, the stores cost
-        // ~20 us of stage 1's 160 on config 3's full documents whatever their shape or cache policy (ordinary, nt,
-        // sc0 sc1: 257.7 / 259.0 / 260.4 us per call): it is the write traffic inside the read stream, so fewer bytes
-        // is what helps (no columns past ql: 24.5 MB instead of 42.6).
-        float* T = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
-        const int n4 = (rows_blk * qlim) >> 2;                 // rows_blk % 8 == 0
-        if (!(a.dbg & 1) && qlim > 0) {
-          if (r < qlim) {
-            const uint32_t vbits = va >> (4 * h);
+        // length — only the ql real tokens are stored.  The chunks of a run sit in consecutive slots, so virtual row iv of
+        // the run is position (slot0 % C) * 40 + iv of its document.  Lane (token r, half h) stores its 16 rows directly:
+        // 16 store instructions of <= 2 x ql x 4 B per block.  Measured by removal the stores cost ~20 us of stage 1's 160
+        // on config 3's full documents WHATEVER their shape or cache policy — transposed through LDS into 3 full-width
+        // 16-B stores per block: 160.6 vs 160.5 us; ordinary / nt / sc0 sc1: 257.7 / 259.0 / 260.4 us per call — it is the
+        // write traffic inside the read stream, so fewer bytes is what helps (no columns past ql: 24.5 MB, not 42.6),
+        // and the direct form leaves the ring slot free for an early hand-back.
+        if (!(a.dbg & 1) && r < qlim) {
+          float* dst = a.cos_out + qi * ((int64_t)a.C * 40 * Q) + ((int64_t)(slot0 - (int)qi * a.C) * 40 + 32 * t + 4 * h) * qlim + r;
+          const uint32_t vbits = va >> (4 * h);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              if (rowof(i) < rows_blk) {  // wave-uniform
-                const float c = (acc[i] * rq) * rdr[i];
-                T[(rowof(i) + 4 * h) * qlim + r] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;   // masked: every kernel underflows to 0
-              }
+          for (int i = 0; i < 16; ++i) {
+            if (rowof(i) < rows_blk) {  // wave-uniform: rows_blk is a multiple of 8 and rowof(i) + 4h stays in rowof(i)'s group of 8
+              const float c = (acc[i] * rq) * rdr[i];
+              dst[rowof(i) * qlim] = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;   // masked: every kernel underflows to exactly 0
             }
           }
-          f32x4* dst = (f32x4*)(a.cos_out + qi * ((int64_t)a.C * 40 * Q) + ((int64_t)(slot0 - (int)qi * a.C) * 40 + 32 * t) * qlim);
-          for (int l = lane; l < n4; l += 64) dst[l] = ((const f32x4*)T)[l];
-          nst = (n4 + 63) >> 6;
+        }
+        if (!(a.dbg & 1) && qlim > 0) {
+          nst = rows_blk / 2;
           pre = inflight;
         }
       } else {
@@ -1198,6 +1229,26 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
       hipLaunchKernelGGL((tkl_stage1_run_kernel<3, K, NBUF, false, false>), grid, block, lds, stream, a);
     return check_launch("tkl_stage1_run_kernel");
   } else {
+    if constexpr (!W) {
+      // fewer pairs than half the wavefront slots (eval.py-sized calls): two wavefronts per pair
+      if (a.n_pairs * 2 <= (int64_t)kCUs * 4 && a.n_md == 0 && a.D > 32) {
+        KpArgs b = a;
+        b.pairs_per_wave = 1;
+        const int lds2 = 2 * (NBUF * kSliceBytes + 128);
+        const dim3 grid2((unsigned)a.n_pairs), block2(128);
+        if (a.E == 100) {
+          (void)hipFuncSetAttribute((const void*)kernel_pool_split_kernel<1, K, NBUF, false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+          hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, false, false, false, 2>), grid2, block2, lds2, stream, b);
+        } else if (a.E == 200) {
+          (void)hipFuncSetAttribute((const void*)kernel_pool_split_kernel<2, K, NBUF, false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+          hipLaunchKernelGGL((kernel_pool_split_kernel<2, K, NBUF, false, false, false, 2>), grid2, block2, lds2, stream, b);
+        } else {
+          (void)hipFuncSetAttribute((const void*)kernel_pool_split_kernel<3, K, NBUF, false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+          hipLaunchKernelGGL((kernel_pool_split_kernel<3, K, NBUF, false, false, false, 2>), grid2, block2, lds2, stream, b);
+        }
+        return check_launch("kernel_pool_split_kernel<2 wavefronts per pair>");
+      }
+    }
     if (a.E == 100)
       hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, false, false, W>), grid, block, lds, stream, a);
     else if (a.E == 200)
@@ -1243,7 +1294,6 @@ static int launch_k(const KpArgs& a0, hipStream_t stream) {
     hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false, true>), dim3((unsigned)a.n_pairs), dim3(64), 0, stream, a);
     return check_launch("kernel_pool_generic_kernel<gated>");
   }
-  if (stream_ok && K == 11 && !env().kp_f32mfma && kp_wg_supported(a)) return kp_wg_launch(a, stream);
   if (stream_ok) return launch_stream<K, false>(a, stream);
   if (a.n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool: too many pairs for one launch");
   hipLaunchKernelGGL((kernel_pool_generic_kernel<K, false>), dim3((unsigned)a.n_pairs, (unsigned)(a.n_md > 0 ? a.n_mblk : 1)), dim3(64), 0,

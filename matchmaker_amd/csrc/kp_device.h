@@ -183,7 +183,7 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
 // which turns the pk_mul of the square into a pk_fma: the gate costs no instruction.
 // KP0..KP1: the kernel pairs this call evaluates, G0..G1: the 8-row groups (a K-split workgroup shares the
 // epilogue between its two waves either by kernel pairs or by rows).
-// the packed constants alone (kernel_pool_wg.hip fetches them from LDS per block instead of holding a whole Rbf)
+// the packed constants alone (for callers that fetch them per block instead of holding a whole Rbf in registers)
 struct RbfPk {
   f32x2 sq2[kMaxK / 2];
   f32x2 msq2[kMaxK / 2];
@@ -260,8 +260,8 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 
-// `loaded()` runs after this lane's values have been read from T and before they are evaluated (the workgroup kernel hands
-// the ring slot that holds T back to its producer there)
+// `loaded()` runs after this lane's values have been read from T and before they are evaluated (a caller that borrowed a
+// ring slot for T can hand it back to its producer there)
 template <int K, bool W, int ROWS, typename Hook = NoHook, typename R = Rbf>
 __device__ __forceinline__ void rbf_redistributed(f32x2 (&pk2)[kMaxK / 2], const float* T, const float* lwrow, int t, int s,
                                                   uint32_t va, const R& rbf, Hook loaded = Hook()) {
@@ -422,10 +422,6 @@ __device__ __forceinline__ bf16x8 to_agpr(bf16x8 v) {
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-
-// kernel_pool_wg.hip: shared-query lists at E = 300, two wavefronts per SIMD (query tile in LDS)
-bool kp_wg_supported(const KpArgs& a);
-int kp_wg_launch(const KpArgs& a, hipStream_t stream);
 
 // kernel_pool128.hip: streaming kernels for E = 64n <= 384 (Q <= 32)
 bool kp128_supported(int Q, int D, int E, bool gated);

@@ -270,12 +270,11 @@ def test_multi_block_pooling_equals_the_sum_of_single_launches(E, D):
 
 
 @pytest.mark.parametrize("Q", [20, 32, 9])
-def test_shared_query_lists_on_the_workgroup_kernel(Q):
-    """Candidate lists of >= 64 pairs per query at E = 300 run on kernel_pool_wg_kernel (two wavefronts per SIMD, the
-    query tile in LDS, 15-chunk slices): every pair vs the fp64 oracle, per-kernel outputs, dense masks with holes,
-    empty documents, queries of every epilogue class (MFMA layout, 11 / 8 / 4 / 2 / 1 rows per lane), a list that is
-    not a multiple of the wavefront count, and bit-equality with the one-wavefront-per-SIMD kernel's layout-independent
-    properties (determinism, permutation equivariance)."""
+def test_shared_query_candidate_lists_every_pair(Q):
+    """"1 query x C candidates" lists at E = 300 (the shared-query layout): every pair vs the fp64 oracle, per-kernel
+    outputs, dense masks with holes, empty documents, queries of every epilogue class (MFMA layout, 11 / 8 / 4 / 2 / 1
+    rows per lane), a list length that is not a multiple of anything, determinism, permutation equivariance, and the
+    same pairs in the pair-per-row layout."""
     from matchmaker_amd import ops
     from oracle import torch_port as TP
     dev = util.require_gpu()

@@ -6,7 +6,7 @@ export PYTHONUNBUFFERED=1
 t0=$(date +%s)
 timeout 600 python -m pytest tests/test_kernel_pool_gpu.py -x -q -m gpu 2>&1 | tail -25 > $O/t_kp.log; echo "kp tests $(( $(date +%s)-t0 ))s"; tail -25 $O/t_kp.log | cut -c1-300
 timeout 600 python -m pytest tests/test_rank_order_gpu.py -q -m gpu -k "tk_split" -s 2>&1 | grep -E "rank parity|passed|failed|Error|assert" | cut -c1-700 > $O/t_rank.log; echo "rank $(( $(date +%s)-t0 ))s"; tail -6 $O/t_rank.log
-for v in 0 1; do
+for v in 0; do
   echo "== TK no_wg=$v"
   MM_KP_NO_WG=$v timeout 300 python tools/bench_kernel_pool.py --full --queries 64 --steps 10 2>&1 | tail -1
   MM_KP_NO_WG=$v timeout 300 python tools/bench_kernel_pool.py --queries 64 --steps 10 --qlen config1 2>&1 | tail -1
