@@ -29,6 +29,7 @@ const EnvCfg& env() {
     c.maxsim_nt = env_int("MM_MAXSIM_NT", c.maxsim_nt);
     c.maxsim_generic = env_int("MM_MAXSIM_GENERIC", 0);
     c.maxsim_inb_untiled = env_int("MM_MAXSIM_INB_UNTILED", 0);
+    c.maxsim_inb_nowg = env_int("MM_MAXSIM_INB_NOWG", 0);
     c.maxsim_f32_terms = env_int("MM_MAXSIM_F32_TERMS", 3) == 2 ? 2 : 3;
     c.kp_generic = env_int("MM_KP_GENERIC", 0);
     c.kp_f32mfma = env_int("MM_KP_F32MFMA", 0);

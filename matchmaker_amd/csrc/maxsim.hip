@@ -268,6 +268,181 @@ __global__ void __launch_bounds__(64, 2) maxsim_allpairs_tiled_kernel(const Maxs
   maxsim_stream_body<DT, 2, false, NSL, false, NQT, 2>(a);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// All pairs, workgroup-shared document ring (large teacher batches).
+//
+// maxsim_allpairs_tiled_kernel gives every wavefront its own 2-slab ring, so the four wavefronts of a CU pull the same
+// documents through LDS four times (12.9 GB of LDS-DMA per 1024 x 1024 launch) and each pays 8 LDS-DMA instructions per
+// 32 MFMAs: 29 % of the MFMA peak (profiles/r02_allpairs_pmc.json: MFMA busy 31 %).  Here the 4 wavefronts of a
+// workgroup hold 4 x NQT DIFFERENT queries and share ONE ring: per 8 KiB slab a wavefront issues only its quarter (two
+// LDS-DMA instructions), waits for those two with a counted vmcnt, and one s_barrier makes the other three quarters
+// visible; the slot a slab leaves is refilled after the NEXT slab's barrier, when every wavefront is done reading it
+// (ring depth 3: two slabs in flight while one is computed).  Work map as in the tiled kernel: (XCD = document slice) x
+// (query-group lane), two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+template <bool TAIL>
+__device__ __forceinline__ void issue_quarter(const char* gbase, uint32_t v0, uint32_t v1, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "s"(gbase), "s"(lds_dst)
+      : "memory", "scc");
+}
+
+template <int DT, int NSL, int NQT>
+__global__ void __launch_bounds__(256, 2) maxsim_allpairs_wg_kernel(const MaxsimArgs a) {
+  constexpr int RB = NSL * 256;
+  constexpr int NB = NSL == 1 ? 3 : 4;                  // ring depth in 8 KiB slabs
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int ts = rest % a.inb_t, jg = rest / a.inb_t;
+  const int64_t S = 8 * (int64_t)a.inb_t, si = (int64_t)xcd * a.inb_t + ts;
+  const int64_t d_first = a.inb_bd * si / S;
+  const int nd = (int)(a.inb_bd * (si + 1) / S - d_first);
+  const int G = (int)((a.inb_bq + 4 * NQT - 1) / (4 * NQT));
+  if (nd <= 0 || jg >= G) return;
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // this wavefront's two LDS-DMA instructions of a slab: instruction k = 2 wv + u moves rows 4k..4k+3 (16 lanes per row),
+  // source-side swizzle as in issue_block; tail variant: rows past D are redirected to the last real row
+  uint32_t vq[2], vq_tail[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = 4 * (2 * wv + u) + (lane >> 4);
+    const int c = (lane & 15) ^ (row & 15);
+    const int rowt = row < rows_last ? row : rows_last - 1;
+    vq[u] = (uint32_t)(row * RB + c * 16);
+    vq_tail[u] = (uint32_t)(rowt * RB + c * 16);
+  }
+  uint32_t lo[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
+
+  const char* dbase = (const char*)a.d;
+  auto doc_len = [&](int dd) -> int {
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, d_first + dd) : D;
+    return len < 0 ? 0 : (len > D ? D : len);
+  };
+
+  for (int g = jg; g < G; g += a.inb_gw) {
+    // ---- this wavefront's NQT queries as MFMA B fragments (the ring is empty here: plain loads may use vmcnt(0)) ----
+    short8 qf[NQT][NSL][8];
+    bool qvalid[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) {
+      int64_t qq = ((int64_t)g * 4 + wv) * NQT + n;
+      const bool exists = qq < a.inb_bq;
+      qq = exists ? qq : a.inb_bq - 1;
+      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qq) : Q;
+      const int qr = r < Q ? r : Q - 1;
+      const char* qrow = (const char*)a.q + (qq * Q + qr) * RB;
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
+      qvalid[n] = exists && r < Q && r < qlen;
+      if (a.qm.bits) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qq) >> r) & 1u);
+    }
+    // nobody may still be reading the previous group's last slabs when the first slabs of this one are requested
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- producer cursor over (document, block, slab); identical in all four wavefronts --------------------------
+    int pd = 0, pt = 0, psl = 0, pn = 0;
+    while (pd < nd && (pn = (doc_len(pd) + 31) >> 5) == 0) ++pd;
+    int pbuf = 0, cbuf = 0, inflight = 0;
+    int pre = 0, nst = 0;   // score stores share the in-order vmcnt queue: `pre` slabs are older than the last burst of `nst` stores
+    auto top_up = [&]() {
+      while (pd < nd && inflight < NB) {
+        const char* gsrc = dbase + ((d_first + pd) * (int64_t)D + (int64_t)pt * 32) * RB + psl * 256;
+        const uint32_t dst = lds0 + (uint32_t)pbuf * kBlkBytes + (uint32_t)wv * 2048;
+        if (pt == nblk_tot - 1 && rows_last != 32)
+          issue_quarter<true>(gsrc, vq_tail[0], vq_tail[1], dst);
+        else
+          issue_quarter<false>(gsrc, vq[0], vq[1], dst);
+        pbuf = (pbuf + 1 == NB) ? 0 : pbuf + 1;
+        ++inflight;
+        if (NSL > 1 && ++psl < NSL) continue;
+        psl = 0;
+        if (++pt == pn) {
+          pt = 0;
+          ++pd;
+          while (pd < nd && (pn = (doc_len(pd) + 31) >> 5) == 0) ++pd;
+        }
+      }
+    };
+    top_up();
+
+    for (int dd = 0; dd < nd; ++dd) {
+      const int len = doc_len(dd);
+      const int nb = (len + 31) >> 5;
+      const float fill = len < D ? -1000.0f : neg_inf();
+      float m1[NQT];
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) m1[n] = fill;
+      for (int t = 0; t < nb; ++t) {
+        f32x16 acc[NQT];
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+          // my quarter of the oldest slab has landed (two instructions per slab in flight behind it, + the last
+          // document's score stores while they are younger than it) ...
+          if (pre > 0) {
+            wait_vm(2 * (inflight - 1) + nst);
+            --pre;
+          } else {
+            nst = 0;
+            wait_vm(2 * (inflight - 1));
+          }
+          // ... and so have the others'; everyone is also done with the slab before it, whose slot is refilled now
+          asm volatile("s_barrier" ::: "memory");
+          top_up();
+          const char* buf = smem + cbuf * kBlkBytes;
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            const short8 av = *(const short8*)(buf + lo[kk]);
+#pragma unroll
+            for (int n = 0; n < NQT; ++n) acc[n] = Mfma32x16<DT>::run(av, qf[n][sl][kk], acc[n]);
+          }
+          cbuf = (cbuf + 1 == NB) ? 0 : cbuf + 1;
+          --inflight;
+        }
+        const int rem = len - 32 * t;
+        const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+        const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, (d_first + dd) * nblk_tot + t) & ex) : ex;
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) block_max1(m1[n], acc[n], ex, va, fill, h);
+      }
+      int stores = 0;
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) {
+        const float sc = finish_pair1(m1[n], qvalid[n], h);
+        const int64_t qq = ((int64_t)g * 4 + wv) * NQT + n;
+        if (qq < a.inb_bq) {                                 // wave-uniform
+          if (lane == 0) a.out[qq * a.inb_bd + d_first + dd] = sc;
+          ++stores;
+        }
+      }
+      nst = stores;       // (counting fewer than were issued would only wait longer; `stores` is exact)
+      pre = inflight;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic path: any E (16-B aligned rows), any Q, any D; bf16 / f16 / f32.
 // One wavefront per pair; query tiles of 32 tokens looped sequentially (deterministic sum order).
@@ -540,12 +715,36 @@ static int launch_stream_inb_tiled(const MaxsimArgs& a0, hipStream_t stream) {
   return check_launch("maxsim_allpairs_tiled_kernel");
 }
 
+// workgroup-shared ring (maxsim_allpairs_wg_kernel): 4 x NQT queries per workgroup, two workgroups per CU
+template <int DT, int NSL, int NQT>
+static int launch_inb_wg(const MaxsimArgs& a0, hipStream_t stream) {
+  MaxsimArgs a = a0;
+  const int lds = (NSL == 1 ? 3 : 4) * kBlkBytes;
+  const int64_t G = (a.inb_bq + 4 * NQT - 1) / (4 * NQT);
+  const int64_t target = (int64_t)kCUs * 2 / 8;                  // workgroups per XCD
+  a.inb_gw = (int)(G < target ? G : target);
+  int64_t T = target / a.inb_gw;
+  const int64_t max_t = (a.inb_bd + 7) / 8;
+  if (T > max_t) T = max_t;
+  if (T < 1) T = 1;
+  a.inb_t = (int)T;
+  if (a.inb_bd >= (1LL << 31)) return kNotLaunched;
+  hipLaunchKernelGGL((maxsim_allpairs_wg_kernel<DT, NSL, NQT>), dim3((unsigned)(8 * T * a.inb_gw)), dim3(256), lds, stream, a);
+  return check_launch("maxsim_allpairs_wg_kernel");
+}
+
 template <int DT>
 static int launch_stream_inb_cfg(const MaxsimArgs& a, hipStream_t stream) {
   // tiled over queries when the query tiles fit the register file (E <= 256), the masks are the documents' own
   // (bug-compatible masking, colbert.py:158, depends on the query index) and there is more than one query
   if (a.Q <= 32 && !a.inb_bug && a.inb_bq > 1 && !env().maxsim_inb_untiled) {
     int e = kNotLaunched;
+    // teacher batches large enough to give every workgroup 16 queries and a few documents: the shared-ring kernel
+    if (a.inb_bq >= 64 && a.inb_bd >= 64 && !env().maxsim_inb_nowg) {
+      if (a.E == 128) e = launch_inb_wg<DT, 1, 4>(a, stream);
+      if (a.E == 256) e = launch_inb_wg<DT, 2, 2>(a, stream);
+    }
+    if (e != kNotLaunched) return e;
     if (a.E == 128) e = launch_stream_inb_tiled<DT, 1, 4>(a, stream);
     if (a.E == 256) e = launch_stream_inb_tiled<DT, 2, 2>(a, stream);
     if (e != kNotLaunched) return e;      // index range too large for the tiled map: one query per wavefront below

@@ -29,6 +29,7 @@ struct EnvCfg {
   int maxsim_nt = 1;        // MM_MAXSIM_NT: non-temporal LDS-DMA
   int maxsim_generic = 0;   // MM_MAXSIM_GENERIC: force the generic MaxSim kernel
   int maxsim_inb_untiled = 0;  // MM_MAXSIM_INB_UNTILED: all-pairs MaxSim with one query per wavefront (A/B runs)
+  int maxsim_inb_nowg = 0;     // MM_MAXSIM_INB_NOWG: all-pairs MaxSim without the workgroup-shared ring (A/B runs)
   int maxsim_f32_terms = 3; // MM_MAXSIM_F32_TERMS: 2 = two-term split for fp32 MaxSim (A/B), default three terms
   int kp_generic = 0;       // MM_KP_GENERIC: force the generic pooling kernel
   int kp_f32mfma = 0;       // MM_KP_F32MFMA: exact-f32 MFMA pooling kernel instead of split-bf16

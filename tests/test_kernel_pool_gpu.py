@@ -265,7 +265,10 @@ def test_multi_block_pooling_equals_the_sum_of_single_launches(E, D):
             want = want + ops.kernel_pool(t(qs[i]), t(ds[j]), t(qm), t(dm), t(mu), t(sigma), t(ones), t(w[i * n + j]))
             ref += O.tk_kernel_pool(qs[i].numpy(), ds[j].numpy(), qm.numpy(), dm.numpy(), MU, SIGMA, ones.numpy(),
                                     w[i * n + j].numpy(), dtype=np.float64)
-    assert torch.equal(got, want)           # same kernels, same (i, t) summation order
+    # same kernels, same (i, t) summation order; not bit-equal in general: a single launch of few pairs splits every pair's
+    # blocks over two wavefronts (eval.py-sized calls), the nine-combination launch does not, and the order in which a
+    # pair's block sums are added differs
+    torch.testing.assert_close(got, want, rtol=2e-6, atol=2e-5)
     np.testing.assert_allclose(got.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
 
 

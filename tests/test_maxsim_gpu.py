@@ -313,3 +313,32 @@ def test_all_pairs_on_the_streaming_kernel(dtype, Bq, Bd, Q, D, E):
     for ri in {min(3, Bq - 1), Bq - 1, Bq // 2}:
         row = ops.maxsim(q[ri:ri + 1].to(dev), d.to(dev), qm[ri:ri + 1].to(dev), dm.to(dev), pairs_per_query=Bd)
         assert torch.equal(row.cpu(), torch.from_numpy(out[ri]))
+
+
+@pytest.mark.parametrize("dtype,Q,D,Bq,Bd,E", [(torch.bfloat16, 32, 180, 80, 200, 128), (torch.float16, 20, 50, 130, 77, 128),
+                                                (torch.bfloat16, 32, 33, 64, 64, 128), (torch.bfloat16, 30, 70, 70, 90, 256)])
+def test_all_pairs_on_the_workgroup_shared_ring(dtype, Q, D, Bq, Bd, E):
+    """Teacher batches of >= 64 x 64 run on maxsim_allpairs_wg_kernel (four wavefronts share one document ring, a
+    quarter of every slab each): every (query, document) score vs the oracle, vs the shared-query kernel bit for bit,
+    ragged / empty documents, hole masks, query counts that are not a multiple of 16."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Bq * 1000 + Bd)
+    q = torch.nn.functional.normalize(torch.randn(Bq, Q, E, generator=g), dim=-1).to(dtype)
+    d = torch.nn.functional.normalize(torch.randn(Bd, D, E, generator=g), dim=-1).to(dtype)
+    q_len = torch.randint(1, Q + 1, (Bq,), generator=g)
+    d_len = torch.randint(0, D + 1, (Bd,), generator=g)
+    d_len[:3] = torch.tensor([0, D, 1])
+    qm = (torch.arange(Q)[None] < q_len[:, None]).long()
+    dm = (torch.arange(D)[None] < d_len[:, None]).long()
+    dm[5, 0] = 0
+    qm[2, 0] = 0
+    out = ops.maxsim_inbatch(q.to(dev), qm.to(dev), d.to(dev), dm.to(dev), bug_compatible=False)
+    assert out.shape == (Bq, Bd)
+    ref = O.maxsim_inbatch(q.float().numpy(), qm.numpy(), d.float().numpy(), dm.numpy(), bug_compatible=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=util.TOL_BF16)
+    # the same pairs through the shared-query kernel (one query x Bd candidates): the same bits
+    for i in (0, 2, Bq - 1):
+        row = ops.maxsim(q[i:i + 1].to(dev), d.to(dev), qm[i:i + 1].to(dev), dm.to(dev), pairs_per_query=Bd)
+        assert torch.equal(row, out[i])
+    assert torch.equal(out, ops.maxsim_inbatch(q.to(dev), qm.to(dev), d.to(dev), dm.to(dev), bug_compatible=False))
