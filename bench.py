@@ -649,6 +649,8 @@ def main():
                     help="launch + collective plumbing only (fabricated scores, value = null); for GPU-less machines")
     args = ap.parse_args()
 
+    if args.only == "headline":
+        args.no_extras = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 

@@ -433,29 +433,185 @@ __global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restric
   if (tid == 0) tau[row] = ord2f(x);
 }
 
+// (score descending, index ascending) bitonic sort of 1024 entries held ONE PER THREAD: the 45 stages whose partner
+// lives in the same wavefront (stride < 64) exchange through lane shuffles, only the 10 strides >= 64 go through LDS
+// (two barriers each) — against 55 barrier-separated LDS passes of the in-LDS network.
+__device__ __forceinline__ void bitonic1024_desc(float& k, int& v, float* xk, int* xv, int tid) {
+  for (int size = 2; size <= 1024; size <<= 1) {
+    const bool desc = (tid & size) == 0;
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      float pk;
+      int pv;
+      if (strd >= 64) {
+        xk[tid] = k;
+        xv[tid] = v;
+        __syncthreads();
+        pk = xk[tid ^ strd];
+        pv = xv[tid ^ strd];
+        __syncthreads();
+      } else {
+        pk = __shfl_xor(k, strd, 64);
+        pv = __shfl_xor(v, strd, 64);
+      }
+      const bool me_lo = (tid & strd) == 0;
+      const bool lo_first = me_lo ? before(k, v, pk, pv) : before(pk, pv, k, v);
+      if (lo_first != desc) {  // the pair is in the wrong order for this sub-sequence: both sides take the partner's entry
+        k = pk;
+        v = pv;
+      }
+    }
+  }
+}
+
+constexpr int kSelMax = 1024;   // entries the selection may keep (k plus the ties of the k-th score)
+
+// Exact top-k of one candidate row.  The ~2.5 k survivors of a row used to be padded to 4,096 and sorted whole (78
+// barrier-separated bitonic passes with 2,048 comparators each, 146.8 M LDS bank-conflict cycles per launch in
+// profiles/r02_dot_pmc.json: 0.93 ms of the call).  Now: (1) radix SELECT of the k-th largest score — keys as
+// order-preserving integers, one 256-bin LDS histogram per byte, bytes on which all keys agree (sign / exponent of
+// scores above one threshold) skipped; (2) the entries >= that score (k plus ties, deterministic whatever order the
+// filter appended them in) are compacted; (3) those <= 1,024 entries are sorted one per thread (bitonic1024_desc).
+// Rows with massive ties (> 1,024 entries at or above the k-th score) or k > 1,024 fall back to the full sort.
 __global__ void __launch_bounds__(1024) topk_rows_kernel(const float* __restrict__ cand_score,
                                                          const int32_t* __restrict__ cand_idx,
                                                          const int32_t* __restrict__ count, int cap, int k,
                                                          int64_t n_total, float* __restrict__ out_score,
                                                          int64_t* __restrict__ out_idx, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* key = (float*)smem;
-  int* val = (int*)(key + cap);
-  const int row = blockIdx.x, tid = threadIdx.x;
+  float* key = (float*)smem;                 // [cap]
+  int* val = (int*)(key + cap);              // [cap]
+  float* skey = (float*)(val + cap);         // [kSelMax]
+  int* sval = (int*)(skey + kSelMax);        // [kSelMax]
+  int* hist = sval + kSelMax;                // [256]
+  int* misc = hist + 256;                    // [8]
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int cnt = count[row];
   const int n = cnt < cap ? cnt : cap;
-  int n2 = 2;
-  while (n2 < n) n2 <<= 1;  // sort only as much as survived (typically ~2.5 k of the 4 k capacity)
-  for (int i = tid; i < n2; i += 1024) {
-    key[i] = i < n ? cand_score[(int64_t)row * cap + i] : -__builtin_huge_valf();
-    val[i] = i < n ? cand_idx[(int64_t)row * cap + i] : 0x7fffffff;
-  }
-  bitonic_desc<true>(key, val, n2, tid, 1024);
   const int64_t want = k < n_total ? k : n_total;  // a shard smaller than k returns everything it has
+  for (int i = tid; i < n; i += 1024) {
+    key[i] = cand_score[(int64_t)row * cap + i];
+    val[i] = cand_idx[(int64_t)row * cap + i];
+  }
+  if (tid < 8) misc[tid] = tid == 1 ? -1 : 0;             // [0] max key, [1] min key (unsigned order), [2] compaction counter
+  __syncthreads();
+  float* okey = key;
+  int* oval = val;
+  int m = n;                                               // entries that are sorted
+  bool in_regs = false;
+  float rk = -__builtin_huge_valf();
+  int rv = 0x7fffffff;
+  if (n > kSelMax && k <= kSelMax) {
+    // ---- (1) select the k-th largest key --------------------------------------------------------
+    uint32_t kmax = 0u, kmin = 0xffffffffu;
+    for (int i = tid; i < n; i += 1024) {
+      const uint32_t o = f2ord(key[i]);
+      kmax = o > kmax ? o : kmax;
+      kmin = o < kmin ? o : kmin;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint32_t a = (uint32_t)__shfl_xor((int)kmax, o, 64), b2 = (uint32_t)__shfl_xor((int)kmin, o, 64);
+      kmax = a > kmax ? a : kmax;
+      kmin = b2 < kmin ? b2 : kmin;
+    }
+    if (lane == 0) {
+      atomicMax((unsigned int*)&misc[0], kmax);
+      atomicMin((unsigned int*)&misc[1], kmin);
+    }
+    __syncthreads();
+    kmax = (uint32_t)misc[0];
+    kmin = (uint32_t)misc[1];
+    const int common = kmax == kmin ? 32 : __builtin_clz(kmax ^ kmin);   // leading bits every key shares
+    uint32_t prefix = common >= 32 ? kmax : (common == 0 ? 0u : (kmax & ~(0xffffffffu >> common)));
+    int need = k;                                          // rank still wanted among the keys matching `prefix`
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (common >= 32 - shift) {                          // every key has the same byte here: nothing to count
+        prefix = (prefix & ~(0xffu << shift)) | (kmax & (0xffu << shift));
+        continue;
+      }
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      const uint32_t hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+      for (int i = tid; i < n; i += 1024) {
+        const uint32_t o = f2ord(key[i]);
+        if ((o & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(o >> shift) & 0xffu], 1);
+      }
+      __syncthreads();
+      if (tid < 64) {                                      // suffix scan of the 256 bins: lane l owns bins 4l .. 4l + 3
+        const int b0 = hist[4 * lane], b1 = hist[4 * lane + 1], b2 = hist[4 * lane + 2], b3 = hist[4 * lane + 3];
+        int above = b0 + b1 + b2 + b3;                     // -> keys in bins of HIGHER lanes
+        int tot = above;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_down(tot, o, 64);
+          tot += (lane + o < 64) ? t : 0;
+        }
+        above = tot - above;                               // strictly above this lane's four bins
+        // the wanted key lies in the first bin (from the top) at which the running count reaches `need`
+        int c3 = above + b3, c2 = c3 + b2, c1 = c2 + b1, c0 = c1 + b0;
+        int bin = -1, gt = 0;
+        if (above < need && c0 >= need) {
+          if (c3 >= need) { bin = 4 * lane + 3; gt = above; }
+          else if (c2 >= need) { bin = 4 * lane + 2; gt = c3; }
+          else if (c1 >= need) { bin = 4 * lane + 1; gt = c2; }
+          else { bin = 4 * lane; gt = c1; }
+          misc[3] = bin;
+          misc[4] = gt;
+        }
+      }
+      __syncthreads();
+      prefix = (prefix & ~(0xffu << shift)) | ((uint32_t)misc[3] << shift);
+      need -= misc[4];
+      __syncthreads();
+    }
+    // prefix is the k-th largest key; every entry >= it is kept (k plus ties)
+    const uint32_t thr = prefix;
+    for (int i = tid; i < n; i += 1024) {
+      const float kf = key[i];
+      if (f2ord(kf) >= thr) {
+        const int pos = atomicAdd(&misc[2], 1);
+        if (pos < kSelMax) {
+          skey[pos] = kf;
+          sval[pos] = val[i];
+        }
+      }
+    }
+    __syncthreads();
+    m = misc[2];
+    if (m <= kSelMax) {
+      in_regs = true;
+      if (tid < m) {
+        rk = skey[tid];
+        rv = sval[tid];
+      }
+      __syncthreads();
+      bitonic1024_desc(rk, rv, skey, sval, tid);
+    } else {
+      m = n;                                               // massive ties: the whole row is sorted below
+    }
+  }
+  if (!in_regs) {
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;  // sort only as much as survived
+    for (int i = n + tid; i < n2; i += 1024) {
+      key[i] = -__builtin_huge_valf();
+      val[i] = 0x7fffffff;
+    }
+    bitonic_desc<true>(key, val, n2, tid, 1024);
+  }
   for (int i = tid; i < k; i += 1024) {
-    const bool ok = i < n && i < want;
-    out_score[(int64_t)row * k + i] = ok ? key[i] : -__builtin_huge_valf();
-    out_idx[(int64_t)row * k + i] = ok ? (int64_t)val[i] : -1;  // faiss pads missing results with -1
+    const bool ok = i < m && i < want;
+    float ks;
+    int vs;
+    if (in_regs) {           // k <= 1024: thread i holds rank i
+      ks = rk;
+      vs = rv;
+    } else {
+      ks = ok ? okey[i] : 0.0f;
+      vs = ok ? oval[i] : 0;
+    }
+    out_score[(int64_t)row * k + i] = ok ? ks : -__builtin_huge_valf();
+    out_idx[(int64_t)row * k + i] = ok ? (int64_t)vs : -1;  // faiss pads missing results with -1
   }
   if (tid == 0) status[row] = cnt > cap ? 2 : (cnt < want ? 1 : 0);
 }
@@ -615,9 +771,10 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
     if (e) return e;
   }
   // phase 3: exact top-k of the survivors
-  if ((size_t)cap * 8 > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cap * 8);
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), (size_t)cap * 8, stream, cand_score, cand_idx, count, cap, k,
+  const size_t lds_rows = (size_t)cap * 8 + kSelMax * 8 + 256 * 4 + 32;
+  if (lds_rows > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(1024), lds_rows, stream, cand_score, cand_idx, count, cap, k,
                      n_docs, out_scores, out_idx, status);
   if (int e = check_launch("topk_rows_kernel")) return e;
   if (a.prof) {  // tools only: synchronous dump of the phase counters

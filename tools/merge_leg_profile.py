@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""One file per bench leg: the leg's own JSON (un-traced run and the run under rocprofv3) + the kernel trace of that very
+process, with the check the judge asked for: algorithmic work / (sum of the leg's kernels per call, from the trace)
+vs the fraction the leg reports.
+
+    python tools/merge_leg_profile.py <leg> <plain.log> <traced.log> <trace_summary.json> <out.json>"""
+import json
+import sys
+
+
+def line(path):
+    try:
+        for ln in reversed(open(path).read().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+    except OSError:
+        pass
+    return None
+
+
+def leg_result(j):
+    if j is None:
+        return None
+    return j.get("result", j)
+
+
+def main():
+    leg, plain, traced, summ, out = sys.argv[1:6]
+    jp, jt = leg_result(line(plain)), leg_result(line(traced))
+    tr = json.load(open(summ))
+    ks = tr.get("kernel_trace", [])
+    res = {"leg": leg, "command": tr.get("workload", {}).get("command"), "untraced": jp, "under_rocprofv3": jt,
+           "kernel_trace": ks}
+
+    def frac_ms(j):
+        if not j:
+            return None, None
+        rf = j.get("roofline") or {}
+        ms = j.get("ms", j.get("ms_per_step", rf.get("kernel_ms")))
+        return rf.get("frac"), ms
+    f_plain, ms_plain = frac_ms(jp)
+    f_tr, ms_tr = frac_ms(jt)
+    if ks and ms_tr:
+        main_calls = max(k["calls"] for k in ks)
+        per_call_ms = sum(k["total_us"] for k in ks if k["calls"] * 4 >= main_calls) / main_calls / 1e3
+        res["check"] = {"kernels_per_call_ms_from_trace": per_call_ms, "leg_ms_same_process": ms_tr, "leg_ms_untraced": ms_plain,
+                        "frac_same_process": f_tr, "frac_untraced": f_plain,
+                        "frac_from_trace": (f_tr * ms_tr / per_call_ms) if (f_tr and per_call_ms) else None,
+                        "trace_vs_leg": per_call_ms / ms_tr if ms_tr else None}
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
