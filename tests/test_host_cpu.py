@@ -410,3 +410,102 @@ def test_tiled_all_pairs_work_map_covers_every_pair_once(Bq, Bd, NQT):
                 if qq < Bq:
                     seen[qq, doc] += 1
     assert seen.min() == 1 and seen.max() == 1
+
+
+@pytest.mark.parametrize("Bq,Bd,NQT", [(64, 64, 4), (1024, 1024, 4), (70, 90, 2), (1030, 137, 4), (65, 20000, 4), (4000, 64, 4)])
+def test_shared_ring_all_pairs_work_map_covers_every_pair_once(Bq, Bd, NQT):
+    """Python mirror of launch_inb_wg / maxsim_allpairs_wg_kernel (csrc/maxsim.hip): workgroup (xcd, t, jg) streams document
+    slice xcd * T + t once per query group jg, jg + Gw, ...; wavefront w of the workgroup owns queries
+    (4 g + w) * NQT .. + NQT - 1.  Every (query, document) pair exactly once."""
+    cus = 256
+    G = (Bq + 4 * NQT - 1) // (4 * NQT)
+    target = cus * 2 // 8
+    gw = min(G, target)
+    T = max(1, min(target // gw, (Bd + 7) // 8))
+    seen = np.zeros((Bq, Bd), dtype=np.int32)
+    for bid in range(8 * T * gw):
+        xcd, rest = bid & 7, bid >> 3
+        t, jg = rest % T, rest // T
+        S, si = 8 * T, xcd * T + t
+        d_first = Bd * si // S
+        nd = Bd * (si + 1) // S - d_first
+        if nd <= 0 or jg >= G:
+            continue
+        for g in range(jg, G, gw):
+            for w in range(4):
+                for n in range(NQT):
+                    qq = (g * 4 + w) * NQT + n
+                    if qq < Bq:
+                        seen[qq, d_first:d_first + nd] += 1
+    assert seen.min() == 1 and seen.max() == 1
+
+
+def test_store_burst_accounting_never_overcounts():
+    """Model of the vmcnt bookkeeping of tkl_stage1_run_kernel / maxsim_allpairs_wg_kernel: a wavefront's loads (slices of
+    `per` instructions) and its bursts of stores retire in issue order; the wait for the oldest slice is
+    vmcnt(per * (inflight - 1) + nst) while `pre` > 0, else vmcnt(per * (inflight - 1)).  The value must never EXCEED the
+    true number of younger operations (that would read a slice before it landed) and should equal it whenever at most one
+    burst is in the queue."""
+    rng = np.random.default_rng(5)
+    for per, nbuf, ns in ((13, 3, 3), (13, 3, 1), (2, 3, 1), (2, 4, 2)):
+        queue = []                       # issue-ordered: ("slice", id) x per | ("store",)
+        inflight, pre, nst, next_id, oldest = 0, 0, 0, 0, 0
+        exact = total = 0
+
+        def top_up():
+            nonlocal inflight, next_id
+            while inflight < nbuf:
+                queue.extend([("slice", next_id)] * per)
+                next_id += 1
+                inflight += 1
+        top_up()
+        for block in range(200):
+            for s in range(ns):
+                top_up()
+                if pre > 0:
+                    n = per * (inflight - 1) + nst
+                    pre -= 1
+                else:
+                    nst = 0
+                    n = per * (inflight - 1)
+                # true number of operations younger than the last instruction of the oldest slice
+                last = max(i for i, op in enumerate(queue) if op == ("slice", oldest))
+                younger = len(queue) - 1 - last
+                assert n <= younger, (per, nbuf, ns, block, s, n, younger)
+                exact += n == younger
+                total += 1
+                queue = queue[last + 1:]                 # everything up to it has retired (in order)
+                oldest += 1
+                inflight -= 1
+                top_up()                                 # early hand-back of the slot
+            burst = int(rng.integers(0, 17))
+            if burst:
+                queue.extend([("store",)] * burst)
+                nst, pre = burst, inflight
+        if (per, nbuf, ns) == (13, 3, 3):   # TKL at E = 300: at most one burst in the queue -> the count is exact
+            assert exact >= 0.9 * total, (per, nbuf, ns, exact, total)   # (elsewhere an older burst is left uncounted on purpose)
+
+
+def test_flat_index_precision_follows_token_dtype():
+    """base_index.py:14: use_fp16 = config["token_dtype"] == "float16"; an fp32 index is refused, not silently rounded."""
+    from matchmaker_amd.retrieval import FlatIPIndexer
+    from matchmaker_amd.ops import NativeError
+    FlatIPIndexer({"token_dim": 128, "token_dtype": "float16"}, device="cpu", topk_fn=lambda *a: None, merge_fn=lambda *a: None)
+    with pytest.raises(NativeError):
+        FlatIPIndexer({"token_dim": 128, "token_dtype": "float32"}, device="cpu", topk_fn=lambda *a: None, merge_fn=lambda *a: None)
+    with pytest.raises(NativeError):
+        FlatIPIndexer({"token_dim": 128, "token_dtype": "float16", "faiss_use_fp16": False}, device="cpu",
+                      topk_fn=lambda *a: None, merge_fn=lambda *a: None)
+
+
+@pytest.mark.parametrize("sat", ["embedding", "log"])
+def test_tkl_parameters_unused_by_the_saturation_mode_get_no_gradient_slot(sat):
+    """The reference leaves .grad = None on parameters its active saturation never reads (kernel_mult under "embedding";
+    the saturation layers, LayerNorm and sat_emb_reduce1 under "log"); the native backward's layout must say so too."""
+    from matchmaker_amd.tkl import TKL_sigir20
+    m = TKL_sigir20(64, [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9], [0.1] * 11, 8, 1, 32, 2000, True, True, sat)
+    scoring, sizes = m._pack_layout()
+    live = {id(p) for p in m._scoring_parameters()}
+    for t, n in zip(scoring, sizes):
+        assert (n is not None) == (id(t) in live)
+    assert sum(n is None for n in sizes) == (1 if sat == "embedding" else 9)
