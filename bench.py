@@ -209,7 +209,7 @@ def extra_dropin_forward(q, d, q_len, d_len, steps):
             "dtype": "bf16", "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
             "bytes_per_pair": by // B, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                     "frac": gbs / HBM_PEAK_GBS},
-            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r03_dropin_pmc.json"}
+            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r03_dropin_forward_trace.json"}
 
 
 def extra_sustained(score_shard, B, seconds=4.0):
@@ -269,7 +269,7 @@ def extra_tk(steps, cpu_budget):
            "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms,
            "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by, "flop": B * (2 * Qt * Dt * Et + 2 * (Qt + Dt) * Et),
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r03_tk_pmc.json"}
+           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r03_tk_pmc.json, profiles/r03_tk_trace.json"}
     del q, d
     torch.cuda.empty_cache()
     try:
@@ -336,14 +336,34 @@ def extra_tkl(steps, cpu_budget):
     gbs = by / (ms * 1e-3) / 1e9
     out = {"workload": f"TKL scoring (sigir20_tkl.py:180-286), {B} documents x D={Dt} (lengths U{{50..{Dt}}}: {P} packed chunks "
                        f"of 50 tokens), dim={Et}, Q={Qt} (lengths U{{3..{Qt}}}), embedding saturation",
-           "dtype": "fp32 (split-bf16 operands)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
+           "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "tkl_stage1_run_kernel + tkl_window_kernel + tkl_region_kernel (whole mm_tkl_fwd call)",
-           "profile": "profiles/r03_tklragged_pmc.json"}
+           "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> + tkl_region_kernel (whole mm_tkl_fwd call)",
+           "profile": "profiles/r03_tkl_pmc.json, profiles/r03_tkl_trace.json (full documents: profiles/r03_tklfull_pmc.json)"}
     try:
         out["exact_f32_mfma"] = tkl_exact_f32_subprocess()
     except Exception as e:
         out["exact_f32_mfma"] = {"error": repr(e)}
+    try:      # the same length distributions at four times the batch: how much of the 256-document figure is fixed cost
+        B4 = 4 * B
+        g4 = torch.Generator(device=dev).manual_seed(3004)
+        d4 = torch.randn(B4, Dt, Et, generator=g4, device=dev)
+        q4 = torch.randn(B4, Qt, Et, generator=g4, device=dev)
+        dl4 = torch.randint(50, Dt + 1, (B4,), generator=g4, device=dev)
+        ql4 = torch.randint(3, Qt + 1, (B4,), generator=g4, device=dev)
+        qm4 = (torch.arange(Qt, device=dev)[None] < ql4[:, None]).float()
+        dm4 = (torch.arange(Dt, device=dev)[None] < dl4[:, None]).float()
+        ch4, cm4, sl4, C4 = chunk_documents(d4 * dm4.unsqueeze(-1), dm4)
+        del d4
+        qc4 = q4 * qm4.unsqueeze(-1)
+        ms4 = gpu_time_ms(lambda: ops.tkl_score(qc4, ch4, cm4, sl4, qm4, params, B4, C4, 11, "embedding"), steps)
+        by4 = ch4.shape[0] * 50 * Et * 4 + B4 * Qt * Et * 4 + ch4.shape[0] * 50 * 4 + 4 * B4
+        out["batch_1024_documents"] = {"ms": ms4, "docs_per_s": B4 / (ms4 * 1e-3), "algorithmic_bytes": by4,
+                                       "frac": by4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        del ch4, cm4, sl4, qc4, q4
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["batch_1024_documents"] = {"error": repr(e)}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         n = 4
@@ -417,7 +437,7 @@ def extra_maxsim_fp32(steps, cpu_budget):
            "dtype": "fp32 (three-term split-bf16 operands x = hi + lo + c, 6 bf16 MFMAs per K step, fp32 accumulation)",
            "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "kernel_pool_split128_kernel<MX> (csrc/kernel_pool128.hip)", "profile": "profiles/r03_maxsimfp32_trace.json"}
+           "kernel": "kernel_pool_split128_kernel<MX> (csrc/kernel_pool128.hip)", "profile": "profiles/r03_maxsim_fp32_trace.json"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         n = 1000
@@ -519,7 +539,7 @@ def extra_published_checkpoint(steps, cpu_budget):
            "dtype": "f16", "ms": ms, "pairs_per_s": n / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
            "kernel": "pack_mask_kernel + maxsim_stream_kernel with two query tiles (NSL = 6, NQT = 2)",
-           "profile": "profiles/r03_published_pmc.json"}
+           "profile": "profiles/r03_published_checkpoint_trace.json"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         m = 256
@@ -557,7 +577,7 @@ def extra_all_pairs(steps, cpu_budget):
            "dtype": "bf16", "ms": ms, "pairs_per_s": Bq * Bd / t, "flop": flop,
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
-           "kernel": "maxsim_allpairs_tiled_kernel: 4 queries per wavefront", "profile": "profiles/r03_allpairs_pmc.json"}
+           "kernel": "maxsim_allpairs_wg_kernel: 4 wavefronts x 4 queries share one document ring", "profile": "profiles/r03_all_pairs_pmc.json"}
     t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
     out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
     if cpu_budget > 0:
@@ -602,7 +622,7 @@ def extra_dot_topk(steps, cpu_budget):
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
            "kernel": "dot_stream_kernel (sample + filter) + sample_tau_kernel + topk_rows_kernel (whole mm_dot_topk_fwd call, wall clock)",
-           "profile": "profiles/r03_dot_pmc.json"}
+           "profile": "profiles/r03_dot_topk_pmc.json, profiles/r03_dot_topk_trace.json"}
     if cpu_budget > 0:
         nqc, nc = 64, 1 << 16
         qc, cc = q[:nqc].float().cpu(), c[:nc].float().cpu()

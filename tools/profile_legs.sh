@@ -29,7 +29,21 @@ for L in $PMCL; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_$L/pmc_fetch -o $L -- $CMD > $O/pmc_$L/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_$L/pmc_write -o $L -- $CMD > $O/pmc_$L/write.log 2>&1
   rocprofv3 --pmc $SQ --kernel-trace -d $O/pmc_$L/pmc_sq -o $L -- $CMD > $O/pmc_$L/sq.log 2>&1
-  MM_PROF_COMMAND="$CMD" python tools/summarize_rocprof.py $O/pmc_$L $O/${L}_pmc.json "mm::" > /dev/null
+  if [ "$L" = headline ]; then   # bench.py matches this file by its workload keys (queries / cands / lengths)
+    python tools/summarize_rocprof.py $O/pmc_$L $O/${L}_pmc.json "mm::" > /dev/null
+  else
+    MM_PROF_COMMAND="$CMD" python tools/summarize_rocprof.py $O/pmc_$L $O/${L}_pmc.json "mm::" > /dev/null
+  fi
   find $O/pmc_$L -name "*.db" -delete
   echo "== pmc $L done"
 done
+
+# TKL on full 2,048-token documents (the bench leg runs config 3's own lengths)
+CMD="python tools/bench_tkl.py --full --steps 5"
+rm -rf $O/pmc_tklfull; mkdir -p $O/pmc_tklfull
+rocprofv3 --kernel-trace --stats -d $O/pmc_tklfull/trace -o t -- $CMD > $O/pmc_tklfull/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_tklfull/pmc_fetch -o t -- $CMD > $O/pmc_tklfull/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_tklfull/pmc_write -o t -- $CMD > $O/pmc_tklfull/write.log 2>&1
+MM_PROF_COMMAND="$CMD" python tools/summarize_rocprof.py $O/pmc_tklfull $O/tklfull_pmc.json "mm::" > /dev/null
+find $O/pmc_tklfull -name "*.db" -delete
+echo "== tklfull done"
