@@ -45,6 +45,7 @@ Q, D, E, CANDS = 32, 180, 128, 1000
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_16BIT = 2.5e15     # dense bf16 / fp16 MFMA peak, FLOP/s (MI355X_MICROARCH.md; no sparsity)
 MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+LEAN = False                 # --lean: a leg runs its main measurement only (profiling runs: one workload per kernel name)
 
 
 def algorithmic_bytes(n_queries: int, cands: int) -> int:
@@ -273,7 +274,8 @@ def extra_tk(steps, cpu_budget):
     del q, d
     torch.cuda.empty_cache()
     try:
-        out["exact_f32_mfma"] = tk_exact_f32_subprocess()
+        if not LEAN:
+            out["exact_f32_mfma"] = tk_exact_f32_subprocess()
     except Exception as e:
         out["exact_f32_mfma"] = {"error": repr(e)}
     g = torch.Generator(device=dev).manual_seed(1001)
@@ -341,10 +343,13 @@ def extra_tkl(steps, cpu_budget):
            "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> + tkl_region_kernel (whole mm_tkl_fwd call)",
            "profile": "profiles/r03_tkl_pmc.json, profiles/r03_tkl_trace.json (full documents: profiles/r03_tklfull_pmc.json)"}
     try:
-        out["exact_f32_mfma"] = tkl_exact_f32_subprocess()
+        if not LEAN:
+            out["exact_f32_mfma"] = tkl_exact_f32_subprocess()
     except Exception as e:
         out["exact_f32_mfma"] = {"error": repr(e)}
     try:      # the same length distributions at four times the batch: how much of the 256-document figure is fixed cost
+        if LEAN:
+            raise RuntimeError("skipped (--lean)")
         B4 = 4 * B
         g4 = torch.Generator(device=dev).manual_seed(3004)
         d4 = torch.randn(B4, Dt, Et, generator=g4, device=dev)
@@ -578,8 +583,9 @@ def extra_all_pairs(steps, cpu_budget):
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
            "kernel": "maxsim_allpairs_wg_kernel: 4 wavefronts x 4 queries share one document ring", "profile": "profiles/r03_all_pairs_pmc.json"}
-    t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
-    out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
+    if not LEAN:
+        t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
+        out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         n = 64
@@ -663,12 +669,16 @@ def main():
                     choices=["headline", "dropin_forward", "published_checkpoint", "all_pairs", "tk", "tkl", "dot_topk",
                              "maxsim_fp32", "eval_batch"],
                     help="run ONE leg and print it alone (the command that is put under rocprofv3 --kernel-trace)")
+    ap.add_argument("--lean", action="store_true",
+                    help="with --only: the leg's main measurement alone (no sub-legs, no child processes): what gets profiled")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses device 0 (RCCL test of the N > 1 path on a single-GPU box; RCCL may refuse it)")
     ap.add_argument("--dry", action="store_true",
                     help="launch + collective plumbing only (fabricated scores, value = null); for GPU-less machines")
     args = ap.parse_args()
 
+    global LEAN
+    LEAN = bool(args.lean)
     if args.only == "headline":
         args.no_extras = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

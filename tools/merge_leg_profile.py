@@ -41,8 +41,10 @@ def main():
     f_plain, ms_plain = frac_ms(jp)
     f_tr, ms_tr = frac_ms(jt)
     if ks and ms_tr:
+        # kernels of the leg's timed call: those launched (about) as often as the most-launched one; a kernel that ran
+        # only in a set-up step (a reference computation, a mask conversion done once) is left out
         main_calls = max(k["calls"] for k in ks)
-        per_call_ms = sum(k["total_us"] for k in ks if k["calls"] * 4 >= main_calls) / main_calls / 1e3
+        per_call_ms = sum(k["avg_us"] for k in ks if k["calls"] * 2 >= main_calls) / 1e3
         res["check"] = {"kernels_per_call_ms_from_trace": per_call_ms, "leg_ms_same_process": ms_tr, "leg_ms_untraced": ms_plain,
                         "frac_same_process": f_tr, "frac_untraced": f_plain,
                         "frac_from_trace": (f_tr * ms_tr / per_call_ms) if (f_tr and per_call_ms) else None,

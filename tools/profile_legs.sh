@@ -14,7 +14,7 @@ cd $R
 O=$R/gpurun_out/legs_$TAG; mkdir -p $O
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 for L in $LEGS; do
-  CMD="python bench.py --only $L --no-cpu-baseline --steps 20 --warmup 3"
+  CMD="python bench.py --only $L --lean --no-cpu-baseline --steps 20 --warmup 3"
   $CMD > $O/${L}_plain.log 2>&1
   rm -rf $O/$L; mkdir -p $O/$L
   rocprofv3 --kernel-trace --stats -d $O/$L/trace -o $L -- $CMD > $O/${L}_traced.log 2>&1
@@ -24,7 +24,7 @@ for L in $LEGS; do
   echo "== $L: $(python -c "import json;j=json.load(open('$O/$L.json'));print(j.get('check'))")"
 done
 for L in $PMCL; do
-  CMD="python bench.py --only $L --no-cpu-baseline --steps 10 --warmup 2"
+  CMD="python bench.py --only $L --lean --no-cpu-baseline --steps 10 --warmup 2"
   rm -rf $O/pmc_$L; mkdir -p $O/pmc_$L
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_$L/pmc_fetch -o $L -- $CMD > $O/pmc_$L/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_$L/pmc_write -o $L -- $CMD > $O/pmc_$L/write.log 2>&1
