@@ -35,7 +35,6 @@ const EnvCfg& env() {
     c.kp_f32mfma = env_int("MM_KP_F32MFMA", 0);
     c.dot_prof = env_int("MM_DOT_PROF", 0);
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
-    c.kp_dbg = env_int("MM_KP_DBG", 0);
     return c;
   }();
   return cfg;

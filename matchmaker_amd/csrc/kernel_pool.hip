@@ -438,7 +438,29 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
   load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
 
   const char* dbase = (const char*)a.d;
+  // WPP = 2 with float masks handed over as they are: this workgroup's ONE pair; both wavefronts derive the same words
+  uint32_t iw[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // validity bits of the document's <= 256 positions
+  int ilen = 0;                                   // its effective length (last real token + 1)
+  uint32_t iqbits = 0xffffffffu;
+  int iqlen = 0;
+  const bool inl = WPP == 2 && a.fdm != nullptr;
+  if (WPP == 2 && inl) {
+    const float* m = a.fdm + p0 * (int64_t)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 64 * i + lane;
+      const unsigned long long bal = __ballot(j < D && m[j < D ? j : D - 1] != 0.0f);
+      iw[2 * i] = (uint32_t)bal;
+      iw[2 * i + 1] = (uint32_t)(bal >> 32);
+      if (bal) ilen = 64 * i + 64 - __builtin_clzll(bal);
+    }
+    const int64_t qrow = a.pair_q ? (int64_t)a.pair_q[p0] : p0 / a.ppq;
+    const unsigned long long qb = __ballot(lane < Q && a.fqm[qrow * Q + (lane < Q ? lane : Q - 1)] != 0.0f);
+    iqbits = (uint32_t)qb;
+    iqlen = qb ? 64 - __builtin_clzll(qb) : 0;
+  }
   auto doc_len = [&](int64_t p) -> int {
+    if (WPP == 2 && inl) return ilen;
     int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
     return len < 0 ? 0 : (len > D ? D : len);
   };
@@ -519,10 +541,10 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
       qloL = to_agpr(qloL);
       ss += __shfl_xor(ss, 32, 64);
       rq = 1.0f / (sqrtf(ss) + 1e-13f);
-      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      const int qlen = (WPP == 2 && inl) ? iqlen : (a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q);
       qvalid = r < Q && r < qlen;
-      qbits = a.qm.bits ? sload_u32(a.qm.bits, qi) : 0xffffffffu;
-      if (a.qm.bits) qvalid = qvalid && ((qbits >> r) & 1u);
+      qbits = (WPP == 2 && inl) ? iqbits : (a.qm.bits ? sload_u32(a.qm.bits, qi) : 0xffffffffu);
+      if (a.qm.bits || (WPP == 2 && inl)) qvalid = qvalid && ((qbits >> r) & 1u);
       // queries of <= 21 real tokens: share each query token's epilogue between np = ceil(32 / rows) lanes (see
       // rbf_redistributed): 3 lanes x 11 rows at qn = 20 instead of 2 x 16 with 24 of the 64 lanes idle
       qn = qlen < Q ? (qlen < 0 ? 0 : qlen) : Q;
@@ -628,7 +650,15 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
       }
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      uint32_t va = ex;
+      if (WPP == 2 && inl) {
+        uint32_t wsel = iw[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) wsel = t == i ? iw[i] : wsel;     // (t is wave-uniform; keeps the words in registers)
+        va = wsel & ex;
+      } else if (a.dm.bits) {
+        va = sload_u32(a.dm.bits, pair * nblk_tot + t) & ex;
+      }
       if constexpr (TKL) {
         tkl_block<K>(a.ps_out + pair * (20 * (int64_t)Q * (K + 1)), Q, t, r, h, acc, rdr, rq, va >> (4 * h), rbf);
       } else if (np > 2) {
@@ -946,12 +976,6 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
         }
         x[12] = *(const f32x4*)(buf + l_off);
         __builtin_amdgcn_sched_barrier(0);
-        if (COS && (a.dbg & 2)) {  // removal experiment: the slice is consumed, nothing is computed
-          acc_hh[0] += x[0][0] + x[5][1] + x[12][2];
-          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
-          --inflight;
-          continue;
-        }
         // as in kernel_pool_split_kernel: the slot goes back before the split / MFMA work — after EVERY slice with the cosine
         // hand-off, whose epilogue needs no scratch (three slices in flight throughout: 159.8 -> 149.3 us with two of three
         // slices released early, config 3's full documents)
@@ -1019,9 +1043,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
       const int i0 = 32 * t;
       const int c0 = (i0 * 205) >> 13, r0 = i0 - 40 * c0;
       uint32_t va;
-      if (COS && (a.dbg & 4)) {
-        va = 0xffffffffu;
-      } else {
+      {
         const uint32_t w0 = sload_u32(a.dm.bits, (pair + c0) * 2), w1 = sload_u32(a.dm.bits, (pair + c0) * 2 + 1);
         const unsigned long long b0 = ((unsigned long long)(w1 & 0xffu) << 32) | w0;
         va = (uint32_t)(b0 >> r0);
@@ -1040,7 +1062,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
         // 16-B stores per block: 160.6 vs 160.5 us; ordinary / nt / sc0 sc1: 257.7 / 259.0 / 260.4 us per call — it is the
         // write traffic inside the read stream, so fewer bytes is what helps (no columns past ql: 24.5 MB, not 42.6),
         // and the direct form leaves the ring slot free for an early hand-back.
-        if (!(a.dbg & 1) && r < qlim) {
+        if (r < qlim) {
           float* dst = a.cos_out + qi * ((int64_t)a.C * 40 * Q) + ((int64_t)(slot0 - (int)qi * a.C) * 40 + 32 * t + 4 * h) * qlim + r;
           const uint32_t vbits = va >> (4 * h);
 #pragma unroll
@@ -1051,7 +1073,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
             }
           }
         }
-        if (!(a.dbg & 1) && qlim > 0) {
+        if (qlim > 0) {
           nst = rows_blk / 2;
           pre = inflight;
         }
@@ -1249,6 +1271,7 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
         return check_launch("kernel_pool_split_kernel<2 wavefronts per pair>");
       }
     }
+    if (a.fdm) return set_error(MM_ELAUNCH, "kernel_pool: float masks were left to a kernel that does not read them (internal)");
     if (a.E == 100)
       hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, false, false, W>), grid, block, lds, stream, a);
     else if (a.E == 200)
@@ -1270,7 +1293,6 @@ int tkl_stage1_stream(const float* q_ctx, const float* chunks, PackedMask dm, co
                       int Q, int E, int32_t* slot2p, int64_t n_slots, hipStream_t stream, float* cos_out) {
   KpArgs a{};
   a.cos_out = cos_out;
-  a.dbg = env().kp_dbg;
   a.q = q_ctx; a.d = chunks; a.dm = dm; a.mu = mu; a.sigma = sigma; a.alpha = nullptr; a.w = nullptr;
   a.qm.len = q_len;  // effective query lengths [B] (may be null): pair rows of later tokens are not written
   a.n_pairs = P; a.ppq = 1; a.Q = Q; a.D = 40; a.E = E; a.K = 11;
@@ -1338,7 +1360,17 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
   a.dw = d_gate; a.clamp_min = clamp_min; a.pair_q = pair_query;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
-  if (int e = resolve_mask_pair(q_mask, q_mask_kind, q_rows, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
+  // eval.py-sized calls of TK at E = 100n with float masks: the two-wavefronts-per-pair kernel reads the masks itself
+  // (one launch instead of two: the call is bound by the host, ~4 us per launch)
+  const bool inline_masks = K == 11 && !d_gate && q_mask_kind == MM_MASK_F32 && d_mask_kind == MM_MASK_F32 && q_mask && d_mask &&
+                            Q <= 32 && D > 32 && D <= 256 && (E == 100 || E == 200 || E == 300) && n_pairs * 2 <= (int64_t)kCUs * 4 &&
+                            !env().kp_generic && !env().kp_f32mfma;
+  if (inline_masks) {
+    a.fqm = (const float*)q_mask;
+    a.fdm = (const float*)d_mask;
+  } else if (int e = resolve_mask_pair(q_mask, q_mask_kind, q_rows, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) {
+    return e;
+  }
   if (K == 11) return launch_k<11>(a, stream);
   // any other kernel count (the lists in tk_kernels_mu / knrm_kernels are configuration): the generic kernel with
   // run-time K

@@ -42,7 +42,6 @@ struct KpArgs {
   // (position, token) across HBM instead of 24, and the transcendental work runs on sixteen thin wavefronts per CU
   // instead of one fat wavefront per SIMD
   float* cos_out;
-  int dbg;  // MM_KP_DBG (measurement by removal, TKL stage 1 only): 1 = no cosine stores, 2 = no split / MFMA, 4 = no mask words
   // variants of the pooling block (same arithmetic family):
   //   dw != nullptr: per document token gate >= 0 multiplying all its activations (TK-Sparse stop-word
   //   vector, cikm20_tk_sparse.py:133-135), [n_pairs, D] float32;
@@ -55,6 +54,11 @@ struct KpArgs {
   // several (query tensor, document tensor) combinations in ONE launch (Conv-KNRM's n_grams^2 match matrices,
   // conv_knrm.py:130-132): blockIdx.y = i * n_md + t scores q = mq[i] against d = md[t] with the bin weights
   // w + y * K and writes its scores to out + y * n_pairs (summed in block order afterwards).  n_md = 0: one combination.
+  // eval.py-sized calls (two wavefronts per pair, one pair per workgroup): the float {0, 1} masks as the caller passes them,
+  // [q rows, Q] / [n_pairs, D] with Q <= 32, D <= 256 — read by the kernel itself (lane loads + ballots) instead of by a
+  // mask-packing launch in front of it; qm / dm stay empty then
+  const float* fqm;
+  const float* fdm;
   const float* mq[4];
   const float* md[4];
   int n_md;

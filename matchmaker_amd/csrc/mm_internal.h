@@ -34,7 +34,6 @@ struct EnvCfg {
   int kp_generic = 0;       // MM_KP_GENERIC: force the generic pooling kernel
   int kp_f32mfma = 0;       // MM_KP_F32MFMA: exact-f32 MFMA pooling kernel instead of split-bf16
   int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
-  int kp_dbg = 0;           // MM_KP_DBG: removal experiments in TKL stage 1 (see KpArgs::dbg); never set in production
   int tkl_pairsums = 0;     // MM_TKL_PAIRSUMS: TKL stage 1 emits pair sums (round-2 data path) instead of cosines (A/B runs)
 };
 const EnvCfg& env();

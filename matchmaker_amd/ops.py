@@ -117,9 +117,25 @@ def _on(dev):
     return _NOCTX if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
+_WSB = {}
+
+
+def _ws_bytes(fn, *key):
+    """Workspace size of a call shape (a pure function of the integers in `key`): one ctypes round trip per shape, not per call."""
+    k = (fn.__name__,) + key
+    v = _WSB.get(k)
+    if v is None:
+        if len(_WSB) > 4096:
+            _WSB.clear()
+        v = _WSB[k] = fn(*key)
+    return v
+
+
 def _vec(t: torch.Tensor) -> torch.Tensor:
-    """float32 contiguous 1-D view of a small parameter tensor (no copy, no dispatch when it already is one)."""
-    if t.dtype is torch.float32 and t.dim() == 1 and t.is_contiguous() and not t.requires_grad:
+    """A small parameter tensor as float32 contiguous memory.  Only its data pointer and element count are used, so a
+    contiguous fp32 tensor of any shape is taken as it is — the models' own buffers / parameters (`mu` [1,1,1,K],
+    `kernel_alpha_scaler` [1,1,K], `kernel_bin_weights.weight` [1,K]) cost no dispatch per call."""
+    if t.dtype is torch.float32 and t.is_contiguous():
         return t
     return t.detach().reshape(-1).to(torch.float32).contiguous()
 
@@ -149,7 +165,7 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
         return out
     q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
     with _on(dev):
-        wsb = L.mm_maxsim_workspace_bytes(B, pairs_per_query, Q, D, qk, dk)
+        wsb = _ws_bytes(L.mm_maxsim_workspace_bytes, B, pairs_per_query, Q, D, qk, dk)
         ws = _workspace(dev, wsb)
         rc = L.mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), B, pairs_per_query,
                              Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
@@ -327,7 +343,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     if B:
         q, d, E = _pad_rows(q, d, 4)
         with _on(dev):
-            wsb = L.mm_kernel_pool_workspace_bytes(max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
+            wsb = _ws_bytes(L.mm_kernel_pool_workspace_bytes, max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
             ws = _workspace(dev, wsb)
             rc = L.mm_kernel_pool_ex_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
                                          gate.data_ptr() if gate is not None else None,
