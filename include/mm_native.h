@@ -249,6 +249,10 @@ int mm_kernel_pool_ex_bwd(const void* q, const void* d,
  *   saturation   0 = "embedding" (:224-234), 1 = "log" (:245-246)
  *   win_scores   [B, W] float32 out (W = (max(C*40,30) - 30)/2 + 1), may be NULL if workspace given
  *   out          [B] float32
+ *   workspace    mm_tkl_workspace_bytes() bytes of device scratch: the slot -> packed-chunk map, the hand-off between the
+ *                match stage and the window stage (the scaled, masked cosines of the real query tokens, 4 B per document
+ *                position and token; on the A/B paths the pair sums of round 2), packed masks, and the partial window
+ *                scores of the query-token groups.  Nothing in it survives the call.
  */
 #define MM_TKL_NPARAMS(K, E) (4 * (K) + 13 + 15 + (E))
 #define MM_TKL_SAT_EMBEDDING 0

@@ -32,17 +32,26 @@ def test_maxsim_one_rank_shard_of_config4():
     assert torch.equal(out, ops.maxsim(q, d, q_len, d_len, pairs_per_query=C)), "non-deterministic"
     half = ops.maxsim((q.float() * 0.5).to(torch.bfloat16), d, q_len, d_len, pairs_per_query=C)
     assert torch.equal(half, out * 0.5)
+    # EVERY query of the shard: scores and rank order.  Oracle = the torch port of colbert.py:68-75 on CPU tensors in fp32
+    # and fp64 (multi-threaded: 16 candidate lists per call; the numpy restatement took 130 s for the 873 lists)
+    from oracle import torch_port as TP
     rows = []
-    for i in range(nq):                                    # EVERY query of the shard: scores and rank order
-        dn = d[i * C:(i + 1) * C].float().cpu().numpy()
-        dm = synth.len_to_mask(d_len[i * C:(i + 1) * C], 180).cpu().numpy()
-        qm = np.repeat(synth.len_to_mask(q_len[i:i + 1], 32).cpu().numpy(), C, 0)
-        qr = np.repeat(q[i:i + 1].float().cpu().numpy(), C, 0)
-        ref = O.maxsim_paired(qr, dn, qm, dm)
-        ref64 = O.maxsim_paired(qr, dn, qm, dm, dtype=np.float64)
-        got = out[i * C:(i + 1) * C].cpu().numpy()
+    G = 16
+    for i0 in range(0, nq, G):
+        i1 = min(nq, i0 + G)
+        n = i1 - i0
+        dn = d[i0 * C:i1 * C].float().cpu()
+        dm = synth.len_to_mask(d_len[i0 * C:i1 * C], 180).cpu()
+        qm = synth.len_to_mask(q_len[i0:i1], 32).cpu().repeat_interleave(C, 0)
+        qr = q[i0:i1].float().cpu().repeat_interleave(C, 0)
+        with torch.no_grad():
+            ref = TP.maxsim_forward(qr, dn, qm, dm).numpy()
+            ref64 = TP.maxsim_forward(qr.double(), dn.double(), qm, dm).numpy()
+        got = out[i0 * C:i1 * C].cpu().numpy()
         np.testing.assert_allclose(got, ref, atol=util.TOL_BF16)
-        rows.append(util.rank_parity(got, ref, ref64, (1, 10, 100, 1000), label=f"shard query {i}"))
+        for j in range(n):
+            sl = slice(j * C, (j + 1) * C)
+            rows.append(util.rank_parity(got[sl], ref[sl], ref64[sl], (1, 10, 100, 1000), label=f"shard query {i0 + j}"))
     assert util.rank_report("config4_one_rank_shard", rows) >= 0.99
     # the ranking this rank contributes is a permutation of its candidates, best first
     ranking = sharding.rank_candidates(out.view(nq, C))
