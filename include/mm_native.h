@@ -240,7 +240,9 @@ int mm_kernel_pool_ex_bwd(const void* q, const void* d,
  *   chunks       [P, 50, E]  contextualised packed chunks (output of :172); the 40 centre
  *                            tokens of each are used (:174)
  *   chunk_mask   [P, 50]     float {0,1} (padding_packed, :163)
- *   chunk_slot   [P] int32   flat slot b*C + c of each packed chunk (packed_indices :159, as indices)
+ *   chunk_slot   [P] int32   flat slot b*C + c of each packed chunk (packed_indices :159, as indices), ASCENDING — the order
+ *                            boolean-mask packing (:160-162) and torch.nonzero produce; the kernels rely on a document's
+ *                            chunks being adjacent and on its last kept chunk coming last
  *   q_mask       [B, Q]      float {0,1}
  *   params       float32[MM_TKL_NPARAMS(K, E)] device, packed as (matchmaker_amd/tkl.py pack_params()):
  *                  mu[K] sigma[K] dense.weight[K] kernel_mult[0][K]

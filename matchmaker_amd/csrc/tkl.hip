@@ -22,6 +22,7 @@ constexpr int kWinPairs = 15; // 30 positions, stride 2
 constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows staged: kWT + 14)
 constexpr int kWThreads = 256;
 constexpr int kTokGroup = 10;  // query tokens per window workgroup (see tkl_window_kernel)
+constexpr int kRThreads = 256;  // region kernel (1,024 threads, one window each, measured slower: 11.3 vs 9.8-10.5 us)
 
 
 // Preparation in ONE launch (round 1: memset + emb + two mask packs + slot map = five, ~25 us of a 0.3 ms call) —
@@ -42,7 +43,8 @@ __global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slo
                                                        const float* __restrict__ q_mask, int64_t B, int Q, int n_q,
                                                        int32_t* __restrict__ qlen_out, uint32_t* __restrict__ qbits_out,
                                                        const float* __restrict__ chunk_mask, int64_t P,
-                                                       int32_t* __restrict__ clen_out, uint32_t* __restrict__ cbits_out) {
+                                                       int32_t* __restrict__ clen_out, uint32_t* __restrict__ cbits_out,
+                                                       const int32_t* __restrict__ chunk_slot, int C, int32_t* __restrict__ ntile) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   if (blk < n_fill) {
@@ -90,6 +92,12 @@ __global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slo
     clen_out[p] = bal ? 64 - __builtin_clzll(bal) : 0;
     cbits_out[p * 2] = (uint32_t)bal;
     cbits_out[p * 2 + 1] = (uint32_t)(bal >> 32);
+    // The LAST kept chunk of a document bounds its live window tiles: windows w <= 20 c + 19 touch chunk c.  A hint for the
+    // window kernel's early exit only — a document without kept chunks leaves its entry unwritten, and whatever stale
+    // value stands there, every tile of such a document is empty and comes out as zeros on either side of the test.
+    const int sl = chunk_slot[p];
+    const int nx = p + 1 < P ? chunk_slot[p + 1] : -1;
+    if (nx < 0 || nx / C != sl / C) ntile[sl / C] = (kU * (sl % C) + kU - 1) / kWT + 1;
   }
 }
 
@@ -159,18 +167,17 @@ __device__ __forceinline__ void window_items(const float* tile, float* red, cons
         const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];              // :230
         const float s2 = 1.0f / (n0 * sp[3] + n1 * sp[4] + sp[5]);      // :231
         const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];              // :232
-        // sum_k dense_k (s1 x_k^s2 - s3) factor  =  factor (s1 sum_k dense_k x_k^s2 - s3 sum_k dense_k): one fma per kernel
-        // instead of three operations (:234, :248, :251 folded; the dense weights' sum is a wave-uniform constant)
-        float acc = 0.0f, dsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < kK; ++k) {
           // x^s2 = exp2(s2 * log2 x) on the hardware transcendentals (x >= 1e-10 > 0): 3 instructions
           // instead of ~80 for powf; |s2 * log2 x| <= ~33 |s2| keeps the error ~1e-6 relative
           const float xp = __builtin_amdgcn_exp2f(s2 * __builtin_amdgcn_logf(fmaxf(pk[k], 1e-10f)));
-          acc += prm[TklParams::dense() + k] * xp;
-          dsum += prm[TklParams::dense() + k];
+          const float sat = s1 * xp - s3;  // :234
+          // (folding this to factor (s1 sum_k w_k x_k^s2 - s3 sum_k w_k) saves two operations per kernel and was tried:
+          // with the reference's biases of 100 in s1 and s3 the two sums cancel to ~1 % of their size, and the window
+          // error against fp64 grew from 9e-7 to 7e-6 — more than the reference's own fp32 evaluation makes)
+          val += prm[TklParams::dense() + k] * (sat * factor);
         }
-        val = factor * (s1 * acc - s3 * dsum);
       } else {
 #pragma unroll
         for (int k = 0; k < kK; ++k) {
@@ -207,7 +214,7 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
                                                          const float* __restrict__ q_mask,
                                                          const int32_t* __restrict__ q_len,
                                                          const float* __restrict__ prm, float* __restrict__ win,
-                                                         int C, int Q, int W, int lds_bytes) {
+                                                         int C, int Q, int W, int lds_bytes, const int32_t* __restrict__ ntile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y;
   const int w0 = blockIdx.x * kWT;
@@ -225,6 +232,12 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   const int qfull = ql;                               // row stride of this document's cosine rows (stage 1 stores real tokens only)
   ql = ql - t0 < kTokGroup ? ql - t0 : kTokGroup;     // this group's tokens (local index i = token t0 + i)
   if (ql <= 0) return;                                // no token of this group is real: the region kernel skips the plane
+  // tiles past the document's last kept chunk are empty (half of all tiles at config 3's U{50..2048} lengths): out after
+  // one scalar load instead of after the lookup barrier (tkl_prep_kernel's hint, see there)
+  if ((int)blockIdx.x >= ntile[b]) {
+    if (tid < kWT && w0 + tid < W) win[(int64_t)b * W + w0 + tid] = 0.0f;
+    return;
+  }
   int wt = kWT;
   while (wt > 4 && window_pass_bytes(wt, ql) > (size_t)lds_bytes) wt >>= 1;
   const int nu = wt + kWinPairs - 1;                  // pair rows needed by one pass
@@ -420,12 +433,12 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
 // One 256-thread workgroup per document: region top-k over the window scores (:254-286).  (One wavefront per
 // document spent 16 us on sixteen dependent 4-byte loads per lane; four wavefronts load the ~1,000 scores of a
 // 2,048-token document in four rounds and share the arg-max.)
-__global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict__ part, int n_planes, int64_t plane,
+__global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* __restrict__ part, int n_planes, int64_t plane,
                                                          const int32_t* __restrict__ q_len, float* __restrict__ win,
                                                          const float* __restrict__ prm, float* __restrict__ out, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float rv[4];
-  __shared__ int ri[4];
+  __shared__ float rv[kRThreads / 64];
+  __shared__ int ri[kRThreads / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int Wp = W < 3 ? 3 : W;                                        // :254-255
   float* orig = (float*)smem;                                          // [Wp]
@@ -438,7 +451,7 @@ __global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict
     np = ql <= 0 ? 0 : (ql + kTokGroup - 1) / kTokGroup;
     np = np < n_planes ? np : n_planes;
   }
-  for (int w = tid; w < Wp; w += 256) {
+  for (int w = tid; w < Wp; w += kRThreads) {
     float s = 0.0f;
     if (w < W) {
       for (int g = 0; g < np; ++g) s += part[g * plane + (int64_t)b * W + w];
@@ -453,7 +466,7 @@ __global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict
   for (int c = 0; c < 3; ++c) {                                        // :268-273
     float bv = -__builtin_huge_valf();
     int bi = 0x7fffffff;
-    for (int w = tid; w < Wp; w += 256) {
+    for (int w = tid; w < Wp; w += kRThreads) {
       const float v = work[w];
       if (v > bv) { bv = v; bi = w; }                                  // first maximal index within the thread
     }
@@ -466,31 +479,34 @@ __global__ void __launch_bounds__(256) tkl_region_kernel(const float* __restrict
     if (lane == 0) { rv[wv] = bv; ri[wv] = bi; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kRThreads / 64; ++k) {
       const float ov = rv[k];
       const int oi = ri[k];
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
     top[c] = bi;
     __syncthreads();                                                   // rv / ri are read; work may change
-    for (int w = tid; w < Wp; w += 256) {
+    for (int w = tid; w < Wp; w += kRThreads) {
       const int dlt = w > bi ? w - bi : bi - w;
       if (dlt < 15) work[w] = -10001.0f - (float)c;                    // |r - best| < 30/2
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    const int offs[5] = {0, -1, 1, -2, 2};                             // :276 peaks, -1, +1, -2, +2
-    float s = 0.0f;
-    for (int g = 0; g < 5; ++g)
-      for (int c = 0; c < 3; ++c) {
-        int idx = top[c] + offs[g];
-        idx = idx < 0 ? 0 : (idx >= Wp ? Wp - 1 : idx);                // :277-278
-        float v = orig[idx];
-        if (v <= -9900.0f) v = 0.0f;                                   // :282
-        s += v * prm[TklParams::chunk_scoring() + g * 3 + c];          // :286
-      }
-    out[b] = s;
+  if (tid < 64) {
+    // the 15 terms of :286 on 15 lanes (thread 0 walking them one after the other was a chain of 15 dependent loads of
+    // the chunk_scoring weights at the end of every document's workgroup), summed by a fixed shuffle tree
+    float term = 0.0f;
+    if (lane < 15) {
+      const int g = lane / 3, c = lane - 3 * g;
+      const int off = g == 0 ? 0 : (g == 1 ? -1 : (g == 2 ? 1 : (g == 3 ? -2 : 2)));   // :276 peaks, -1, +1, -2, +2
+      int idx = (c == 0 ? top[0] : (c == 1 ? top[1] : top[2])) + off;
+      idx = idx < 0 ? 0 : (idx >= Wp ? Wp - 1 : idx);                  // :277-278
+      float v = orig[idx];
+      if (v <= -9900.0f) v = 0.0f;                                     // :282
+      term = v * prm[TklParams::chunk_scoring() + lane];               // :286 (weight index g * 3 + c = lane)
+    }
+    const float s = wave_sum(term);
+    if (lane == 0) out[b] = s;
   }
 }
 
@@ -512,7 +528,8 @@ extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int
   return align256((size_t)B * C * 4) + handoff_bytes(B, P, C, Q) +
          packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4) +
          packed_mask_bytes(MM_MASK_F32, B, Q) +  // + the packed query mask (effective lengths)
-         align256((size_t)((Q + kTokGroup - 1) / kTokGroup) * B * W * 4);  // + the token groups' partial window scores
+         align256((size_t)((Q + kTokGroup - 1) / kTokGroup) * B * W * 4) +  // + the token groups' partial window scores
+         align256((size_t)B * 4);                                          // + live window tiles per document
 }
 
 extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
@@ -549,6 +566,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   // chunk masks (effective length + validity bits of the 40 centre tokens)
   PackedMask qmk, dm;
   float* planes = nullptr;                              // [n_planes][B][W] partial window scores of the token groups
+  int32_t* ntile = nullptr;                             // [B] live window tiles per document (tkl_prep_kernel)
   const int n_planes = (Q + kTokGroup - 1) / kTokGroup;
   {
     if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
@@ -558,6 +576,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     uint32_t* cbits = (uint32_t*)(ws + (size_t)P * 4);
     char* qws = (char*)emb + align256((size_t)B * Q * 4);
     planes = (float*)(qws + packed_mask_bytes(MM_MASK_F32, B, Q));
+    ntile = (int32_t*)((char*)planes + align256((size_t)n_planes * B * W * 4));
     int32_t* qlen = (int32_t*)qws;
     uint32_t* qbits = (uint32_t*)(qws + (size_t)B * 4);
     const int n_fill = (int)((B * (int64_t)C + 255) / 256);
@@ -566,7 +585,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     const int n_chunk = (int)((P + 3) / 4);
     hipLaunchKernelGGL(tkl_prep_kernel, dim3((unsigned)(n_fill + n_emb + n_q + n_chunk)), dim3(256), 0, stream, slot2p,
                        B * (int64_t)C, n_fill, (const float*)q_ctx, params, emb, B * (int64_t)Q, E, n_emb, q_mask, B, Q, n_q,
-                       qlen, qbits, chunk_mask, P, clen, cbits);
+                       qlen, qbits, chunk_mask, P, clen, cbits, chunk_slot, C, ntile);
     if (int e = check_launch("tkl_prep_kernel")) return e;
     qmk.len = qlen;
     qmk.bits = qbits;
@@ -595,7 +614,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     auto launch = [&](auto kern) {
       if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, grid2, dim3(kWThreads), lds2, stream, (const float*)ps, (const int32_t*)slot2p, (const float*)emb, q_mask,
-                         (const int32_t*)qmk.len, params, wdst, C, Q, W, (int)lds2);
+                         (const int32_t*)qmk.len, params, wdst, C, Q, W, (int)lds2, (const int32_t*)ntile);
     };
     if (saturation == MM_TKL_SAT_EMBEDDING) {
       if (use_cos) launch(tkl_window_kernel<MM_TKL_SAT_EMBEDDING, true>);
@@ -607,7 +626,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     if (int e = check_launch("tkl_window_kernel")) return e;
   }
   const int Wp = W < 3 ? 3 : W;
-  hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(256), (size_t)Wp * 8, stream,
+  hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(kRThreads), (size_t)Wp * 8, stream,
                      (const float*)(n_planes > 1 ? planes : win), n_planes, (int64_t)B * W, (const int32_t*)qmk.len, win, params, out, W);
   return check_launch("tkl_region_kernel");
 }
