@@ -176,12 +176,23 @@ def profile_summary(pattern, kernel_substr, key):
     return best
 
 
-def gpu_time_ms(fn, steps, warmup=2):
-    """Median of per-call HIP-event times on the current stream (the stream the operators launch on)."""
+def gpu_time_ms(fn, steps, warmup=2, warm_ms=40.0, timed_ms=25.0, max_calls=400):
+    """Median of per-call HIP-event times on the current stream (the stream the operators launch on), in steady state:
+    after `warmup` calls the call is repeated until ~warm_ms of device time have passed, and at least `steps` calls — as
+    many as ~timed_ms of device time hold — are timed.  A leg whose call takes 0.15-1.5 ms is otherwise measured while the
+    GPU still climbs out of its idle clocks: the first ten launches of the 1.4 ms all-pairs kernel ran 12 % slower than
+    the next ten in the same process (1.54 vs 1.37 ms); an evaluation loop keeps the device busy."""
     import torch
     for _ in range(warmup):
         fn()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = max(a.elapsed_time(b), 1e-3)
+    for _ in range(min(max_calls, int(warm_ms / t))):
+        fn()
+    n = min(max_calls, max(steps, int(timed_ms / t)))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:
         a.record(); fn(); b.record()
     torch.cuda.synchronize()

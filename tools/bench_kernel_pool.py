@@ -33,13 +33,8 @@ p = [torch.tensor([1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9], 
      torch.ones(11, device=dev), torch.linspace(-0.014, 0.014, 11, device=dev)]
 kw = dict(pairs_per_query=a.cands, clamp_min=a.clamp,
           d_gate=torch.relu(torch.randn(B, D, generator=g, device=dev)) if a.gate else None)
-for _ in range(3):
-    ops.kernel_pool(q, d, q_len, d_len, *p, **kw)
-ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-for s, e in ev:
-    s.record(); ops.kernel_pool(q, d, q_len, d_len, *p, **kw); e.record()
-torch.cuda.synchronize()
-ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+import bench
+ms = bench.gpu_time_ms(lambda: ops.kernel_pool(q, d, q_len, d_len, *p, **kw), a.steps, warmup=3)
 useful = int(((d_len + 31) // 32 * 32).clamp(max=D).sum().item()) * E * 4
 padded = B * D * E * 4
 print(json.dumps({"pairs_per_s": B / (ms * 1e-3), "ms": ms, "GBps_padded_bytes": padded / ms / 1e6,

@@ -32,13 +32,8 @@ del d
 params = m.pack_params()
 P = chunks.shape[0]
 fn = lambda: ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, "embedding")
-for _ in range(3):
-    fn()
-ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-for s, e in ev:
-    s.record(); fn(); e.record()
-torch.cuda.synchronize()
-ms = sorted(s.elapsed_time(e) for s, e in ev)[len(ev) // 2]
+import bench
+ms = bench.gpu_time_ms(fn, a.steps, warmup=3)      # steady state: warmed up for ~40 ms of device time first
 byt = P * 50 * E * 4 + B * Q * E * 4 + P * 50 * 4 + 4 * B
 print(json.dumps({"docs_per_s": B / (ms * 1e-3), "ms": ms, "GBps_algorithmic": byt / ms / 1e6, "B": B, "P": P, "C": C,
                   "bytes": byt}))
