@@ -35,6 +35,22 @@ def main():
         ks = [{"name": r[0][:160], "calls": r[1], "total_us": r[2], "avg_us": r[3], "pct": r[4]}
               for r in rows if pat in r[0]]
         if tag == "trace" or tag.startswith("trace"):
+            # per-dispatch durations (the `kernels` view): the median and the mean of the later half of the launches sit
+            # beside the --stats average, which also counts a process's first, cold-clock launches
+            try:
+                per = {}
+                for name, dur in cur.execute("select name, duration from kernels order by start"):
+                    per.setdefault(name, []).append(dur)
+                for k, r in zip(ks, [r for r in rows if pat in r[0]]):
+                    d = per.get(r[0])
+                    if d:
+                        sd = sorted(d)
+                        late = d[len(d) // 2:]
+                        k["median_us"] = sd[len(sd) // 2] / 1e3
+                        k["late_half_avg_us"] = sum(late) / len(late) / 1e3
+                        k["min_us"] = sd[0] / 1e3
+            except sqlite3.Error:
+                pass
             res["kernel_trace"] += ks
             res["kernel_trace_all_top5"] = [{"name": r[0][:100], "calls": r[1], "avg_us": r[3], "pct": r[4]} for r in rows[:5]]
         try:
