@@ -30,6 +30,8 @@ const EnvCfg& env() {
     c.maxsim_generic = env_int("MM_MAXSIM_GENERIC", 0);
     c.maxsim_inb_untiled = env_int("MM_MAXSIM_INB_UNTILED", 0);
     c.maxsim_inb_nowg = env_int("MM_MAXSIM_INB_NOWG", 0);
+    c.maxsim_no_inline_masks = env_int("MM_MAXSIM_NO_INLINE_MASKS", 0);
+    c.maxsim_no_wpp2 = env_int("MM_MAXSIM_NO_WPP2", 0);
     c.maxsim_f32_terms = env_int("MM_MAXSIM_F32_TERMS", 3) == 2 ? 2 : 3;
     c.kp_generic = env_int("MM_KP_GENERIC", 0);
     c.kp_f32mfma = env_int("MM_KP_F32MFMA", 0);

@@ -36,11 +36,19 @@ namespace mm {
 // (xcd = blockIdx % 8, t, jg) sweeps document slice xcd * T + t of 8T for the query groups jg, jg + Gw, ... — the
 // wavefronts of one XCD stream the same documents for different queries at the same time, so a slice comes through
 // that XCD's L2 once per sweep instead of once per group.
-template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB>
+// IM: the tokenizer's int64 masks are read by the kernel itself (lane loads + ballots before the first block is put in
+// flight) — for launches in which every wavefront scores ONE pair, i.e. eval.py-sized calls of 512 pairs, where the separate
+// mask-packing launch was 11 of the call's 45 us at the published checkpoint's shapes.
+// WPP = 2 (with IM): TWO wavefronts per pair — when a call has fewer pairs than half the wavefront slots (512 pairs on 1,024
+// SIMDs) wavefront w streams blocks w, w + 2, ... of the pair through its own ring and the running maxima meet in LDS once.
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB, bool IM = false, int WPP = 1>
 __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
+  static_assert(WPP == 1 || (IM && NQT >= 2 && !RAG && INB == 0), "two wavefronts per pair: the one-pair-per-workgroup launches only");
   constexpr int RB = NSL * 256;  // bytes per token row
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int lane = WPP > 1 ? (threadIdx.x & 63) : threadIdx.x;
+  const int wv = WPP > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  char* const smem = smem_all + wv * (NBUF * kBlkBytes);   // this wavefront's ring
   const int r = lane & 31, h = lane >> 5;
   int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
   int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
@@ -92,7 +100,28 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
     if (INB == 2) return doc_row(p);
     return INB ? (a.inb_bug ? p / a.inb_bd : p % a.inb_bd) : p;
   };
+  // IM: validity bits of this wavefront's pair (D <= 256, Q <= 64) and its length = last real token + 1, the values
+  // pack_mask2_kernel would have written (common.hip)
+  unsigned long long ib0 = 0, ib1 = 0, ib2 = 0, ib3 = 0, iq = 0;
+  int ilen = 0;
+  if constexpr (IM) {
+    const int64_t* dmr = a.dm64 + p0 * D;
+    const int64_t* qmr = a.qm64 + (p0 / ppq) * Q;
+    const int64_t v0 = lane < D ? dmr[lane] : 0;
+    const int64_t v1 = 64 + lane < D ? dmr[64 + lane] : 0;
+    const int64_t v2 = 128 + lane < D ? dmr[128 + lane] : 0;
+    const int64_t v3 = 192 + lane < D ? dmr[192 + lane] : 0;
+    const int64_t vq = lane < Q ? qmr[lane] : 0;
+    ib0 = __ballot(v0 != 0);
+    ib1 = __ballot(v1 != 0);
+    ib2 = __ballot(v2 != 0);
+    ib3 = __ballot(v3 != 0);
+    iq = __ballot(vq != 0);
+    ilen = ib3 ? 256 - __builtin_clzll(ib3) : ib2 ? 192 - __builtin_clzll(ib2) : ib1 ? 128 - __builtin_clzll(ib1)
+                                                                               : ib0 ? 64 - __builtin_clzll(ib0) : 0;
+  }
   auto doc_len = [&](int64_t p) -> int {
+    if (IM) return ilen;
     if (RAG) {
       const int64_t l = sload_i64(a.rag_end, p) - sload_i64(a.rag_begin, p);
       return l < 0 ? 0 : (l > 0x7fffffe0LL ? 0x7fffffe0 : (int)l);
@@ -103,8 +132,8 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
 
   // ---- producer cursor: next (pair, block, slice) to put in flight ---------------------------
   int64_t pp = p0;
-  int pt = 0, pn = 0, psl = 0, plen = 0;
-  while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) == 0) ++pp;
+  int pt = wv, pn = 0, psl = 0, plen = 0;
+  while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) <= wv) ++pp;   // (WPP = 1: skips empty documents)
   int64_t prow0 = (INB == 2 && pp < p1) ? doc_row(pp) * D : 0;
   int pbuf = 0, cbuf = 0, inflight = 0;
 
@@ -137,10 +166,11 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
       ++inflight;
       if (NSL > 1 && ++psl < NSL) continue;
       psl = 0;
-      if (++pt == pn) {
-        pt = 0;
+      pt += WPP;
+      if (pt >= pn) {
+        pt = wv;
         ++pp;
-        while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) == 0) ++pp;
+        while (pp < p1 && (pn = ((plen = doc_len(pp)) + 31) >> 5) <= wv) ++pp;
         if (INB == 2 && pp < p1) prow0 = doc_row(pp) * D;
       }
     }
@@ -181,7 +211,7 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
           if (a.qm.bits) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qq) >> r) & 1u);   // Q <= 32: one word per query
         }
       } else {
-        const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+        const int qlen = (!IM && a.qm.len) ? (int)sload_u32(a.qm.len, qi) : Q;
 #pragma unroll
         for (int n = 0; n < NQT; ++n) {
           const int qt = 32 * n + r;
@@ -190,7 +220,8 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
 #pragma unroll
           for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
           qvalid[n] = qt < Q && qt < qlen;
-          if (a.qm.bits && n < qwords) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qi * qwords + n) >> r) & 1u);
+          if (IM) qvalid[n] = qvalid[n] && ((iq >> qt) & 1ull);
+          else if (a.qm.bits && n < qwords) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qi * qwords + n) >> r) & 1u);
         }
       }
     }
@@ -210,7 +241,7 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
       for (int i = 0; i < 16; ++i) m[n][i] = fill;
     }
 
-    for (int t = 0; t < nb; ++t) {
+    for (int t = wv; t < nb; t += WPP) {
       f32x16 acc[NQT];
 #pragma unroll
       for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
@@ -230,7 +261,13 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
       }
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-      const uint32_t va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, mask_row(pair) * nblk_tot + t) & ex) : ex;
+      uint32_t va;
+      if (IM) {
+        const unsigned long long w = t < 2 ? ib0 : t < 4 ? ib1 : t < 6 ? ib2 : ib3;
+        va = (uint32_t)(w >> (32 * (t & 1))) & ex;
+      } else {
+        va = (!RAG && a.dm.bits) ? (sload_u32(a.dm.bits, mask_row(pair) * nblk_tot + t) & ex) : ex;
+      }
 #pragma unroll
       for (int n = 0; n < NQT; ++n) {
         if (ONE) block_max1(m1[n], acc[n], ex, va, fill, h);
@@ -246,6 +283,18 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
         if (lane == 0 && qq < a.inb_bq) a.out[qq * a.inb_bd + dj] = s;
       }
     } else {
+      if constexpr (WPP > 1) {
+        // the second wavefront's maxima (its ring is drained: every block it requested has been consumed)
+        float* comb = (float*)(smem_all + WPP * NBUF * kBlkBytes);   // [NQT][64]
+        if (wv == 1) {
+#pragma unroll
+          for (int n = 0; n < NQT; ++n) comb[n * 64 + lane] = m1[n];
+        }
+        __syncthreads();
+        if (wv == 1) return;
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) m1[n] = fmaxf(m1[n], comb[n * 64 + lane]);
+      }
       float s = 0.0f;
 #pragma unroll
       for (int n = 0; n < NQT; ++n)  // tiles in index order: deterministic
@@ -255,9 +304,14 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
   }
 }
 
-template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB = 0>
+template <int DT, int NBUF, bool NT, int NSL, bool RAG, int NQT, int INB = 0, bool IM = false>
 __global__ void __launch_bounds__(64) maxsim_stream_kernel(const MaxsimArgs a) {
-  maxsim_stream_body<DT, NBUF, NT, NSL, RAG, NQT, INB>(a);
+  maxsim_stream_body<DT, NBUF, NT, NSL, RAG, NQT, INB, IM>(a);
+}
+
+template <int DT, int NBUF, bool NT, int NSL, int NQT>
+__global__ void __launch_bounds__(128) maxsim_stream_wpp2_kernel(const MaxsimArgs a) {
+  maxsim_stream_body<DT, NBUF, NT, NSL, false, NQT, 0, true, 2>(a);
 }
 
 // The tiled all-pairs instantiations are compiled for two wavefronts per SIMD (<= 256 registers): that makes the
@@ -674,8 +728,26 @@ static int launch_stream(const MaxsimArgs& a0, hipStream_t stream) {
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  if constexpr (NQT == 2 && !RAG) {      // (a query of <= 32 tokens in this layout is the pair kernel's, maxsim_pair.hip)
+    if (a.dm64) {
+      if (a.pairs_per_wave != 1) return set_error(MM_EINVAL, "maxsim: in-kernel masks need one pair per wavefront");
+      if (a.n_pairs * 2 <= (int64_t)kCUs * 4 && a.D > 32 && !env().maxsim_no_wpp2) {
+        hipLaunchKernelGGL((maxsim_stream_wpp2_kernel<DT, NBUF, NT, NSL, NQT>), dim3((unsigned)waves), dim3(128), 2 * lds + NQT * 256, stream, a);
+        return check_launch("maxsim_stream_wpp2_kernel");
+      }
+      hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL, RAG, NQT, 0, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+      return check_launch("maxsim_stream_kernel<in-kernel masks>");
+    }
+  }
   hipLaunchKernelGGL((maxsim_stream_kernel<DT, NBUF, NT, NSL, RAG, NQT>), dim3((unsigned)waves), dim3(64), lds, stream, a);
   return check_launch("maxsim_stream_kernel");
+}
+
+// every wavefront of launch_stream<.., NBUF = 2, ..> gets at most one pair
+static bool stream_one_pair_per_wave(int64_t n_pairs) {
+  int wpc = env().maxsim_wpc > 0 ? env().maxsim_wpc : (160 * 1024) / (2 * kBlkBytes);
+  if (wpc > 16) wpc = 16;
+  return n_pairs <= (int64_t)kCUs * wpc;
 }
 
 template <int DT, int NSL>
@@ -829,10 +901,18 @@ extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, i
     a.dm64 = (const int64_t*)d_mask;
     return maxsim_pair_launch(a, dtype, true, stream);
   }
-  if (int e = resolve_mask_pair(q_mask, q_mask_kind, nq, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
-  if (pair_kernel) return maxsim_pair_launch(a, dtype, false, stream);
   const bool stream_ok = !env().maxsim_generic && dtype != MM_F32 && Q <= 64 &&
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
+  // a long query (ColBERT's [MASK] augmentation: 30 + 8 tokens) in a call small enough that every wavefront scores one
+  // pair: the two-tile streaming kernel reads the int64 masks itself, one launch per call
+  if (stream_ok && !pair_kernel && Q > 32 && D <= 256 && q_mask_kind == MM_MASK_I64 && d_mask_kind == MM_MASK_I64 && q_mask &&
+      d_mask && !env().maxsim_no_inline_masks && stream_one_pair_per_wave(n_pairs)) {
+    a.qm64 = (const int64_t*)q_mask;
+    a.dm64 = (const int64_t*)d_mask;
+    return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
+  }
+  if (int e = resolve_mask_pair(q_mask, q_mask_kind, nq, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
+  if (pair_kernel) return maxsim_pair_launch(a, dtype, false, stream);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, false>(a, stream) : launch_stream_cfg<MM_F16, false>(a, stream);
   // fp32 token vectors (ColBERT run with use_fp16 = False): the split-bf16 streaming kernel of kernel_pool128.hip
   // with the MaxSim epilogue

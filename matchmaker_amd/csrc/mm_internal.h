@@ -29,6 +29,8 @@ struct EnvCfg {
   int maxsim_nt = 1;        // MM_MAXSIM_NT: non-temporal LDS-DMA
   int maxsim_generic = 0;   // MM_MAXSIM_GENERIC: force the generic MaxSim kernel
   int maxsim_inb_untiled = 0;  // MM_MAXSIM_INB_UNTILED: all-pairs MaxSim with one query per wavefront (A/B runs)
+  int maxsim_no_inline_masks = 0;  // MM_MAXSIM_NO_INLINE_MASKS: pack int64 masks in their own launch even for one-pair-per-wavefront calls (A/B runs)
+  int maxsim_no_wpp2 = 0;          // MM_MAXSIM_NO_WPP2: one wavefront per pair also in eval.py-sized calls (A/B runs)
   int maxsim_inb_nowg = 0;     // MM_MAXSIM_INB_NOWG: all-pairs MaxSim without the workgroup-shared ring (A/B runs)
   int maxsim_f32_terms = 3; // MM_MAXSIM_F32_TERMS: 2 = two-term split for fp32 MaxSim (A/B), default three terms
   int kp_generic = 0;       // MM_KP_GENERIC: force the generic pooling kernel

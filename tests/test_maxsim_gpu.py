@@ -277,6 +277,47 @@ def test_pair_per_row_layout_with_tokenizer_masks(dtype, Q, D, E):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Q,D,E", [(38, 200, 768), (38, 180, 128), (64, 256, 256), (33, 47, 384), (40, 2, 512), (38, 193, 768)])
+def test_long_queries_in_eval_sized_calls_read_the_tokenizer_masks_in_the_kernel(dtype, Q, D, E):
+    """eval.py's call at the published checkpoint's shapes (batch_size_eval 512, Q = 30 + 8 [MASK], int64 HF masks): every
+    wavefront of the two-tile streaming kernel scores one pair and reads the int64 masks itself (no packing launch); with
+    at most 512 pairs TWO wavefronts share a pair (alternate blocks, maxima combined in LDS).
+    The same pairs with bool masks take the packed-mask path of the same kernel: the scores must be bit-identical; a call
+    too large for one pair per wavefront (int64 masks packed in their own launch) must be, too."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 131 + D + E)
+    # 512 / 5: two wavefronts per pair; 1500: one pair per wavefront; 2600: more pairs than wavefront slots (packed masks)
+    for B in (512, 5, 1500, 2600):
+        q = (torch.randn(B, Q, E, generator=g) / E ** 0.5).to(dtype)
+        d = (torch.randn(B, D, E, generator=g) / E ** 0.5).to(dtype)
+        ql = torch.randint(1, Q + 1, (B,), generator=g)
+        dl = torch.randint(0, D + 1, (B,), generator=g)
+        dl[0] = D
+        dl[1] = 0                                           # an empty document
+        qm = (torch.arange(Q)[None] < ql[:, None]).long()
+        dm = (torch.arange(D)[None] < dl[:, None]).long()
+        qm[2] = 0                                           # an all-padding query
+        qm[0, 1] = 0
+        qm[3, Q - 1] = 1                                    # a real token after padding, in the second query word
+        if D > 4:
+            dm[0, 1] = 0                                    # holes
+            dm[0, D - 2] = 0
+            dm[4, D - 1] = 1                                # a real token after padding: the length is last + 1
+        nz = dm != 0
+        dm[nz] = torch.randint(1, 1 << 40, (int(nz.sum()),), generator=g) * (1 - 2 * torch.randint(0, 2, (int(nz.sum()),), generator=g))
+        qd, dd = q.to(dev), d.to(dev)
+        out = ops.maxsim(qd, dd, qm.to(dev), dm.to(dev), pairs_per_query=1)
+        packed = ops.maxsim(qd, dd, (qm != 0).to(dev), (dm != 0).to(dev), pairs_per_query=1)
+        assert torch.equal(out, packed)
+        m = min(B, 600)
+        ref = O.maxsim_paired(q[:m].float().numpy(), d[:m].float().numpy(), qm[:m].numpy(), dm[:m].numpy())
+        np.testing.assert_allclose(out[:m].cpu().numpy(), ref, atol=util.TOL_BF16, rtol=1e-4)
+        o = out.cpu().numpy()
+        assert o[2] == 0.0 and o[1] == -1000.0 * int((qm[1] != 0).sum())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Bq,Bd,Q,D,E", [(70, 300, 32, 180, 128), (9, 1100, 38, 200, 128), (33, 33, 30, 64, 768), (5, 2000, 20, 47, 256),
                                           (130, 70, 32, 33, 128), (1030, 37, 17, 64, 128), (3, 5, 9, 41, 256), (32, 32, 32, 180, 128), (7, 20, 38, 200, 768),
                                           (2, 1, 1, 1, 128), (6, 9, 32, 32, 128), (4, 3, 5, 97, 256)])
