@@ -199,6 +199,23 @@ def gpu_time_ms(fn, steps, warmup=2, warm_ms=40.0, timed_ms=25.0, max_calls=400)
     return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
 
 
+def vendor_gemm_tflops(shapes):
+    """torch.mm (hipBLASLt / rocBLAS) at the given {name: (M, N, K, dtype)} shapes, 16-bit output written: a calibration of
+    what matrix rate this board sustains, not part of any product path."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res = {}
+    for name, (M, N, K, dt) in shapes.items():
+        a = torch.randn(M, K, device=dev, dtype=dt)
+        b = torch.randn(N, K, device=dev, dtype=dt)
+        c = torch.empty(M, N, device=dev, dtype=dt)
+        ms = gpu_time_ms(lambda: torch.mm(a, b.t(), out=c), 5, warm_ms=100.0, timed_ms=60.0)
+        res[name] = {"shape_mnk": [M, N, K], "ms": ms, "tflops": 2.0 * M * N * K / (ms * 1e-3) / 1e12}
+        del a, b, c
+    torch.cuda.empty_cache()
+    return res
+
+
 # ------------------------------------------------------------------------------------------ extras (N = 1)
 def extra_dropin_forward(q, d, q_len, d_len, steps):
     """eval.py:108 -> ColBERT.forward -> colbert.py:68-75 exactly as the reference batches it: the query
@@ -597,6 +614,12 @@ def extra_all_pairs(steps, cpu_budget):
     if not LEAN:
         t0 = gpu_time_ms(lambda: ops.maxsim_inbatch(q[:32], qm[:32], d[:32], dm[:32], bug_compatible=True), steps)
         out["reference_batch_32x32"] = {"ms": t0, "note": "dynamic_teacher.py:245-276 calls it with batch_size_train = 32, bug-compatible masks"}
+        # the vendor GEMM on this box: the same product with the [Bq Q, Bd D] score matrix WRITTEN (what colbert.py:154 does
+        # before its max / sum passes) and a square 8192^3 (the matrix rate the board's power budget allows)
+        out["vendor_gemm"] = vendor_gemm_tflops({"same_product_score_matrix_written_bf16": (Bq * Q, Bd * D, E, torch.bfloat16),
+                                                 "square_8192_bf16": (8192, 8192, 8192, torch.bfloat16)})
+        out["vendor_gemm"]["this_kernel_over_same_product"] = (flop / t / 1e12) / out["vendor_gemm"]["same_product_score_matrix_written_bf16"]["tflops"]
+        out["vendor_gemm"]["this_kernel_over_square_8192"] = (flop / t / 1e12) / out["vendor_gemm"]["square_8192_bf16"]["tflops"]
     if cpu_budget > 0:
         from oracle import torch_port as TP
         n = 64
@@ -640,6 +663,13 @@ def extra_dot_topk(steps, cpu_budget):
                         "frac": flop / t / MFMA_PEAK_16BIT},
            "kernel": "dot_stream_kernel (sample + filter) + sample_tau_kernel + topk_rows_kernel (whole mm_dot_topk_fwd call, wall clock)",
            "profile": "profiles/r03_dot_topk_pmc.json, profiles/r03_dot_topk_trace.json"}
+    if not LEAN:
+        # what the vendor GEMM reaches on THIS box: the same product (one 262,144-passage slice, fp16 scores written, no
+        # top-k) and a square 8192^3 — the matrix rate the board's power budget allows, next to the 2.5 PFLOP/s nominal peak
+        out["vendor_gemm"] = vendor_gemm_tflops({"same_product_262144_passages_fp16": (nq, 1 << 18, Ed, torch.float16),
+                                                 "square_8192_bf16": (8192, 8192, 8192, torch.bfloat16)})
+        out["vendor_gemm"]["this_call_over_same_product"] = (flop / t / 1e12) / out["vendor_gemm"]["same_product_262144_passages_fp16"]["tflops"]
+        out["vendor_gemm"]["this_call_over_square_8192"] = (flop / t / 1e12) / out["vendor_gemm"]["square_8192_bf16"]["tflops"]
     if cpu_budget > 0:
         nqc, nc = 64, 1 << 16
         qc, cc = q[:nqc].float().cpu(), c[:nc].float().cpu()

@@ -61,6 +61,7 @@ struct DotArgs {
   float* cand_score;  // [nq, cap]
   int32_t* cand_idx;  // [nq, cap] document index inside the shard
   int cap;
+  int spread;         // LDS-DMA of block b + 1 spread over block b's K loop (default; MM_DOT_NO_SPREAD=1: all at once)
   unsigned long long* prof;  // optional [grid * 4 wavefronts][6] cycle counters (MM_DOT_PROF=1, tools only)
 };
 
@@ -138,6 +139,19 @@ __device__ __forceinline__ void dot_issue(const char* gbase, uint32_t voff, uint
 }
 #undef MM_DOT_ISSUE
 #undef MM_DOT_LD
+
+// ONE LDS-DMA instruction (4 rows x 256 B of one slice), for the K loop: issued right after the block barrier the 2 NSL
+// instructions of a wavefront queue behind those of the three other wavefronts at the CU's one address unit (48 KiB per
+// block at 64 B per cycle: ~0.9 k cycles of every wavefront's 5.6 k per block, MM_DOT_PROF); one every second K step
+// rides behind the MFMAs instead.  No lgkmcnt wait: the slot written is the one block b - 1 used, every read of which
+// was consumed before the barrier.
+__device__ __forceinline__ void dot_issue_one(const char* gbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_dst)
+               : "memory");
+}
 
 template <int N>
 __device__ __forceinline__ void dot_wait() {
@@ -252,7 +266,24 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     if (PROF) t1 = now();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
     if (PROF) t2 = now();
-    if (b + 1 < b_hi) issue(b + 1, slot_i ^ 1);  // into the slot block b - 1 used
+    // block b + 1 goes into the slot block b - 1 used: all at once here, or (a.spread) one instruction every second K step
+    const bool more = b + 1 < b_hi;
+    const bool spread = more && a.spread;
+    const char* gbn = (const char*)a.c;
+    uint32_t nvo[2] = {0, 0};
+    const uint32_t ndst = lds0 + (uint32_t)((slot_i ^ 1) * BLK + w * 1024);
+    if (spread) {
+      const int64_t left = a.ndocs - (b + 1) * 32;
+      gbn = (const char*)a.c + (b + 1) * 32 * rowstep;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int row = lrow[u];
+        if (left < 32 && row >= left) row = (int)left - 1;
+        nvo[u] = (uint32_t)(row * rowstep) + lslot[u];
+      }
+    } else if (more) {
+      issue(b + 1, slot_i ^ 1);
+    }
 
     if (PROF) t3 = now();
     f32x16 acc[NQT];
@@ -274,6 +305,10 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       for (int n = 0; n < NQT; ++n) acc[n] = DotMfma<DT>::run(av[s % (AHEAD + 1)], qf[n][s >> 3][s & 7], acc[n]);
       __builtin_amdgcn_sched_group_barrier(0x008, NQT, 0);  // NQT MFMAs of step s
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
+      if ((s & 1) == 0 && (s >> 1) < 2 * NSL) {
+        const int u = (s >> 1) / NSL, sl = (s >> 1) % NSL;
+        if (spread) dot_issue_one(gbn, nvo[u] + (uint32_t)(sl * 256), ndst + (uint32_t)(u * 4096 + sl * 0x2000));
+      }
     }
     slot_i ^= 1;
     if (PROF) {
@@ -782,6 +817,7 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   int32_t* cand_idx = (int32_t*)ws;
 
   DotArgs a{};
+  a.spread = env().dot_no_spread ? 0 : 1;
   a.q = queries; a.c = corpus; a.nq = nq; a.E = E; a.q_base = 0;
   a.tau = tau; a.count = count; a.cand_score = cand_score; a.cand_idx = cand_idx; a.cap = cap;
 
