@@ -20,6 +20,11 @@
 #include "mm_internal.h"
 #include "kp_device.h"
 
+// VALU instructions scheduled behind each MFMA of the split kernels' K steps (sched_group_barrier).  Measured on one box,
+// round-robin: 3: 2.82-2.84 ms | 4: 2.79-2.83 | 5: 2.78-2.79 | 6: 2.79 | 7: 2.81-2.83 | 8: 2.83-2.87 | 10: 2.83-2.85 for TK
+// (profiles/r03_experiments/tk_schedule_ab.txt); TKL's stage 1 does not care (0.135-0.138 ms for 3 .. 12).
+constexpr int kShadowValu = 5;
+
 namespace mm {
 
 // TKL: the wavefront that processes packed chunk p publishes its slot-map entry (see KpArgs::slot2p)
@@ -566,7 +571,9 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
     }
 
     for (int t = wv; t < nb; t += WPP) {
-      f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+      // two accumulators: hi.hi, and the three cross terms (all ~2^-9 of it) together — a third one was 16 more
+      // v_accvgpr_read + 8 v_pk_add per block in the epilogue, and this kernel's time is its instruction energy (3.3)
+      f32x16 acc_hh = {0}, acc_xl = {0};
       f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
       f32x2 ss2 = {0.0f, 0.0f};
 #pragma unroll
@@ -600,7 +607,7 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
           bf16x8 nh = ah, nl = al;
           if (p + 1 < kSplitSteps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
           acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
-          acc_lh = mfma_bf16(al, qhi[s][p], acc_lh);
+          acc_xl = mfma_bf16(al, qhi[s][p], acc_xl);
           acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
           acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
           {
@@ -614,7 +621,7 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 VALU in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x002, kShadowValu, 0);  // VALU in its shadow
           }
           ah = nh;
           al = nl;
@@ -631,14 +638,14 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
         bf16x8 ah, al;
         split8(park[0], park[1], ah, al);
         acc_hh = mfma_bf16(ah, qhiL, acc_hh);
-        acc_lh = mfma_bf16(al, qhiL, acc_lh);
+        acc_xl = mfma_bf16(al, qhiL, acc_xl);
         acc_xl = mfma_bf16(ah, qloL, acc_xl);
         acc_xl = mfma_bf16(al, qloL, acc_xl);
       }
       float ss = ss2[0] + ss2[1];
       f32x16 acc;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + acc_xl[i];
       // document-token norms: lane (r,h) summed its K-halves of row r (from the fp32 values)
       ss += __shfl_xor(ss, 32, 64);
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
@@ -1006,7 +1013,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, kShadowValu, 0);
           }
           ah = nh;
           al = nl;

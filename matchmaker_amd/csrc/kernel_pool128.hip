@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
 #pragma unroll
           for (int g = 0; g < (MX == 2 ? 6 : 4); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 VALU in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // 5 VALU in its shadow (fp32 MaxSim, round-robin on one box: 4: 1.048-1.050 ms | 5: 1.030-1.038 | 6: 1.046-1.051 | 8: 1.048-1.057 | 11: 1.056-1.059)
           }
           ah = nh;
           al = nl;
