@@ -1,5 +1,5 @@
 #!/bin/bash
-# which of the three VALU reductions costs time: TK leg per library variant, twice round-robin on one box
+# A/B of library builds on ONE box: LEG=<bench leg> VARIANTS="a b c" -> csrc/libmm_native_<variant>.so swapped in turn, two round-robin passes
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/stepc
 L=matchmaker_amd/csrc

@@ -16,6 +16,8 @@ for k,v in j['extra'].items():
         for n,s in v['shapes'].items(): print(' ', n, round(s['us_per_call_completed'],1), round(s['us_per_call_host_issue'],1), round(s['roofline']['frac'],3))
     else: print(k, str(v)[:200])
 print('tk exact', j['extra']['tk'].get('exact_f32_mfma'))
+print('vendor gemm (dot)', j['extra']['dot_topk'].get('vendor_gemm'))
+print('vendor gemm (all pairs)', j['extra']['all_pairs'].get('vendor_gemm'))
 print('tkl exact', j['extra']['tkl'].get('exact_f32_mfma'))
 print('tkl 1024', j['extra']['tkl'].get('batch_1024_documents'))
 PY
