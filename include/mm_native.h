@@ -66,7 +66,9 @@ const char* mm_last_error(void);
  * eval.py:108); pairs_per_query = C is the "1 query x C candidates" re-ranking layout in which
  * the query tile is read once per candidate list.
  * q_mask rows follow q (n_queries rows), d_mask rows follow d (n_pairs rows).
- * workspace: mm_maxsim_workspace_bytes() bytes of device scratch (may be 0 -> NULL allowed).
+ * workspace: mm_maxsim_workspace_bytes() bytes of device scratch (may be 0 -> NULL allowed).  It holds the packed masks;
+ *   calls whose int64 masks the kernel reads itself (the pair-per-row layout, and long queries when every wavefront scores
+ *   one pair: eval.py's 512-pair batches) leave it untouched.
  */
 size_t mm_maxsim_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
                                  int q_mask_kind, int d_mask_kind);

@@ -509,3 +509,29 @@ def test_tkl_parameters_unused_by_the_saturation_mode_get_no_gradient_slot(sat):
     for t, n in zip(scoring, sizes):
         assert (n is not None) == (id(t) in live)
     assert sum(n is None for n in sizes) == (1 if sat == "embedding" else 9)
+
+
+def test_stream_handle_is_read_once_and_the_public_path_is_the_fallback(monkeypatch):
+    """ops._stream: the raw handle of the current stream through torch._C._cuda_getCurrentRawStream (one C call), the
+    public torch.cuda.current_stream() when that symbol is missing; ops._workspace keys its cache by the handle it is given."""
+    from matchmaker_amd import ops
+    dev = torch.device("cuda", 0)
+    calls = []
+    monkeypatch.setattr(ops, "_RAW_STREAM", lambda idx: calls.append(idx) or 0x1234)
+    assert ops._stream(dev) == 0x1234 and calls == [0]
+
+    class _S:
+        cuda_stream = 0x77
+    monkeypatch.setattr(ops, "_RAW_STREAM", None)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _S())
+    assert ops._stream(dev) == 0x77
+    # workspace cache: one buffer per (device, stream handle), reused while large enough
+    made = []
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch, "empty", lambda n, dtype=None, device=None: made.append(n) or torch.zeros(n, dtype=torch.uint8))
+    monkeypatch.setattr(ops, "_WS", {})
+    a = ops._workspace(dev, 100, 5)
+    b = ops._workspace(dev, 4096, 5)
+    c = ops._workspace(dev, 100, 6)
+    assert a is b and c is not a and made == [1 << 16, 1 << 16]
+    assert ops._workspace(dev, 0, 5) is None

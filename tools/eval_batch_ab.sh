@@ -1,5 +1,6 @@
 #!/bin/bash
-# in-kernel masks of the two-tile MaxSim kernel: parity, eval-sized calls before / after, host-path profile
+# eval.py-sized calls: parity of the in-kernel-mask path, bench.py eval_batch with and without two wavefronts per pair
+# (MM_MAXSIM_NO_WPP2=1; MM_MAXSIM_NO_INLINE_MASKS=1 restores the packing launch), host-path profile
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/stepa
 timeout 600 python -m pytest tests/test_maxsim_gpu.py -q -m gpu -x -k "long_queries or longer_than_one_tile or pair_per_row" 2>&1 | tail -5
