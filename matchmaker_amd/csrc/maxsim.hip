@@ -218,7 +218,12 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
           const int qr = qt < Q ? qt : Q - 1;
           const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
 #pragma unroll
-          for (int sl = 0; sl < NSL; ++sl) load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
+          for (int sl = 0; sl < NSL; ++sl) {
+            // two tiles at dim >= 512 exceed the 256 VGPRs: the second tile lives in AGPRs and is read from there by the MFMA
+            // (284 -> 92 v_accvgpr_read per block at dim 768; 0.885 -> 0.878 ms on the published checkpoint's shapes)
+            if (NQT == 2 && NSL >= 4 && n == 1) load_q_frags_agpr(qrow + sl * 256 + h * 16, qf[n][sl]);
+            else load_q_frags(qrow + sl * 256 + h * 16, qf[n][sl]);
+          }
           qvalid[n] = qt < Q && qt < qlen;
           if (IM) qvalid[n] = qvalid[n] && ((iq >> qt) & 1ull);
           else if (a.qm.bits && n < qwords) qvalid[n] = qvalid[n] && ((sload_u32(a.qm.bits, qi * qwords + n) >> r) & 1u);

@@ -108,6 +108,26 @@ __device__ __forceinline__ void load_q_frags(const char* base, short8 (&qf)[8]) 
       : "memory");
 }
 
+// The same into ACCUMULATOR registers: the fragments stay there and the MFMA reads its B operand from AGPRs directly.  Two
+// query tiles at dim 768 are 384 registers of B fragments; left to itself the allocator parks the overflow in AGPRs and
+// fetches every parked fragment back with four v_accvgpr_read before each use (284 of them per 32-token block).
+__device__ __forceinline__ void load_q_frags_agpr(const char* base, short8 (&qf)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off\n\t"
+      "global_load_dwordx4 %1, %8, off offset:32\n\t"
+      "global_load_dwordx4 %2, %8, off offset:64\n\t"
+      "global_load_dwordx4 %3, %8, off offset:96\n\t"
+      "global_load_dwordx4 %4, %8, off offset:128\n\t"
+      "global_load_dwordx4 %5, %8, off offset:160\n\t"
+      "global_load_dwordx4 %6, %8, off offset:192\n\t"
+      "global_load_dwordx4 %7, %8, off offset:224\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&a"(qf[0]), "=&a"(qf[1]), "=&a"(qf[2]), "=&a"(qf[3]), "=&a"(qf[4]), "=&a"(qf[5]), "=&a"(qf[6]),
+        "=&a"(qf[7])
+      : "v"(base)
+      : "memory");
+}
+
 // The same with ONE running maximum per lane (the 16 rows a lane holds all belong to its query token, and max is
 // exact in any order): 8 v_max3 per block instead of 16 v_max, 1 register instead of 16 — what lets the all-pairs
 // kernel keep four query tiles AND their accumulators in VGPRs.
