@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r03}
 LEGS=${2:-"headline dropin_forward published_checkpoint maxsim_fp32 all_pairs tk tkl dot_topk eval_batch"}
-PMCL=${3:-"headline tk tkl dot_topk all_pairs"}
+PMCL=${3-"headline tk tkl dot_topk all_pairs"}   # "" = no counter passes
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
@@ -39,6 +39,7 @@ for L in $PMCL; do
 done
 
 # TKL on full 2,048-token documents (the bench leg runs config 3's own lengths)
+if [ -n "$PMCL" ]; then
 CMD="python tools/bench_tkl.py --full --steps 5"
 rm -rf $O/pmc_tklfull; mkdir -p $O/pmc_tklfull
 rocprofv3 --kernel-trace --stats -d $O/pmc_tklfull/trace -o t -- $CMD > $O/pmc_tklfull/trace.log 2>&1
@@ -47,3 +48,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_tklfull/pmc_write -o t -- $C
 MM_PROF_COMMAND="$CMD" python tools/summarize_rocprof.py $O/pmc_tklfull $O/tklfull_pmc.json "mm::" > /dev/null
 find $O/pmc_tklfull -name "*.db" -delete
 echo "== tklfull done"
+fi
