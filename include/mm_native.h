@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2 /* 2: `flags` on the MaxSim forwards (the reference's 16-bit dtype flow); mm_tkl_fwd's ascending chunk_slot
+                            contract and workspace layout */
 
 /* element types of the embedding tensors */
 #define MM_F32 0
@@ -47,6 +48,19 @@ extern "C" {
 #define MM_EWORKSPACE -3   /* workspace missing or too small                               */
 #define MM_ELAUNCH -4      /* HIP reported a launch error                                  */
 
+/* `flags` of the MaxSim forwards: the reference's dtype flow for 16-bit inputs.  In the reference the similarity matrix has
+ * the dtype of the token vectors: under torch.cuda.amp.autocast(enabled=use_fp16) — config/train/defaults.yaml:21
+ * `use_fp16: True`, colbert.py:60 — `bmm` returns fp16 (fp32 accumulation, ONE rounding per element), the -1000 fill and
+ * `max` stay fp16 and only `sum` is promoted to fp32 (colbert.py:68-75).  Rounding is monotone, so rounding the per-token
+ * maximum reproduces that arithmetic exactly.
+ *   MM_SIM_ROUND  every per-query-token maximum is rounded (RNE) to the element type of q / d before the fp32 sum:
+ *                 ColBERT.forward / forward_aggregation under autocast (colbert.py:60-75, indexing_heads.py:49-56)
+ *   MM_SUM_ROUND  the pair's sum is rounded to that type as well: 16-bit tensors OUTSIDE autocast, where `sum` is a 16-bit op
+ *                 too (fp32 accumulation, one rounding) — the dynamic teacher's all-pairs call, dynamic_teacher.py:245-246
+ * Both are no-ops for MM_F32 inputs.  0 = fp32 accumulators through max and sum (the fp32 contract of `use_fp16: False`). */
+#define MM_SIM_ROUND 1
+#define MM_SUM_ROUND 2
+
 int mm_abi_version(void);
 const char* mm_last_error(void);
 
@@ -66,6 +80,7 @@ const char* mm_last_error(void);
  * eval.py:108); pairs_per_query = C is the "1 query x C candidates" re-ranking layout in which
  * the query tile is read once per candidate list.
  * q_mask rows follow q (n_queries rows), d_mask rows follow d (n_pairs rows).
+ * flags: MM_SIM_ROUND / MM_SUM_ROUND above (0 = fp32 through max and sum).
  * workspace: mm_maxsim_workspace_bytes() bytes of device scratch (may be 0 -> NULL allowed).  It holds the packed masks;
  *   calls whose int64 masks the kernel reads itself (the pair-per-row layout, and long queries when every wavefront scores
  *   one pair: eval.py's 512-pair batches) leave it untouched.
@@ -78,7 +93,7 @@ int mm_maxsim_fwd(const void* q, const void* d,
                   const void* d_mask, int d_mask_kind,
                   float* out,
                   int64_t n_pairs, int64_t pairs_per_query,
-                  int Q, int D, int E, int dtype,
+                  int Q, int D, int E, int dtype, int flags,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* All-pairs MaxSim: out[i, j] over query i x document j.
@@ -94,7 +109,7 @@ int mm_maxsim_inbatch_fwd(const void* q, const void* d,
                           const void* d_mask, int d_mask_kind,
                           float* out,
                           int64_t Bq, int64_t Bd, int Q, int D, int E, int dtype,
-                          int bug_compatible,
+                          int bug_compatible, int flags,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Ragged (CSR) MaxSim over a resident token store: document p = rows [doc_begin[p], doc_end[p]) of
@@ -110,7 +125,7 @@ size_t mm_maxsim_ragged_workspace_bytes(int64_t n_pairs, int64_t pairs_per_query
 
 int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int64_t* doc_begin, const int64_t* doc_end,
                          const void* q_mask, int q_mask_kind, float* out,
-                         int64_t n_pairs, int64_t pairs_per_query, int Q, int E, int dtype,
+                         int64_t n_pairs, int64_t pairs_per_query, int Q, int E, int dtype, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the paired MaxSim (pair-per-row layout, the one train.py uses: train.py:347-348,

@@ -11,6 +11,8 @@ LIB_PATH = os.path.join(HERE, "csrc", "libmm_native.so")
 MM_F32, MM_F16, MM_BF16 = 0, 1, 2
 MASK_NONE, MASK_LEN_I32, MASK_U8, MASK_I64, MASK_F32 = 0, 1, 2, 3, 4
 TKL_SAT_EMBEDDING, TKL_SAT_LOG = 0, 1
+SIM_ROUND, SUM_ROUND = 1, 2          # MM_SIM_ROUND / MM_SUM_ROUND
+ABI_VERSION = 2
 
 _c = ctypes
 _vp, _i64, _i, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -20,11 +22,11 @@ SIGNATURES = {
     "mm_abi_version": (_i, []),
     "mm_last_error": (_c.c_char_p, []),
     "mm_maxsim_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
-    "mm_maxsim_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_maxsim_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_maxsim_inbatch_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
-    "mm_maxsim_inbatch_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_maxsim_inbatch_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_maxsim_ragged_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
-    "mm_maxsim_ragged_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_maxsim_ragged_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_maxsim_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "mm_maxsim_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
@@ -69,6 +71,9 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
+        if L.mm_abi_version() != ABI_VERSION:
+            raise NativeError(f"{LIB_PATH} has ABI version {L.mm_abi_version()}, this binding needs {ABI_VERSION}: "
+                              "rebuild with `python -m matchmaker_amd.build --force`")
         _lib = L
     return _lib
 

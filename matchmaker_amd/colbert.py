@@ -35,15 +35,29 @@ class _MaxSimFn(torch.autograd.Function):
     on the device, no [B,Q,D] tensor) for the training path, train.py:347-348 / :503-524."""
 
     @staticmethod
-    def forward(ctx, q, d, q_mask, d_mask):
+    def forward(ctx, q, d, q_mask, d_mask, sim_round=False, sum_round=False):
         ctx.save_for_backward(q, d, q_mask, d_mask)
-        return ops.maxsim(q, d, q_mask, d_mask, pairs_per_query=1)
+        return ops.maxsim(q, d, q_mask, d_mask, pairs_per_query=1, sim_round=sim_round, sum_round=sum_round)
 
     @staticmethod
     def backward(ctx, g):
+        # (rounding is piecewise constant: the gradient is that of the unrounded maximum, routed to an arg-max of the
+        # fp32 similarities — which is also an arg-max of the rounded ones)
         q, d, q_mask, d_mask = ctx.saved_tensors
         gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g)
-        return gq.to(q.dtype), gd.to(d.dtype), None, None
+        return gq.to(q.dtype), gd.to(d.dtype), None, None, None, None
+
+
+def _as_reference_would(query_vecs, document_vecs):
+    """The token vectors in the dtype the reference's `bmm` / `mm` would see them in, + the rounding flags of its dtype flow
+    (ops.reference_rounding): under autocast fp32 vectors are cast to the autocast dtype first (colbert.py:60,68;
+    indexing_heads.py:49-56 for the fp32 memmap store)."""
+    if torch.is_autocast_enabled("cuda") and query_vecs.dtype == torch.float32:
+        ac = torch.get_autocast_dtype("cuda")
+        query_vecs, document_vecs = query_vecs.to(ac), document_vecs.to(ac)
+    elif query_vecs.dtype != document_vecs.dtype:
+        document_vecs = document_vecs.to(query_vecs.dtype)
+    return (query_vecs, document_vecs) + ops.reference_rounding(query_vecs)
 
 
 class ColBERT(PreTrainedModel):
@@ -78,10 +92,14 @@ class ColBERT(PreTrainedModel):
     # ------------------------------------------------------------------ scoring (the hot path)
     @staticmethod
     def _score(query_vecs, document_vecs, query_mask, document_mask):
-        """colbert.py:68-75."""
-        if torch.is_grad_enabled() and (query_vecs.requires_grad or document_vecs.requires_grad):
-            return _MaxSimFn.apply(query_vecs, document_vecs, query_mask, document_mask)
-        return ops.maxsim(query_vecs, document_vecs, query_mask, document_mask, pairs_per_query=1)
+        """colbert.py:68-75, in the arithmetic the reference's eager ops have in the current autocast state: fp16 similarities
+        and maxima, fp32 sum under `use_fp16` (defaults.yaml:21); fp32 throughout for fp32 vectors outside autocast."""
+        q, d, sim_round, sum_round = _as_reference_would(query_vecs, document_vecs)
+        if torch.is_grad_enabled() and (q.requires_grad or d.requires_grad):
+            score = _MaxSimFn.apply(q, d, query_mask, document_mask, sim_round, sum_round)
+        else:
+            score = ops.maxsim(q, d, query_mask, document_mask, pairs_per_query=1, sim_round=sim_round, sum_round=sum_round)
+        return score.to(q.dtype) if sum_round else score      # (16-bit tensors outside autocast: `sum` returns their dtype)
 
     def forward(self, query: Dict[str, torch.LongTensor], document: Dict[str, torch.LongTensor],
                 use_fp16: bool = True, output_secondary_output: bool = False):
@@ -89,12 +107,7 @@ class ColBERT(PreTrainedModel):
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
             query_vecs = self.forward_representation(query)
             document_vecs = self.forward_representation(document)
-            if use_fp16 and query_vecs.dtype == torch.float32:
-                # autocast would run the reference's bmm in fp16 (colbert.py:60,68)
-                q_s, d_s = query_vecs.half(), document_vecs.half()
-            else:
-                q_s, d_s = query_vecs, document_vecs
-            score = self._score(q_s, d_s, query["attention_mask"], document["attention_mask"])
+            score = self._score(query_vecs, document_vecs, query["attention_mask"], document["attention_mask"])
 
             if self.is_teacher_model:
                 return (score, query_vecs, document_vecs)
@@ -113,10 +126,11 @@ class ColBERT(PreTrainedModel):
         return vecs
 
     def forward_aggregation(self, query_vecs, document_vecs):
-        """colbert.py:100-112 — unmasked MaxSim over pre-encoded vectors."""
-        if query_vecs.dtype != document_vecs.dtype:
-            document_vecs = document_vecs.to(query_vecs.dtype)
-        return ops.maxsim(query_vecs, document_vecs, None, None, pairs_per_query=1)
+        """colbert.py:100-112 — unmasked MaxSim over pre-encoded vectors (QuerySearcherHead calls it under autocast,
+        indexing_heads.py:49-56: fp16 similarities, fp32 sum)."""
+        q, d, sim_round, sum_round = _as_reference_would(query_vecs, document_vecs)
+        score = ops.maxsim(q, d, None, None, pairs_per_query=1, sim_round=sim_round, sum_round=sum_round)
+        return score.to(q.dtype) if sum_round else score
 
     def forward_inbatch_aggregation(self, query_vecs, query_mask, document_vecs, document_mask):
         """colbert.py:114-162 — all-pairs MaxSim [Bq, Bd]."""
@@ -124,8 +138,12 @@ class ColBERT(PreTrainedModel):
             # the reference's mask expansion (:158) raises for Bq != Bd
             raise RuntimeError("forward_inbatch_aggregation (reference-compatible masking) needs the same number "
                                "of queries and documents; set inbatch_bug_compatible = False for the general case")
-        return ops.maxsim_inbatch(query_vecs, query_mask, document_vecs, document_mask,
-                                  bug_compatible=self.inbatch_bug_compatible)
+        # (the dynamic teacher calls this OUTSIDE autocast on the fp16 vectors its forward returned, dynamic_teacher.py:245-246:
+        # `mm`, `max` and `sum` are all fp16 ops there, and so is the result)
+        q, d, sim_round, sum_round = _as_reference_would(query_vecs, document_vecs)
+        score = ops.maxsim_inbatch(q, query_mask, d, document_mask, bug_compatible=self.inbatch_bug_compatible,
+                                   sim_round=sim_round, sum_round=sum_round)
+        return score.to(q.dtype) if sum_round else score
 
     def get_param_stats(self):            # colbert.py:164-165
         return "ColBERT: / "

@@ -283,7 +283,7 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
       const int64_t dj = doc_row(pair);
 #pragma unroll
       for (int n = 0; n < NQT; ++n) {
-        const float s = finish_pair1(m1[n], qvalid[n], h);
+        const float s = finish_sum<DT>(finish_pair1<DT>(m1[n], qvalid[n], h, a.rnd), a.rnd);
         const int64_t qq = ((int64_t)g0 + qi * a.inb_gw) * NQT + n;
         if (lane == 0 && qq < a.inb_bq) a.out[qq * a.inb_bd + dj] = s;
       }
@@ -303,8 +303,8 @@ __device__ __forceinline__ void maxsim_stream_body(const MaxsimArgs& a) {
       float s = 0.0f;
 #pragma unroll
       for (int n = 0; n < NQT; ++n)  // tiles in index order: deterministic
-        s += ONE ? finish_pair1(m1[n], qvalid[n], h) : finish_pair(m[n], qvalid[n], h);
-      if (lane == 0) a.out[pair] = s;
+        s += ONE ? finish_pair1<DT>(m1[n], qvalid[n], h, a.rnd) : finish_pair<DT>(m[n], qvalid[n], h, a.rnd);
+      if (lane == 0) a.out[pair] = finish_sum<DT>(s, a.rnd);
     }
   }
 }
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256, 2) maxsim_allpairs_wg_kernel(const Maxsim
       int stores = 0;
 #pragma unroll
       for (int n = 0; n < NQT; ++n) {
-        const float sc = finish_pair1(m1[n], qvalid[n], h);
+        const float sc = finish_sum<DT>(finish_pair1<DT>(m1[n], qvalid[n], h, a.rnd), a.rnd);
         const int64_t qq = ((int64_t)g * 4 + wv) * NQT + n;
         if (qq < a.inb_bq) {                                 // wave-uniform
           if (lane == 0) a.out[qq * a.inb_bd + d_first + dd] = sc;
@@ -595,9 +595,9 @@ __global__ void __launch_bounds__(64) maxsim_generic_kernel(const MaxsimArgs a) 
       const uint32_t va = (!rag && a.dm.bits) ? (a.dm.bits[mi * nblk_tot + t] & ex) : ex;
       block_max(m, acc, ex, va, fill, h);
     }
-    total += finish_pair(m, qvalid, h);
+    total += finish_pair<DT>(m, qvalid, h, a.rnd);
   }
-  if (lane == 0) a.out[pair] = total;
+  if (lane == 0) a.out[pair] = finish_sum<DT>(total, a.rnd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -717,6 +717,11 @@ static int validate(const void* q, const void* d, float* out, int64_t n_pairs, i
   const int per16 = dtype == MM_F32 ? 4 : 8;
   if (E % per16) return set_error(MM_EUNSUPPORTED, "maxsim: E=%d rows are not 16-byte multiples (pad E to a multiple of %d)", E, per16);
   if (((uintptr_t)q | (uintptr_t)d) & 15) return set_error(MM_EINVAL, "maxsim: q/d must be 16-byte aligned");
+  return MM_OK;
+}
+
+static int validate_flags(int flags) {
+  if (flags & ~(MM_SIM_ROUND | MM_SUM_ROUND)) return set_error(MM_EINVAL, "maxsim: unknown flags 0x%x", flags);
   return MM_OK;
 }
 
@@ -885,16 +890,17 @@ extern "C" size_t mm_maxsim_workspace_bytes(int64_t n_pairs, int64_t pairs_per_q
 
 extern "C" int mm_maxsim_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
                              const void* d_mask, int d_mask_kind, float* out, int64_t n_pairs,
-                             int64_t pairs_per_query, int Q, int D, int E, int dtype, void* workspace,
+                             int64_t pairs_per_query, int Q, int D, int E, int dtype, int flags, void* workspace,
                              size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = validate(q, d, out, n_pairs, Q, D, E, dtype)) return e;
+  if (int e = validate_flags(flags)) return e;
   if (pairs_per_query <= 0) return set_error(MM_EINVAL, "maxsim: pairs_per_query must be >= 1");
   if (n_pairs == 0) return MM_OK;
   const int64_t nq = (n_pairs + pairs_per_query - 1) / pairs_per_query;
   MaxsimArgs a{};
   a.q = q; a.d = d; a.out = out; a.n_pairs = n_pairs; a.ppq = pairs_per_query; a.inb_bd = 0; a.inb_bug = 0;
-  a.Q = Q; a.D = D; a.E = E;
+  a.Q = Q; a.D = D; a.E = E; a.rnd = flags;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   // the reference's batch layout (one query tile per pair, eval.py:108): the pair kernel; HF int64 masks are read by
@@ -934,10 +940,11 @@ extern "C" size_t mm_maxsim_inbatch_workspace_bytes(int64_t Bq, int64_t Bd, int 
 
 extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q_mask, int q_mask_kind,
                                      const void* d_mask, int d_mask_kind, float* out, int64_t Bq, int64_t Bd,
-                                     int Q, int D, int E, int dtype, int bug_compatible, void* workspace,
+                                     int Q, int D, int E, int dtype, int bug_compatible, int flags, void* workspace,
                                      size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (Bq < 0 || Bd < 0) return set_error(MM_EINVAL, "maxsim_inbatch: negative batch");
+  if (int e = validate_flags(flags)) return e;
   if (int e = validate(q, d, out, Bq * Bd, Q, D, E, dtype)) return e;
   if (bug_compatible && Bq != Bd)
     return set_error(MM_EINVAL, "maxsim_inbatch: bug_compatible masking (colbert.py:158) requires Bq == Bd (got %lld, %lld)",
@@ -945,7 +952,7 @@ extern "C" int mm_maxsim_inbatch_fwd(const void* q, const void* d, const void* q
   if (Bq * Bd == 0) return MM_OK;
   MaxsimArgs a{};
   a.q = q; a.d = d; a.out = out; a.n_pairs = Bq * Bd; a.ppq = 1; a.inb_bd = Bd; a.inb_bq = Bq; a.inb_bug = bug_compatible ? 1 : 0;
-  a.Q = Q; a.D = D; a.E = E;
+  a.Q = Q; a.D = D; a.E = E; a.rnd = flags;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, Bq, Q, &ws, &left, stream, &a.qm)) return e;
@@ -968,17 +975,18 @@ extern "C" size_t mm_maxsim_ragged_workspace_bytes(int64_t n_pairs, int64_t pair
 
 extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int64_t* doc_begin, const int64_t* doc_end,
                                     const void* q_mask, int q_mask_kind, float* out, int64_t n_pairs,
-                                    int64_t pairs_per_query, int Q, int E, int dtype, void* workspace,
+                                    int64_t pairs_per_query, int Q, int E, int dtype, int flags, void* workspace,
                                     size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (int e = validate(q, tokens, out, n_pairs, Q, 1, E, dtype)) return e;
+  if (int e = validate_flags(flags)) return e;
   if (!doc_begin || !doc_end) return set_error(MM_EINVAL, "maxsim_ragged: null document range pointer");
   if (pairs_per_query <= 0) return set_error(MM_EINVAL, "maxsim_ragged: pairs_per_query must be >= 1");
   if (n_pairs == 0) return MM_OK;
   const int64_t nq = (n_pairs + pairs_per_query - 1) / pairs_per_query;
   MaxsimArgs a{};
   a.q = q; a.d = tokens; a.out = out; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
-  a.Q = Q; a.D = 32; a.E = E; a.rag_begin = doc_begin; a.rag_end = doc_end;
+  a.Q = Q; a.D = 32; a.E = E; a.rag_begin = doc_begin; a.rag_end = doc_end; a.rnd = flags;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, nq, Q, &ws, &left, stream, &a.qm)) return e;

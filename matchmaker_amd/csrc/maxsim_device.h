@@ -25,6 +25,7 @@ struct MaxsimArgs {
   // pair-per-row kernel (maxsim_pair.hip): the tokenizer's int64 masks, read in the kernel itself
   const int64_t* qm64;
   const int64_t* dm64;
+  int rnd;         // MM_SIM_ROUND | MM_SUM_ROUND: the reference's dtype flow for 16-bit inputs (round_like below)
 };
 
 // maxsim_pair.hip
@@ -148,17 +149,46 @@ __device__ __forceinline__ void block_max1(float& m, const f32x16& acc, uint32_t
   }
 }
 
-__device__ __forceinline__ float finish_pair1(float m, bool qvalid, int h) {
+// The reference's similarity matrix has the dtype of its inputs: under torch.cuda.amp.autocast (colbert.py:60,
+// defaults.yaml:21 use_fp16: True) `bmm` returns fp16 — fp32 accumulation, ONE rounding per element — the -1000 fill and
+// `max` stay in fp16 and only `sum` is promoted to fp32 (:68-75).  Rounding is monotone, so
+// max_j round(s_ij) = round(max_j s_ij): one conversion of the per-token maximum reproduces that arithmetic exactly.
+// -1000 is representable in fp16 and bf16.  (bf16: what torch.bmm does on bf16 tensors.)
+template <int DT>
+__device__ __forceinline__ float round_like(float x) {
+  if constexpr (DT == MM_F16) {
+    return (float)(_Float16)x;                                 // v_cvt_f16_f32: RNE, overflow -> inf as torch's cast
+  } else if constexpr (DT == MM_BF16) {
+    const uint32_t u = __float_as_uint(x);
+    return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);   // RNE (no NaNs reach here)
+  } else {
+    return x;
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ float finish_pair1(float m, bool qvalid, int h, int rnd) {
   m = fmaxf(m, __shfl_xor(m, 32, 64));  // other half holds the other 16 rows of every block
+  if (rnd & MM_SIM_ROUND) m = round_like<DT>(m);
   return wave_sum((qvalid && h == 0) ? m : 0.0f);
 }
 
-__device__ __forceinline__ float finish_pair(const float (&m)[16], bool qvalid, int h) {
+template <int DT>
+__device__ __forceinline__ float finish_pair(const float (&m)[16], bool qvalid, int h, int rnd) {
   float mx = m[0];
 #pragma unroll
   for (int i = 1; i < 16; ++i) mx = fmaxf(mx, m[i]);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // other half holds the other 16 rows of every block
+  if (rnd & MM_SIM_ROUND) mx = round_like<DT>(mx);
   return wave_sum((qvalid && h == 0) ? mx : 0.0f);
+}
+
+// the pair's score: fp32 (autocast promotes `sum`, colbert.py:75), or — all-fp16 tensors outside autocast, the dynamic
+// teacher's all-pairs call, dynamic_teacher.py:245-246 — rounded like the inputs (torch sums 16-bit tensors in fp32 and
+// rounds the result once)
+template <int DT>
+__device__ __forceinline__ float finish_sum(float s, int rnd) {
+  return (rnd & MM_SUM_ROUND) ? round_like<DT>(s) : s;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -266,8 +266,8 @@ __global__ void __launch_bounds__(64) maxsim_pair_kernel(const MaxsimArgs a) {
       }
       block_max(m, acc, ex, va, fill, h);
     }
-    const float s = finish_pair(m, qvalid, h);
-    if (lane == 0) a.out[pair] = s;
+    const float s = finish_pair<DT>(m, qvalid, h, a.rnd);
+    if (lane == 0) a.out[pair] = finish_sum<DT>(s, a.rnd);
   }
 }
 

@@ -148,13 +148,31 @@ def _vec(t: torch.Tensor) -> torch.Tensor:
     return t.detach().reshape(-1).to(torch.float32).contiguous()
 
 
+def _flags(sim_round: bool, sum_round: bool) -> int:
+    return (_lib.SIM_ROUND if sim_round else 0) | (_lib.SUM_ROUND if sum_round else 0)
+
+
+def reference_rounding(q: torch.Tensor) -> "tuple[bool, bool]":
+    """(sim_round, sum_round) that reproduce what the reference's eager ops do with token vectors of q's dtype in the
+    CURRENT autocast state: 16-bit vectors give a 16-bit similarity matrix (`bmm` / `mm`, the -1000 fill and `max`,
+    colbert.py:68-71); `sum` (:75) is promoted to fp32 under autocast and is a 16-bit op outside it (the dynamic
+    teacher's all-pairs call, dynamic_teacher.py:245-246).  fp32 vectors outside autocast: no rounding anywhere."""
+    ac = torch.is_autocast_enabled("cuda")
+    lowp = q.dtype in (torch.float16, torch.bfloat16)
+    return (lowp or ac), (lowp and not ac)
+
+
 def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = None,
-           d_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1) -> torch.Tensor:
+           d_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1, sim_round: bool = False,
+           sum_round: bool = False) -> torch.Tensor:
     """ColBERT MaxSim (matchmaker/models/colbert.py:68-75; unmasked: :100-112).
 
     q [n_queries, Q, E], d [n_pairs, D, E]; pair p scores against query p // pairs_per_query.
     Masks: None | 1-D lengths | [rows, L] bool/uint8/int64/float (nonzero = real token).
-    Returns float32 [n_pairs]."""
+    sim_round / sum_round: the reference's dtype flow for fp16 / bf16 vectors (MM_SIM_ROUND / MM_SUM_ROUND in
+    include/mm_native.h): per-token maxima rounded to the vectors' dtype before the fp32 sum (what autocast does,
+    colbert.py:60-75), and the sum as well (16-bit tensors outside autocast).  Default: fp32 through max and sum.
+    Returns float32 [n_pairs] (with sum_round the values are exactly representable in the vectors' dtype)."""
     dev = _dev_check(q, d, q_mask, d_mask)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != d.dtype:
@@ -177,7 +195,8 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
         st = _stream(dev)
         ws = _workspace(dev, wsb, st)
         rc = L.mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), B, pairs_per_query,
-                             Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None, wsb, st)
+                             Q, D, E, _DT[q.dtype], _flags(sim_round, sum_round),
+                             ws.data_ptr() if ws is not None else None, wsb, st)
     _lib.check(rc, "mm_maxsim_fwd")
     return out
 
@@ -199,7 +218,7 @@ def _check_ranges(doc_begin: torch.Tensor, doc_end: torch.Tensor, n_rows: int):
 
 def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor, doc_end: torch.Tensor,
                   q_mask: Optional[torch.Tensor] = None, pairs_per_query: int = 1,
-                  check_ranges: bool = True) -> torch.Tensor:
+                  check_ranges: bool = True, sim_round: bool = False, sum_round: bool = False) -> torch.Tensor:
     """Unpadded MaxSim over a resident token store (the ColBERT retrieval aggregate,
     matchmaker/dense_retrieval.py:398-412 + colbert.py:100-112, in ONE launch).
 
@@ -234,7 +253,7 @@ def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor
         wsb = L.mm_maxsim_ragged_workspace_bytes(B, pairs_per_query, Q, qk)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         rc = L.mm_maxsim_ragged_fwd(q.data_ptr(), tokens.data_ptr(), doc_begin.data_ptr(), doc_end.data_ptr(), qp, qk,
-                                    out.data_ptr(), B, pairs_per_query, Q, E, _DT[q.dtype],
+                                    out.data_ptr(), B, pairs_per_query, Q, E, _DT[q.dtype], _flags(sim_round, sum_round),
                                     ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
     _lib.check(rc, "mm_maxsim_ragged_fwd")
     return out
@@ -276,9 +295,11 @@ def maxsim_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor],
 
 
 def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Tensor,
-                   d_mask: Optional[torch.Tensor], bug_compatible: bool = False) -> torch.Tensor:
+                   d_mask: Optional[torch.Tensor], bug_compatible: bool = False, sim_round: bool = False,
+                   sum_round: bool = False) -> torch.Tensor:
     """All-pairs MaxSim [Bq, Bd] (matchmaker/models/colbert.py:154-162).  bug_compatible=True masks
-    score[i, j] with document i's mask as the reference does (and needs Bq == Bd)."""
+    score[i, j] with document i's mask as the reference does (and needs Bq == Bd).  sim_round / sum_round as in
+    maxsim() (the dynamic teacher calls this on fp16 vectors outside autocast: both, dynamic_teacher.py:245-246)."""
     dev = _dev_check(q, d, q_mask, d_mask)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != d.dtype:
@@ -298,7 +319,7 @@ def maxsim_inbatch(q: torch.Tensor, q_mask: Optional[torch.Tensor], d: torch.Ten
         wsb = L.mm_maxsim_inbatch_workspace_bytes(Bq, Bd, Q, D, qk, dk)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         rc = L.mm_maxsim_inbatch_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), Bq, Bd, Q, D, E,
-                                     _DT[q.dtype], 1 if bug_compatible else 0,
+                                     _DT[q.dtype], 1 if bug_compatible else 0, _flags(sim_round, sum_round),
                                      ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
     _lib.check(rc, "mm_maxsim_inbatch_fwd")
     return out

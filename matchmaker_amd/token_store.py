@@ -72,10 +72,14 @@ class TokenStore:
         dev = self.tokens.device
         return torch.from_numpy(self._begin[idx]).to(dev), torch.from_numpy(self._end[idx]).to(dev)
 
-    def aggregate(self, query_vecs: torch.Tensor, candidates: Sequence[Sequence]) -> List[List[Tuple[object, float]]]:
+    def aggregate(self, query_vecs: torch.Tensor, candidates: Sequence[Sequence],
+                  use_fp16: bool = True) -> List[List[Tuple[object, float]]]:
         """query_vecs [nq, Q, E] (forward_representation output, already multiplied by its mask as in
         `search_type="encode"`); candidates[i] = the seq_ids to re-score for query i (the set the
-        reference loops over, :400-402).  Returns, per query, [(seq_id, score)] like
+        reference loops over, :400-402).  use_fp16: the searcher head's autocast switch (indexing_heads.py:49-56,
+        `model_config["use_fp16"]` at :407): the stored rows go through `.float()` and autocast's cast back — the same fp16
+        values — and `bmm` / `max` return fp16, so every per-token maximum is rounded to fp16 before the fp32 sum;
+        False = fp32 similarities of the stored values.  Returns, per query, [(seq_id, score)] like
         `validation_results[query_id]` (:410)."""
         nq = query_vecs.shape[0]
         if len(candidates) != nq:
@@ -97,7 +101,8 @@ class TokenStore:
             bb[i, :n], ee[i, :n] = b[off: off + n], e[off: off + n]
             off += n
         q = query_vecs.to(self.tokens.dtype)
-        scores = ops.maxsim_ragged(q, self.tokens, bb.view(-1), ee.view(-1), None, pairs_per_query=C, check_ranges=False).view(nq, C)
+        scores = ops.maxsim_ragged(q, self.tokens, bb.view(-1), ee.view(-1), None, pairs_per_query=C, check_ranges=False,
+                                   sim_round=bool(use_fp16)).view(nq, C)
         scores = scores.cpu()
         return [[(candidates[i][j], float(scores[i, j])) for j in range(counts[i])] for i in range(nq)]
 

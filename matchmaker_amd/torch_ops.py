@@ -2,8 +2,10 @@
 
 Importing this module defines
 
-    torch.ops.mm_native.maxsim(q, d, q_mask, d_mask, pairs_per_query=1)            -> [n_pairs]
-    torch.ops.mm_native.maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False)  -> [Bq, Bd]
+    torch.ops.mm_native.maxsim(q, d, q_mask, d_mask, pairs_per_query=1,
+                               sim_round=False, sum_round=False)                    -> [n_pairs]
+    torch.ops.mm_native.maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False,
+                                       sim_round=False, sum_round=False)            -> [Bq, Bd]
     torch.ops.mm_native.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w,
                                     pairs_per_query=1, d_gate=None, clamp_min=1e-10) -> [n_pairs]
     torch.ops.mm_native.tkl_window_pool(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params,
@@ -12,8 +14,9 @@ Importing this module defines
 for HIP tensors only (dispatch key CUDA; a CPU tensor raises NotImplementedError: there is no CPU kernel), each
 with a fake (meta) implementation for tracing, an autograd formula backed by the native backward kernels
 (maxsim, kernel_pool) and an autocast rule that mirrors what the reference's eager code does under
-`torch.cuda.amp.autocast(enabled=use_fp16)` (colbert.py:60: the bmm runs in fp16, scores come back fp32;
-the TK family stays fp32 — allennlp's cosine has no fp16 path the configs use, tk.yaml `use_fp16: False`).
+`torch.cuda.amp.autocast(enabled=use_fp16)` (colbert.py:60: the bmm runs in fp16 and RETURNS fp16 — the MaxSim ops cast
+their vectors to the autocast dtype and set sim_round, so every per-token maximum is rounded as the reference's fp16 `max`
+is — and the promoted `sum` returns fp32; the TK family stays fp32 — allennlp's cosine has no fp16 path the configs use, tk.yaml `use_fp16: False`).
 The drop-in modules call `matchmaker_amd.ops` directly; these registrations are the boundary for callers
 that want dispatcher-level ops (torch.compile graphs, TorchScript-free export, other extensions).
 """
@@ -30,17 +33,17 @@ _NS = "mm_native"
 # ---------------------------------------------------------------------------------------------- maxsim
 @torch.library.custom_op(_NS + "::maxsim", mutates_args=(), device_types="cuda")
 def maxsim(q: Tensor, d: Tensor, q_mask: Optional[Tensor], d_mask: Optional[Tensor],
-           pairs_per_query: int = 1) -> Tensor:
-    return ops.maxsim(q, d, q_mask, d_mask, pairs_per_query)
+           pairs_per_query: int = 1, sim_round: bool = False, sum_round: bool = False) -> Tensor:
+    return ops.maxsim(q, d, q_mask, d_mask, pairs_per_query, sim_round=sim_round, sum_round=sum_round)
 
 
 @maxsim.register_fake
-def _(q, d, q_mask, d_mask, pairs_per_query=1):
+def _(q, d, q_mask, d_mask, pairs_per_query=1, sim_round=False, sum_round=False):
     return q.new_empty((d.shape[0],), dtype=torch.float32)
 
 
 def _maxsim_setup(ctx, inputs, output):
-    q, d, q_mask, d_mask, ppq = inputs
+    q, d, q_mask, d_mask, ppq, _sim, _sum = inputs
     ctx.save_for_backward(q, d, q_mask, d_mask)
     ctx.ppq = ppq
 
@@ -51,25 +54,46 @@ def _maxsim_backward(ctx, g):
         raise ops.NativeError("mm_native::maxsim backward needs the pair-per-row layout (pairs_per_query = 1), "
                               "the one train.py feeds")
     gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g)
-    return gq.to(q.dtype), gd.to(d.dtype), None, None, None
+    return gq.to(q.dtype), gd.to(d.dtype), None, None, None, None, None
 
 
 maxsim.register_autograd(_maxsim_backward, setup_context=_maxsim_setup)
-torch.library.register_autocast(_NS + "::maxsim", "cuda", torch.float16)
+
+_FRAG = torch.library.Library(_NS, "FRAGMENT")
+_AUTOCAST_KEYS = torch._C.DispatchKeySet(torch._C.DispatchKey.AutocastCPU) | torch._C.DispatchKeySet(torch._C.DispatchKey.AutocastCUDA)
+
+
+def _ac_cast(t):
+    return t.to(torch.get_autocast_dtype("cuda")) if t.dtype == torch.float32 else t
+
+
+def _maxsim_autocast(_ks, q, d, q_mask, d_mask, pairs_per_query=1, sim_round=False, sum_round=False):
+    """What eager does under autocast (colbert.py:60-75): vectors in the autocast dtype, similarities and maxima in it
+    (sim_round), the sum promoted to fp32."""
+    with torch._C._ExcludeDispatchKeyGuard(_AUTOCAST_KEYS):
+        return torch.ops.mm_native.maxsim(_ac_cast(q), _ac_cast(d), q_mask, d_mask, pairs_per_query, True, False)
+
+
+_FRAG.impl("maxsim", _maxsim_autocast, "AutocastCUDA", with_keyset=True)
 
 
 @torch.library.custom_op(_NS + "::maxsim_inbatch", mutates_args=(), device_types="cuda")
 def maxsim_inbatch(q: Tensor, q_mask: Optional[Tensor], d: Tensor, d_mask: Optional[Tensor],
-                   bug_compatible: bool = False) -> Tensor:
-    return ops.maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible)
+                   bug_compatible: bool = False, sim_round: bool = False, sum_round: bool = False) -> Tensor:
+    return ops.maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible, sim_round=sim_round, sum_round=sum_round)
 
 
 @maxsim_inbatch.register_fake
-def _(q, q_mask, d, d_mask, bug_compatible=False):
+def _(q, q_mask, d, d_mask, bug_compatible=False, sim_round=False, sum_round=False):
     return q.new_empty((q.shape[0], d.shape[0]), dtype=torch.float32)
 
 
-torch.library.register_autocast(_NS + "::maxsim_inbatch", "cuda", torch.float16)
+def _maxsim_inbatch_autocast(_ks, q, q_mask, d, d_mask, bug_compatible=False, sim_round=False, sum_round=False):
+    with torch._C._ExcludeDispatchKeyGuard(_AUTOCAST_KEYS):
+        return torch.ops.mm_native.maxsim_inbatch(_ac_cast(q), q_mask, _ac_cast(d), d_mask, bug_compatible, True, False)
+
+
+_FRAG.impl("maxsim_inbatch", _maxsim_inbatch_autocast, "AutocastCUDA", with_keyset=True)
 
 
 # ---------------------------------------------------------------------------------------------- kernel pooling

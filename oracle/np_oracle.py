@@ -20,34 +20,63 @@ in rank-order checks.
 import numpy as np
 
 # ----------------------------------------------------------------------------- ColBERT
+#
+# The reference's DEFAULT precision mode (config/train/defaults.yaml:21 `use_fp16: True`, colbert.py:60) runs the block
+# under torch.cuda.amp.autocast: `bmm` takes fp16 vectors and RETURNS an fp16 matrix (GPU GEMMs accumulate in fp32 and
+# round each element once), the masked assignment and `max` are fp16 ops, and `sum` — on autocast's fp32 list — is
+# promoted to fp32 (:68-75).  `sim_dtype` restates that: the similarity matrix is rounded to it (np.float16, or
+# "bfloat16" for torch.bmm on bf16 tensors) right after the product; mask / max then act on representable values
+# (-1000 is exact in both) exactly as the fp16 ops do.  `sum_dtype` rounds the pair's sum as well: 16-bit tensors OUTSIDE
+# autocast (the dynamic teacher's all-pairs call, distillation/dynamic_teacher.py:245-246), where `sum` is a 16-bit op
+# that accumulates in fp32 and rounds once.  Use dtype=np.float64 for the product to take the accumulation order out of
+# the rounding decision (the inputs are fp16-valued: the fp64 product is exact to ~1e-16).
 
 
-def maxsim_paired(q, d, q_mask, d_mask, dtype=np.float32):
+def _bf16_rne(x):
+    """float32 -> bfloat16 (round to nearest even) -> float32, bit-exact with v_cvt_pk_bf16_f32."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << np.uint32(16)
+    return r.view(np.float32)
+
+
+def round_to(x, lowp):
+    """x rounded (RNE) to the 16-bit type `lowp` (None = unchanged), returned in x's own dtype."""
+    if lowp is None:
+        return x
+    x = np.asarray(x)
+    if lowp == "bfloat16":
+        return _bf16_rne(x.astype(np.float32)).astype(x.dtype)
+    with np.errstate(over="ignore"):
+        return x.astype(lowp).astype(x.dtype)
+
+
+def maxsim_paired(q, d, q_mask, d_mask, dtype=np.float32, sim_dtype=None, sum_dtype=None):
     """ColBERT.forward scoring block — matchmaker/models/colbert.py:68-75.
 
     q [B,Q,E], d [B,D,E]; q_mask [B,Q], d_mask [B,D] (any dtype, nonzero = real token).
     score[b] = sum_{i: q_mask} max_j ( d_mask[b,j] ? <q_i, d_j> : -1000 )
+    sim_dtype / sum_dtype: the 16-bit dtype flow of the autocast / all-fp16 modes (section comment above).
     """
     q = np.asarray(q, dtype=dtype)
     d = np.asarray(d, dtype=dtype)
-    s = np.matmul(q, np.swapaxes(d, 1, 2))                       # :68  bmm -> [B,Q,D]
+    s = round_to(np.matmul(q, np.swapaxes(d, 1, 2)), sim_dtype)  # :68  bmm -> [B,Q,D] (fp16 under autocast)
     dm = np.asarray(d_mask) != 0
     s = np.where(dm[:, None, :], s, dtype(-1000))                # :69  doc pad -> -1000 (not -inf)
     m = s.max(-1)                                                # :71  max over D
     qm = np.asarray(q_mask) != 0
     m = np.where(qm, m, dtype(0))                                # :73  query pad -> 0
-    return m.sum(-1, dtype=dtype)                                # :75
+    return round_to(m.sum(-1, dtype=dtype), sum_dtype)           # :75  (fp32 under autocast)
 
 
-def maxsim_unmasked(q, d, dtype=np.float32):
+def maxsim_unmasked(q, d, dtype=np.float32, sim_dtype=None, sum_dtype=None):
     """ColBERT.forward_aggregation — matchmaker/models/colbert.py:100-112 (no masks)."""
     q = np.asarray(q, dtype=dtype)
     d = np.asarray(d, dtype=dtype)
-    s = np.matmul(q, np.swapaxes(d, 1, 2))                       # :101
-    return s.max(-1).sum(-1, dtype=dtype)                        # :104, :108
+    s = round_to(np.matmul(q, np.swapaxes(d, 1, 2)), sim_dtype)  # :101
+    return round_to(s.max(-1).sum(-1, dtype=dtype), sum_dtype)   # :104, :108
 
 
-def maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False, dtype=np.float32):
+def maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False, dtype=np.float32, sim_dtype=None, sum_dtype=None):
     """ColBERT.forward_inbatch_aggregation — matchmaker/models/colbert.py:154-162.
 
     q [Bq,Q,E], d [Bd,D,E] -> [Bq,Bd].  The reference (:158) expands the document mask as
@@ -58,7 +87,7 @@ def maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False, dtype=np.float32)
     d = np.asarray(d, dtype=dtype)
     Bq, Q, E = q.shape
     Bd, D, _ = d.shape
-    s = (q.reshape(-1, E) @ d.reshape(-1, E).T).reshape(Bq, Q, Bd, D)   # :154
+    s = round_to(q.reshape(-1, E) @ d.reshape(-1, E).T, sim_dtype).reshape(Bq, Q, Bd, D)   # :154
     s = np.swapaxes(s, 1, 2)                                            # :156 [Bq,Bd,Q,D]
     dm = np.asarray(d_mask) != 0
     if bug_compatible:
@@ -71,7 +100,7 @@ def maxsim_inbatch(q, q_mask, d, d_mask, bug_compatible=False, dtype=np.float32)
     m = s.max(-1)                                                       # :159
     qm = np.asarray(q_mask) != 0
     m = np.where(qm[:, None, :], m, dtype(0))                           # :160
-    return m.sum(-1, dtype=dtype)                                       # :161
+    return round_to(m.sum(-1, dtype=dtype), sum_dtype)                  # :161
 
 
 # ----------------------------------------------------------------------------- cosine
@@ -87,13 +116,6 @@ def cosine_matrix(a, b, dtype=np.float32):
     an = a / (np.sqrt((a * a).sum(-1, keepdims=True, dtype=dtype)) + tiny)
     bn = b / (np.sqrt((b * b).sum(-1, keepdims=True, dtype=dtype)) + tiny)
     return np.matmul(an, np.swapaxes(bn, -1, -2))
-
-
-def _bf16_rne(x):
-    """float32 -> bfloat16 (round to nearest even) -> float32, bit-exact with v_cvt_pk_bf16_f32."""
-    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << np.uint32(16)
-    return r.view(np.float32)
 
 
 def cosine_matrix_split_bf16(a, b):

@@ -114,6 +114,18 @@ def colbert_forward(q, d, q_mask, d_mask, grad=False):
                          {"vecs": d, "attention_mask": d_mask}, use_fp16=False)
 
 
+def colbert_forward_16bit(q, d, q_mask, d_mask):
+    """Real ColBERT.forward (colbert.py:54-86) on 16-bit CPU token vectors with autocast off: `bmm`, the masked assignment,
+    `max` AND `sum` run as fp16 (bf16) ops — the dtype flow MM_SIM_ROUND | MM_SUM_ROUND restates.  (CUDA autocast, which
+    promotes `sum` to fp32, is inert on the CPU: that mode is checked on the GPU box against oracle/torch_port under
+    torch.autocast, tests/test_fp16_flow_gpu.py.)  Returns [B] in the vectors' dtype."""
+    assert q.dtype in (torch.float16, torch.bfloat16)
+    m = _make_colbert()
+    with torch.no_grad():
+        return m.forward({"vecs": q, "attention_mask": q_mask},
+                         {"vecs": d, "attention_mask": d_mask}, use_fp16=False)
+
+
 def make_colbert_with_encoder(encoder, compression_dim):
     """Real ColBERT class (colbert.py) around a given HF encoder: the constructor (:37-52) downloads weights by
     name and its config class does not validate under transformers >= 5, so the object is assembled the way

@@ -76,6 +76,39 @@ def gen_colbert():
                                 R.colbert_forward_inbatch_aggregation(q, qm, d, dm).numpy()))
 
 
+def gen_colbert_16bit_flow():
+    """The reference's 16-bit dtype flow, run by the REAL class on fp16 / bf16 CPU tensors (autocast off: bmm / mm, the
+    -1000 fill, max and sum are all 16-bit ops — what the dynamic teacher's all-pairs call executes on the GPU,
+    dynamic_teacher.py:245-246).  Pins np_oracle's sim_dtype / sum_dtype variants and the device's
+    MM_SIM_ROUND | MM_SUM_ROUND arithmetic."""
+    for (tag, dt, B, Q, D, E, seed, unit) in [("fp16", torch.float16, 16, 32, 180, 128, 2102, True),
+                                              ("fp16", torch.float16, 6, 38, 200, 768, 2103, False),
+                                              ("fp16", torch.float16, 5, 13, 47, 64, 2104, False),
+                                              ("bf16", torch.bfloat16, 16, 32, 180, 128, 2105, True)]:
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(B, Q, E, generator=g)
+        d = torch.randn(B, D, E, generator=g)
+        if unit:
+            q, d = torch.nn.functional.normalize(q, dim=-1), torch.nn.functional.normalize(d, dim=-1)
+        else:
+            q, d = q * 0.3, d * 0.3
+        q, d = q.to(dt), d.to(dt)
+        q_len = torch.randint(1, Q + 1, (B,), generator=g)
+        d_len = torch.randint(0, D + 1, (B,), generator=g)
+        d_len[0], d_len[1] = D, 0
+        qm = prefix_mask(q_len, Q, torch.int64)
+        dm = prefix_mask(d_len, D, torch.int64)
+        dm[2, min(3, D - 1)] = 0                                         # a hole
+        bits = (lambda x: x.view(torch.int16).numpy().view(np.uint16))
+        np.savez_compressed(os.path.join(OUT, f"flow16_{tag}_q{Q}_d{D}_e{E}.npz"),
+                            dtype=tag, q_bits=bits(q), d_bits=bits(d),
+                            q_mask=qm.numpy().astype(np.uint8), d_mask=dm.numpy().astype(np.uint8),
+                            forward=R.colbert_forward_16bit(q, d, qm, dm).float().numpy(),
+                            forward_aggregation=R.colbert_forward_aggregation(q, d).float().numpy(),
+                            forward_inbatch_aggregation=(
+                                R.colbert_forward_inbatch_aggregation(q, qm, d, dm).float().numpy()))
+
+
 def gen_colbert_e2e():
     # the real ColBERT.forward end to end (encoder + compressor + scoring, colbert.py:54-98) on token ids, with
     # a tiny randomly initialised BERT: what eval.py:108 calls, minus the checkpoint download
@@ -369,7 +402,7 @@ def gen_tkl_grad():
                             **extra, **grads, **sd)
 
 
-GENERATORS = {"colbert": gen_colbert, "colbert_e2e": gen_colbert_e2e, "e2e_tk_tkl": gen_e2e_tk_tkl, "tk": gen_tk,
+GENERATORS = {"colbert": gen_colbert, "colbert_16bit_flow": gen_colbert_16bit_flow, "colbert_e2e": gen_colbert_e2e, "e2e_tk_tkl": gen_e2e_tk_tkl, "tk": gen_tk,
               "knrm": gen_knrm, "conv_knrm": gen_conv_knrm, "tkl": gen_tkl, "tk_sparse": gen_tk_sparse, "idcm": gen_idcm, "tkl_grad": gen_tkl_grad}
 
 if __name__ == "__main__":

@@ -40,8 +40,9 @@ def test_forward_equals_oracle_on_module_vectors(use_fp16):
         s2, qv, dv = m.forward(query, doc, use_fp16=use_fp16)
         m.is_teacher_model = False
     assert score.dtype == torch.float32 and torch.equal(score, s2)
+    # use_fp16: the reference's autocast arithmetic — fp16 similarities and maxima, fp32 sum (colbert.py:60-75)
     ref = O.maxsim_paired(qv.float().cpu().numpy(), dv.float().cpu().numpy(), query["attention_mask"].cpu().numpy(),
-                          doc["attention_mask"].cpu().numpy())
+                          doc["attention_mask"].cpu().numpy(), sim_dtype=np.float16 if use_fp16 else None)
     np.testing.assert_allclose(score.cpu().numpy(), ref, atol=util.TOL_BF16 if use_fp16 else util.TOL_FP32)
     if use_fp16:
         assert qv.dtype == torch.float16

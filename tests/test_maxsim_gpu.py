@@ -165,7 +165,7 @@ def test_errors_are_loud():
     from matchmaker_amd import _lib
     out = torch.empty(2, dtype=torch.float32, device=dev)
     rc = _lib.lib().mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), None, _lib.MASK_NONE, None, _lib.MASK_NONE, out.data_ptr(), 2, 2,
-                                  4, 5, 12, _lib.MM_BF16, None, 0, torch.cuda.current_stream(dev).cuda_stream)
+                                  4, 5, 12, _lib.MM_BF16, 0, None, 0, torch.cuda.current_stream(dev).cuda_stream)
     assert rc != 0 and "16-byte" in _lib.lib().mm_last_error().decode()
     with pytest.raises(NativeError):
         ops.maxsim(q.cpu(), d.cpu(), pairs_per_query=2)              # no CPU fallback

@@ -9,8 +9,9 @@ import matchmaker_amd.torch_ops  # noqa: F401  (defines torch.ops.mm_native.*)
 def test_ops_are_registered_with_the_documented_schemas():
     ns = torch.ops.mm_native
     assert str(ns.maxsim.default._schema) == \
-        "mm_native::maxsim(Tensor q, Tensor d, Tensor? q_mask, Tensor? d_mask, SymInt pairs_per_query=1) -> Tensor"
-    for name, n_args in (("maxsim_inbatch", 5), ("kernel_pool", 11), ("tkl_window_pool", 10)):
+        ("mm_native::maxsim(Tensor q, Tensor d, Tensor? q_mask, Tensor? d_mask, SymInt pairs_per_query=1, "
+         "bool sim_round=False, bool sum_round=False) -> Tensor")
+    for name, n_args in (("maxsim_inbatch", 7), ("kernel_pool", 11), ("tkl_window_pool", 10)):
         assert len(getattr(ns, name).default._schema.arguments) == n_args
     assert len(ns.tkl_window_pool.default._schema.returns) == 2
 

@@ -26,11 +26,15 @@ def test_maxsim_op_autograd_and_autocast():
     assert torch.equal(s, ops.maxsim(q, d, qm, dm))
     ref = O.maxsim_paired(q.cpu().numpy(), d.cpu().numpy(), qm.cpu().numpy(), dm.cpu().numpy(), dtype=np.float64)
     np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
-    # autocast: fp32 inputs run through the fp16 kernel (what the reference's autocast does to its bmm), fp32 scores
+    # autocast: fp32 inputs run through the fp16 kernel AND every per-token maximum is rounded to fp16 — what the reference's
+    # autocast does to its bmm / max (colbert.py:60-75) — fp32 scores; bit-equal to torch's own eager ops under autocast
     with torch.autocast("cuda", dtype=torch.float16):
         sa = torch.ops.mm_native.maxsim(q, d, qm, dm, 1)
-    assert sa.dtype == torch.float32 and torch.equal(sa, ops.maxsim(q.half(), d.half(), qm, dm))
-    np.testing.assert_allclose(sa.cpu().numpy(), ref, atol=0.15, rtol=util.TOL_BF16)
+        from oracle import torch_port as TP
+        eager = TP.maxsim_forward(q, d, qm, dm)
+    assert sa.dtype == torch.float32 and torch.equal(sa, ops.maxsim(q.half(), d.half(), qm, dm, sim_round=True))
+    assert eager.dtype == torch.float32 and float((sa - eager).abs().max()) <= 2.0 ** -6      # (one fp16 ulp of a token of size < 32)
+    np.testing.assert_allclose(sa.cpu().numpy(), ref, atol=0.3, rtol=util.TOL_BF16)
     # autograd through mm_maxsim_bwd
     ql, dl = q.clone().requires_grad_(True), d.clone().requires_grad_(True)
     go = torch.randn(B, generator=gen).to(dev)

@@ -25,6 +25,28 @@ def load(name):
     return out
 
 
+def load_flow16(name):
+    """tests/golden/flow16_*.npz: outputs of the REAL reference class on fp16 / bf16 CPU tensors (all-16-bit dtype flow).
+    Returns the dict with q / d as float32 arrays holding the 16-bit values, and `lowp` = np.float16 | "bfloat16"."""
+    g = load(name)
+    bf = str(g["dtype"]) == "bf16"
+    for k in ("q", "d"):
+        bits = g[k + "_bits"]
+        g[k] = bf16_bits_to_f32(bits) if bf else bits.view(np.float16).astype(np.float32)
+    g["lowp"] = "bfloat16" if bf else np.float16
+    return g
+
+
+def ulps16(got, ref, lowp):
+    """|got - ref| in units of ref's 16-bit ulp (fp16: 11 significant bits, bf16: 8)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    bits = 8 if lowp == "bfloat16" else 11
+    mag = np.maximum(np.abs(ref), np.abs(got))
+    e = np.floor(np.log2(np.maximum(mag, 2.0 ** (-126 if lowp == "bfloat16" else -14))))
+    return np.abs(got - ref) / 2.0 ** (e - (bits - 1))
+
+
 def golden_files(prefix):
     return sorted(f for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
 
