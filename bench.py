@@ -199,6 +199,53 @@ def gpu_time_ms(fn, steps, warmup=2, warm_ms=40.0, timed_ms=25.0, max_calls=400)
     return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
 
 
+def smi_sample():
+    """Shader / memory clock (MHz) and socket power (W) of this rank's GPU as rocm-smi reports them (~0.5 s per call)."""
+    import re
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=30)
+    except Exception as e:
+        return {"error": repr(e)}
+    gpu = os.environ.get("LOCAL_RANK", "0")
+    out = {}
+    for line in r.stdout.splitlines():
+        if not line.startswith(f"GPU[{gpu}]"):
+            continue
+        m = re.search(r"(sclk|mclk) clock level: \d+: \((\d+)Mhz\)", line)
+        if m:
+            out[m.group(1) + "_mhz"] = int(m.group(2))
+        m = re.search(r"Power \(W\): ([0-9.]+)", line)
+        if m:
+            out["socket_power_w"] = float(m.group(1))
+    return out or {"error": (r.stdout + r.stderr)[-200:]}
+
+
+def extra_hbm_calibration(d, steps, headline_gbs):
+    """What THIS box's memory system gives the headline's access pattern, measured in the same process over the same
+    11.8 GB document tensor: (i) mm_hbm_stream_probe = maxsim_stream_kernel's LDS-DMA read stream with the arithmetic
+    removed (same geometry, ring, counted waits; no MFMA, no maximum), (ii) a device-to-device copy of half of it
+    (hipMemcpyDtoD through torch: bytes read + written).  The headline kernel's rate over (i) separates a slow box from a
+    slow kernel: the kernel is at the stream's own limit when the ratio is ~1."""
+    import torch
+    from matchmaker_amd import ops
+    nbytes = d.numel() * d.element_size() // 8192 * 8192
+    out = {}
+    for name, nt in (("lds_dma_read_stream_nt", True), ("lds_dma_read_stream", False)):
+        ms = gpu_time_ms(lambda: ops.hbm_stream_probe(d, nt=nt), steps)
+        out[name] = {"ms": ms, "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes": nbytes}
+    half = d[: d.shape[0] // 2]
+    dst = torch.empty_like(half)
+    ms = gpu_time_ms(lambda: dst.copy_(half), steps)
+    hb = half.numel() * half.element_size()
+    out["memcpy_dtod"] = {"ms": ms, "GBps_read_plus_write": 2 * hb / (ms * 1e-3) / 1e9, "bytes_copied": hb}
+    del dst
+    torch.cuda.empty_cache()
+    out["headline_kernel_GBps"] = headline_gbs
+    out["headline_over_read_stream"] = headline_gbs / out["lds_dma_read_stream_nt"]["GBps"]
+    out["kernel"] = "hbm_stream_probe_kernel (csrc/maxsim.hip): the headline kernel's stream, no arithmetic"
+    return out
+
+
 def vendor_gemm_tflops(shapes):
     """torch.mm (hipBLASLt / rocBLAS) at the given {name: (M, N, K, dtype)} shapes, 16-bit output written: a calibration of
     what matrix rate this board sustains, not part of any product path."""
@@ -244,9 +291,14 @@ def extra_dropin_forward(q, d, q_len, d_len, steps):
 def extra_sustained(score_shard, B, seconds=4.0):
     """The same launch back to back for a few seconds of wall clock: long enough for an external sampler (rocm-smi at a
     multi-second cadence) to see the GPU busy, and a cross-check of the 20-step figure on the host clock."""
+    import threading
     import torch
+    idle = smi_sample()
     score_shard()
     torch.cuda.synchronize()
+    busy = {}
+    th = threading.Timer(1.5, lambda: busy.update(smi_sample()))      # one sample while the loop below keeps the GPU busy
+    th.start()
     n, t0 = 0, time.perf_counter()
     while True:
         for _ in range(100):
@@ -254,10 +306,10 @@ def extra_sustained(score_shard, B, seconds=4.0):
         torch.cuda.synchronize()
         n += 100
         dt = time.perf_counter() - t0
-        if dt >= seconds:
+        if dt >= seconds and not th.is_alive():
             break
     return {"workload": "the headline launch repeated back to back", "steps": n, "seconds": dt, "ms_per_step": 1e3 * dt / n,
-            "pairs_per_s": n * B / dt}
+            "pairs_per_s": n * B / dt, "rocm_smi_idle_before": idle, "rocm_smi_during": busy}
 
 
 def tk_exact_f32_subprocess():
@@ -360,14 +412,18 @@ def extra_tkl(steps, cpu_budget):
     chunks, cmask, slot, C = chunk_documents(d * dm.unsqueeze(-1), dm)       # stands in for the contextualised chunks
     params = m.pack_params()
     P = chunks.shape[0]
-    fn = lambda: ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, "embedding")
+    fn = lambda: ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, "embedding", check_order=False)   # (chunk_documents packs ascending)
     ms = gpu_time_ms(fn, steps)
     by = P * 50 * Et * 4 + B * Qt * Et * 4 + P * 50 * 4 + 4 * B
+    # SURVEY.md §8(d) prices all 50 rows of a packed chunk; the scoring reads the 40 centre rows (sigir20_tkl.py:174) — the
+    # bytes the call actually needs, and the tighter fraction
+    by_needed = P * 40 * Et * 4 + B * Qt * Et * 4 + P * 40 * 4 + 4 * B
     gbs = by / (ms * 1e-3) / 1e9
     out = {"workload": f"TKL scoring (sigir20_tkl.py:180-286), {B} documents x D={Dt} (lengths U{{50..{Dt}}}: {P} packed chunks "
                        f"of 50 tokens), dim={Et}, Q={Qt} (lengths U{{3..{Qt}}}), embedding saturation",
            "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "needed_bytes": by_needed, "frac_needed_bytes": by_needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> + tkl_region_kernel (whole mm_tkl_fwd call)",
            "profile": "profiles/r03_tkl_pmc.json, profiles/r03_tkl_trace.json (full documents: profiles/r03_tklfull_pmc.json)"}
     try:
@@ -389,7 +445,7 @@ def extra_tkl(steps, cpu_budget):
         ch4, cm4, sl4, C4 = chunk_documents(d4 * dm4.unsqueeze(-1), dm4)
         del d4
         qc4 = q4 * qm4.unsqueeze(-1)
-        ms4 = gpu_time_ms(lambda: ops.tkl_score(qc4, ch4, cm4, sl4, qm4, params, B4, C4, 11, "embedding"), steps)
+        ms4 = gpu_time_ms(lambda: ops.tkl_score(qc4, ch4, cm4, sl4, qm4, params, B4, C4, 11, "embedding", check_order=False), steps)
         by4 = ch4.shape[0] * 50 * Et * 4 + B4 * Qt * Et * 4 + ch4.shape[0] * 50 * 4 + 4 * B4
         out["batch_1024_documents"] = {"ms": ms4, "docs_per_s": B4 / (ms4 * 1e-3), "algorithmic_bytes": by4,
                                        "frac": by4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -537,6 +593,43 @@ def extra_eval_batch(steps, cpu_budget):
 
     run("colbert_dim128_bf16", 16, colbert_batch_maker(Q, D, E, torch.bfloat16), lambda b: ColBERT._score(*b),
         Bc * ((D + Q) * E * 2 + 8 * (D + Q) + 4))
+    # the same calls replayed from HIP graphs (one captured call per resident batch): what rerank.evaluate_batches(graph=True)
+    # does per batch shape — the Python + launch path of a call becomes one graph launch
+    try:
+        make = colbert_batch_maker(Q, D, E, torch.bfloat16)
+        batches = [make() for _ in range(16)]
+        graphs = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for b in batches:
+                ColBERT._score(*b)
+        torch.cuda.current_stream().wait_stream(side)
+        for b in batches:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                o = ColBERT._score(*b)
+            graphs.append((gr, o))
+        want = ColBERT._score(*batches[3])
+        graphs[3][0].replay()
+        same = bool(torch.equal(want, graphs[3][1]))
+        torch.cuda.synchronize()
+        n_calls = 400
+        t0 = time.perf_counter()
+        for i in range(n_calls):
+            graphs[i % 16][0].replay()
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_done = time.perf_counter() - t0
+        byc = Bc * ((D + Q) * E * 2 + 8 * (D + Q) + 4)
+        res["colbert_dim128_bf16"]["graph_replay"] = {
+            "us_per_call_completed": 1e6 * t_done / n_calls, "us_per_call_host_issue": 1e6 * t_issue / n_calls,
+            "frac": byc / (t_done / n_calls) / 1e9 / HBM_PEAK_GBS, "replayed_scores_equal_eager": same,
+            "what": "torch.cuda.CUDAGraph of one ColBERT._score call per resident batch, replayed back to back"}
+        del batches, graphs
+        torch.cuda.empty_cache()
+    except Exception as e:
+        res["colbert_dim128_bf16"]["graph_replay"] = {"error": repr(e)[:300]}
     run("colbert_published_dim768_fp16", 3, colbert_batch_maker(38, 200, 768, torch.float16), lambda b: ColBERT._score(*b),
         Bc * ((200 + 38) * 768 * 2 + 8 * (200 + 38) + 4))
     prm = [torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev), torch.ones(11, device=dev),
@@ -686,8 +779,373 @@ def extra_dot_topk(steps, cpu_budget):
     return out
 
 
+def extra_train_step(steps, cpu_budget):
+    """The training path (train.py:347-348 forward, :503-524 loss.backward()) through the native operators: forward +
+    backward of ColBERT._score (fp16 autocast, defaults.yaml:21), ECAI20_TK's pooling block and TKL's scoring, at
+    `batch_size_train: 32` x 2 (positive + negative documents, defaults.yaml:114) and at 2,048 pairs.  Beside each: the same
+    step through the reference's own torch statements (oracle/torch_port.py) with autograd ON THIS GPU — the stated eager
+    baseline, not a product path.  Bytes: the forward's reads, the backward's re-read of the same operands (nothing is
+    saved: the match matrix is recomputed) and the fp32 gradients written."""
+    import torch
+    from oracle import torch_port as TP
+    from matchmaker_amd import ops, synth
+    from matchmaker_amd.colbert import ColBERT
+    from matchmaker_amd.tk import _KernelPoolFn
+    from matchmaker_amd.tkl import TKL_sigir20, _TKLScoreFn, chunk_documents
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res = {}
+
+    def leg(name, B, fwd, step_native, step_eager, fwd_bytes, grad_bytes, n_timed):
+        with torch.no_grad():
+            f_ms = gpu_time_ms(fwd, n_timed)
+        s_ms = gpu_time_ms(step_native, n_timed)
+        by = 2 * fwd_bytes + grad_bytes
+        row = {"pairs": B, "forward_us": 1e3 * f_ms, "step_us": 1e3 * s_ms, "backward_over_forward": (s_ms - f_ms) / f_ms,
+               "algorithmic_bytes": by,
+               "roofline": {"bound": "hbm", "achieved": by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        try:
+            e_ms = gpu_time_ms(step_eager, max(3, n_timed // 2), warm_ms=20.0, timed_ms=15.0, max_calls=50)
+            row["eager_gpu_baseline"] = {"step_us": 1e3 * e_ms, "kind": "port",
+                                         "what": "oracle/torch_port.py statements + torch autograd on this GPU",
+                                         "native_speedup": e_ms / s_ms}
+        except Exception as e:      # (an out-of-memory eager step at 2,048 TKL documents is a result, not a failure)
+            row["eager_gpu_baseline"] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+        res.setdefault(name, {})[f"pairs_{B}"] = row
+
+    for B in (64, 2048):
+        # ---- ColBERT: fp16 token vectors as the compressor emits them under autocast, int64 HF masks
+        g = torch.Generator(device=dev).manual_seed(64 + B)
+        q = torch.nn.functional.normalize(torch.randn(B, Q, E, generator=g, device=dev), dim=-1).half().requires_grad_(True)
+        d = torch.nn.functional.normalize(torch.randn(B, D, E, generator=g, device=dev), dim=-1).half().requires_grad_(True)
+        qm = synth.len_to_mask(torch.randint(4, Q + 1, (B,), generator=g, device=dev), Q)
+        dm = synth.len_to_mask(synth.msmarco_doc_lengths(B, D, g, dev), D)
+        go = torch.randn(B, generator=g, device=dev)
+
+        def c_fwd():
+            with torch.autocast("cuda", dtype=torch.float16):
+                return ColBERT._score(q, d, qm, dm)
+
+        def c_native():
+            q.grad = d.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                ColBERT._score(q, d, qm, dm).backward(go)
+
+        def c_eager():
+            q.grad = d.grad = None
+            with torch.autocast("cuda", dtype=torch.float16):
+                TP.maxsim_forward(q, d, qm, dm).backward(go)
+        leg("colbert_fp16_autocast_q32_d180_e128", B, c_fwd, c_native, c_eager, B * ((D + Q) * E * 2 + 8 * (D + Q) + 4),
+            B * (D + Q) * E * 4, steps)
+        del q, d
+
+        # ---- TK pooling (tk.yaml: fp32, Q = 20 / D = 200 / dim = 300)
+        Qt, Dt, Et = 20, 200, 300
+        tq = torch.randn(B, Qt, Et, generator=g, device=dev).requires_grad_(True)
+        td = torch.randn(B, Dt, Et, generator=g, device=dev).requires_grad_(True)
+        tqm = synth.len_to_mask(torch.randint(3, Qt + 1, (B,), generator=g, device=dev), Qt, torch.float32)
+        tdm = synth.len_to_mask(torch.randint(10, Dt + 1, (B,), generator=g, device=dev), Dt, torch.float32)
+        mu, sg = torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev)
+        al = torch.ones(11, device=dev, requires_grad=True)
+        w = torch.linspace(-0.014, 0.014, 11, device=dev).requires_grad_(True)
+        leaves = (tq, td, al, w)
+
+        def zero():
+            for t in leaves:
+                t.grad = None
+
+        def t_fwd():
+            return ops.kernel_pool(tq, td, tqm, tdm, mu, sg, al, w)
+
+        def t_native():
+            zero()
+            _KernelPoolFn.apply(tq, td, tqm, tdm, mu, sg, al, w).backward(go)
+
+        def t_eager():
+            zero()
+            TP.tk_kernel_pool(tq, td, tqm, tdm, mu.view(1, 1, 1, -1), sg.view(1, 1, 1, -1), al.view(1, 1, -1), w.view(1, -1)).backward(go)
+        leg("tk_pooling_q20_d200_e300", B, t_fwd, t_native, t_eager, B * ((Dt + Qt) * Et * 4 + 4 * (Dt + Qt) + 4),
+            B * (Dt + Qt) * Et * 4 + 2 * B * 11 * 4, steps)
+        del tq, td
+        torch.cuda.empty_cache()
+
+    # ---- TKL scoring (tkl.yaml: fp32, D = 2048, dim = 300, Q = 20): documents are the unit
+    Qt, Dt, Et = 20, 2048, 300
+    m = TKL_sigir20(Et, MU, [0.1] * 11, 10, 2, 300, 2000, True, True, "embedding").to(dev)
+    for B in (64, 2048):
+        g = torch.Generator(device=dev).manual_seed(640 + B)
+        d_len = torch.randint(50, Dt + 1, (B,), generator=g, device=dev)
+        q_len = torch.randint(3, Qt + 1, (B,), generator=g, device=dev)
+        qm = synth.len_to_mask(q_len, Qt, torch.float32)
+        dm = synth.len_to_mask(d_len, Dt, torch.float32)
+        dd = torch.randn(B, Dt, Et, generator=g, device=dev) * dm.unsqueeze(-1)
+        chunks, cmask, slot, C = chunk_documents(dd, dm)
+        del dd
+        chunks = chunks.requires_grad_(True)
+        q_ctx = (torch.randn(B, Qt, Et, generator=g, device=dev) * qm.unsqueeze(-1)).requires_grad_(True)
+        go = torch.randn(B, generator=g, device=dev)
+        scoring, sizes = m._pack_layout()
+        packed = m.pack_params()
+        P = chunks.shape[0]
+
+        def zero():
+            q_ctx.grad = chunks.grad = None
+            for t in scoring:
+                t.grad = None
+
+        def l_fwd():
+            return ops.tkl_score(q_ctx, chunks, cmask, slot, qm, packed, B, C, 11, "embedding", check_order=False)
+
+        def l_native():
+            zero()
+            _TKLScoreFn.apply(q_ctx, chunks, cmask, slot, qm, (B, C, 11, "embedding", packed, sizes), *scoring)[0].backward(go)
+
+        prm = {"mu": m.mu, "sigma": m.sigma, "dense_w": m.dense.weight, "sat_w1": m.saturation_linear.weight,
+               "sat_b1": m.saturation_linear.bias, "sat_w2": m.saturation_linear2.weight, "sat_b2": m.saturation_linear2.bias,
+               "sat_w3": m.saturation_linear3.weight, "sat_b3": m.saturation_linear3.bias, "ln_w": m.sat_normer.weight,
+               "ln_b": m.sat_normer.bias, "emb_reduce_w": m.sat_emb_reduce1.weight, "kernel_mult0": m.kernel_mult[0],
+               "chunk_scoring": m.chunk_scoring}
+        prm = {k: v.reshape(-1) for k, v in prm.items()}
+        packed_idx = torch.zeros(B * C, dtype=torch.bool, device=dev)
+        packed_idx[slot.long()] = True
+        cm40 = cmask[:, 5:-5].float().contiguous()
+
+        def l_eager():
+            zero()
+            TP.tkl_scoring(q_ctx, chunks[:, 5:-5], cm40, packed_idx, B, qm, prm, "embedding")[0].backward(go)
+        fwd_bytes = P * 50 * Et * 4 + B * Qt * Et * 4 + P * 50 * 4 + 4 * B
+        # the exact gradient touches at most 15 windows x 30 positions per document; grad_chunks is a full zero-filled tensor
+        leg("tkl_scoring_d2048_e300", B, l_fwd, l_native, l_eager, fwd_bytes, P * 50 * Et * 4 + B * Qt * Et * 4, max(3, steps // 2))
+        del chunks, q_ctx
+        torch.cuda.empty_cache()
+    res["note"] = ("step = forward + backward of the scoring block alone (encoders / contextualisers are PyTorch on both sides and "
+                   "not part of it); TKL's backward recomputes only the <= 15 windows per document that carry gradient")
+    res["profile"] = "profiles/r04_train_step_trace.json"
+    return res
+
+
+def extra_ragged_aggregate(steps, cpu_budget):
+    """SURVEY.md §8 f-3, the ColBERT retrieval aggregate (dense_retrieval.py:398-412): candidates gathered from the resident
+    token store (token_reps_N.npy rows, MSMARCO-length passages, fp16, dim 128) and scored by ONE mm_maxsim_ragged_fwd
+    launch under the searcher head's autocast (sim_round) — against the reference's structure, one
+    forward_aggregation call per candidate (here through the drop-in's own method, i.e. already on the native kernel)."""
+    import torch
+    from matchmaker_amd import ops, synth
+    from matchmaker_amd.colbert import ColBERT
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(3131)
+    n_docs, nq, C = 2_000_000, 64, CANDS
+    lens = synth.msmarco_doc_lengths(n_docs, D, g, dev).long()
+    end = torch.cumsum(lens, 0)
+    begin = end - lens
+    T = int(end[-1])
+    tokens = torch.empty((T, E), dtype=torch.float16, device=dev)
+    for s0 in range(0, T, 1 << 24):
+        n = min(1 << 24, T - s0)
+        tokens[s0:s0 + n] = torch.nn.functional.normalize(torch.randn(n, E, generator=g, device=dev), dim=-1).half()
+    q = torch.nn.functional.normalize(torch.randn(nq, Q, E, generator=g, device=dev), dim=-1).half()
+    cand = torch.randint(0, n_docs, (nq, C), generator=g, device=dev)
+    bb, ee = begin[cand].reshape(-1).contiguous(), end[cand].reshape(-1).contiguous()
+    fn = lambda: ops.maxsim_ragged(q, tokens, bb, ee, None, pairs_per_query=C, check_ranges=False, sim_round=True)
+    ms = gpu_time_ms(fn, steps)
+    by = int((ee - bb).sum()) * E * 2 + nq * Q * E * 2 + 16 * nq * C + 4 * nq * C
+    one = lambda: ops.maxsim_ragged(q[:1], tokens, bb[:C], ee[:C], None, pairs_per_query=C, check_ranges=False, sim_round=True)
+    ms1 = gpu_time_ms(one, steps)
+    out = {"workload": f"{nq} queries x {C} candidates per launch gathered from a resident store of {n_docs} passages "
+                       f"({T} token rows, {T * E * 2 / 1e9:.1f} GB fp16, lengths N(70, 25) clipped to [8, {D}]), Q={Q}/dim={E}",
+           "dtype": "f16 (fp16 maxima, fp32 sums: the searcher head's autocast)", "ms": ms, "pairs_per_s": nq * C / (ms * 1e-3),
+           "algorithmic_bytes": by,
+           "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "one_query_1000_candidates_us": 1e3 * ms1,
+           "kernel": "maxsim_stream_kernel<RAG> (CSR ranges into the store, no gather, no padding)",
+           "profile": "profiles/r04_ragged_aggregate_trace.json"}
+    if not LEAN:
+        # the reference's loop: one forward_aggregation per candidate (dense_retrieval.py:400-410), 1000 calls for one query
+        m = ColBERT.__new__(ColBERT)
+        torch.nn.Module.__init__(m)
+        b0, e0 = bb[:C].tolist(), ee[:C].tolist()
+
+        def loop():
+            with torch.autocast("cuda", dtype=torch.float16):
+                for a, b in zip(b0, e0):
+                    m.forward_aggregation(q[:1], tokens[a:b].unsqueeze(0))
+        with torch.no_grad():
+            loop()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop()
+            torch.cuda.synchronize()
+            t_loop = time.perf_counter() - t0
+        out["per_candidate_loop"] = {"us_per_query_of_1000_candidates": 1e6 * t_loop,
+                                     "what": "1000 forward_aggregation calls (colbert.py:100-112 via the drop-in), wall clock",
+                                     "one_launch_speedup": 1e6 * t_loop / (1e3 * ms1)}
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        n = 200
+        qc = q[:1].float().cpu()
+        docs = [tokens[int(bb[i]):int(ee[i])].float().cpu().unsqueeze(0) for i in range(n)]
+
+        def run():
+            with torch.no_grad():
+                for dv in docs:
+                    TP.maxsim_aggregation(qc, dv)
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: run, cpu_budget, n)
+        out["cpu_baseline"] = {"value": ra, "unit": "pairs/s", "cores": threads, "kind": "port", "single_thread_value": r1,
+                               "sample": f"{n} candidates of one query per call, one oracle/torch_port.maxsim_aggregation call per "
+                                         f"candidate as dense_retrieval.py:400-410 loops, {na} calls in {ta:.1f} s"}
+    del tokens
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_variants(steps, cpu_budget):
+    """the kernel-pooling variants at the shapes their configs give them (max_query_length 30 /
+    max_doc_length 200, defaults.yaml:126-127; 11 kernels), 64 queries x 1000 candidates each, on the pooling kernels:
+    KNRM (300-d embeddings), Conv-KNRM (3 n-gram widths -> 9 match matrices of 128-d vectors in ONE launch), TK-Sparse
+    (TK + the stop-word gate) and IDCM's passage sampler (64-token passages, floor 1e-4 + bias; "ck" 768-d, "ck-small" 128-d)."""
+    import torch
+    from matchmaker_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nq, C = 64, 1000
+    B = nq * C
+    g = torch.Generator(device=dev).manual_seed(9090)
+    prm = [torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev), torch.ones(11, device=dev),
+           torch.linspace(-0.014, 0.014, 11, device=dev)]
+    res = {}
+
+    def one(name, Qv, Dv, Ev, n_d=1, gate=False, clamp=1e-10, n_q=1, ref=""):
+        q = [torch.randn(nq if n_q == 1 and n_d == 1 else B, Qv, Ev, generator=g, device=dev) for _ in range(n_q)]
+        d = [torch.randn(B, Dv, Ev, generator=g, device=dev) for _ in range(n_d)]
+        q_len = torch.randint(3, Qv + 1, (q[0].shape[0],), generator=g, device=dev).to(torch.int32)
+        d_len = torch.randint(max(8, Dv // 4), Dv + 1, (B,), generator=g, device=dev).to(torch.int32)
+        if n_d > 1:
+            w9 = torch.linspace(-0.014, 0.014, 11 * n_q * n_d, device=dev)
+            fn = lambda: ops.kernel_pool_multi(q, d, q_len, d_len, prm[0], prm[1], prm[2], w9)
+        else:
+            gt = torch.relu(torch.randn(B, Dv, generator=g, device=dev)) if gate else None
+            fn = lambda: ops.kernel_pool(q[0], d[0], q_len, d_len, *prm, pairs_per_query=C, d_gate=gt, clamp_min=clamp)
+        ms = gpu_time_ms(fn, steps)
+        rows = int(((d_len + 31) // 32 * 32).clamp(max=Dv).sum())
+        by = n_d * B * Dv * Ev * 4 + sum(t.numel() for t in q) * 4 + 4 * (B + q[0].shape[0]) + 4 * B + (B * Dv * 4 if gate else 0)
+        res[name] = {"shape_QDE": [Qv, Dv, Ev], "pairs": B, "match_matrices_per_pair": n_q * n_d, "ms": ms,
+                     "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes_padded": by,
+                     "bytes_of_rows_below_the_document_lengths": n_d * rows * Ev * 4,
+                     "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, "reference": ref}
+        del q, d
+        torch.cuda.empty_cache()
+
+    one("knrm", 30, 200, 300, ref="models/knrm.py:52-84 (alpha = 1, x 0.01 folded into the weights)")
+    one("conv_knrm_3x3", 30, 200, 128, n_d=3, n_q=3, ref="models/conv_knrm.py:144-170: n_grams^2 = 9 poolings + dense, one launch (pair-per-row)")
+    one("tk_sparse", 30, 200, 300, gate=True, ref="published/cikm20_tk_sparse.py:106-146 (stop-word gate)")
+    one("idcm_sampler_ck", 30, 64, 768, clamp=1e-4, ref="published/sigir21_idcm.py:182-186, sample_context ck (768-d)")
+    one("idcm_sampler_ck_small", 30, 64, 128, clamp=1e-4, ref="published/sigir21_idcm.py:182-186, sample_context ck-small (128-d)")
+    if cpu_budget > 0:
+        from oracle import torch_port as TP
+        n = 200
+        qc, dc = torch.randn(n, 30, 300), torch.randn(n, 200, 300)
+        qm, dm = torch.ones(n, 30), torch.ones(n, 200)
+        mu, sg = prm[0].cpu().view(1, 1, 1, -1), prm[1].cpu().view(1, 1, 1, -1)
+
+        def run():
+            with torch.no_grad():
+                TP.tk_kernel_pool(qc, dc, qm, dm, mu, sg, prm[2].cpu().view(1, 1, -1), prm[3].cpu().view(1, -1))
+        (ra, na, ta), (r1, n1, t1), threads = both_thread_settings(lambda: run, cpu_budget, n)
+        res["cpu_baseline"] = {"value": ra, "unit": "pairs/s", "cores": threads, "kind": "port", "single_thread_value": r1,
+                               "sample": f"KNRM / TK-Sparse shape (Q30 / D200 / 300-d): {n}-pair calls of oracle/torch_port.tk_kernel_pool "
+                                         f"(the variants differ from it in constants only), {na} calls in {ta:.1f} s"}
+    res["profile"] = "profiles/r04_variants_trace.json"
+    return res
+
+
 LEGS = (("eval_batch", extra_eval_batch), ("maxsim_fp32", extra_maxsim_fp32), ("published_checkpoint", extra_published_checkpoint),
-        ("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("dot_topk", extra_dot_topk))
+        ("all_pairs", extra_all_pairs), ("tk", extra_tk), ("tkl", extra_tkl), ("train_step", extra_train_step),
+        ("ragged_aggregate", extra_ragged_aggregate), ("variants", extra_variants), ("dot_topk", extra_dot_topk))
+
+
+def init_dist(args, dev, world, rank, backend):
+    import torch.distributed as dist
+    # the GPU boxes export NCCL_DEBUG=VERSION and RCCL prints to STDOUT (its banner would follow the JSON line, once
+    # per rank; WARN is noisier still): no RCCL logging unless MM_NCCL_DEBUG asks for it — the version is reported
+    # in the line itself
+    os.environ.pop("NCCL_DEBUG", None)
+    if os.environ.get("MM_NCCL_DEBUG"):
+        os.environ["NCCL_DEBUG"] = os.environ["MM_NCCL_DEBUG"]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    kw = {"device_id": dev} if dev.type == "cuda" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+
+
+def nccl_version(backend):
+    import torch
+    if backend != "nccl":
+        return None
+    try:
+        return ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        return "unknown"
+
+
+def sharded_dot_topk(args, dev, world, rank, backend):
+    """BASELINE.json configs[4] as the 8-GPU job runs it: the collection row-sharded over the ranks (sharding.shard_range),
+    every rank searches ITS shard for all queries (mm_dot_topk_fwd), two RCCL all-gathers of the [nq, 1000] (score, id) lists and
+    the native merge (retrieval.FlatIPIndexer.search_device = faiss_indices.py:62-66 `co.shard` + :29-36).  With one rank and
+    --force-dist the collectives and the merge still run (rehearsal on a single-GPU box)."""
+    import torch
+    import torch.distributed as dist
+    from matchmaker_amd.retrieval import FlatIPIndexer
+    from matchmaker_amd.sharding import shard_range
+    init_dist(args, dev, world, rank, backend)
+    Ed, nq, k = 768, 6980, 1000
+    lo, hi = shard_range(args.dot_passages, max(world, 8) if world == 1 else world, rank)     # one rank alone: an eighth
+    n_local = hi - lo
+    g = torch.Generator(device=dev).manual_seed(5005 + rank)
+    c = torch.empty((n_local, Ed), dtype=torch.float16, device=dev)
+    for s0 in range(0, n_local, 1 << 18):
+        n = min(1 << 18, n_local - s0)
+        c[s0:s0 + n] = torch.randn(n, Ed, generator=g, device=dev).half()
+    gq = torch.Generator(device=dev).manual_seed(5005)                # the same queries on every rank
+    q = torch.randn(nq, Ed, generator=gq, device=dev).half()
+    ix = FlatIPIndexer({"token_dim": Ed, "token_dtype": "float16"}, device=dev, merge_single_rank=True)
+    ix.index_resident(torch.arange(lo, hi, device=dev), c)
+    s, ids = ix.search_device(q, k)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    steps = max(2, min(args.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s, ids = ix.search_device(q, k)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    tt = torch.tensor([t], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t = float(tt.item())
+    # every rank ends with the same merged lists; the local shard's own top-1 must appear in them with its global id
+    from matchmaker_amd import ops
+    ls, li = ops.dot_topk(q[:64], c, 1)
+    ok = bool((ids[:64] == (li[:, :1] + lo)).any(dim=1).logical_or(s[:64, -1] > ls[:, 0]).all()) and \
+        bool((s[:, :-1] >= s[:, 1:]).all())
+    n_tot = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    dist.all_reduce(n_tot)
+    if rank == 0:
+        flop = 2.0 * nq * float(n_tot.item()) * Ed
+        print(json.dumps({"only": "dot_topk", "sharded": True, "result": {
+            "workload": f"configs[4]: {int(n_tot.item())} passages x dim {Ed} fp16 row-sharded over {world} rank(s) "
+                        f"({n_local} on rank 0), {nq} queries, exact top-{k}; FlatIPIndexer.search_device = local mm_dot_topk_fwd + "
+                        f"2 all-gathers of [nq, {k}] (score, id) + mm_topk_merge",
+            "world_size": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "version": nccl_version(backend),
+            "ms": 1e3 * t, "queries_per_s": nq / t, "flop": flop,
+            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12 / world, "peak": MFMA_PEAK_16BIT / 1e12,
+                         "unit": "TFLOP/s per GPU", "frac": flop / t / MFMA_PEAK_16BIT / world},
+            "merged_lists_sorted_and_contain_the_local_top1": ok}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------- main
@@ -708,12 +1166,20 @@ def main():
                          "RCCL path on a single-GPU box)")
     ap.add_argument("--only", default=None,
                     choices=["headline", "dropin_forward", "published_checkpoint", "all_pairs", "tk", "tkl", "dot_topk",
-                             "maxsim_fp32", "eval_batch"],
+                             "maxsim_fp32", "eval_batch", "train_step", "ragged_aggregate", "variants"],
                     help="run ONE leg and print it alone (the command that is put under rocprofv3 --kernel-trace)")
     ap.add_argument("--lean", action="store_true",
                     help="with --only: the leg's main measurement alone (no sub-legs, no child processes): what gets profiled")
     ap.add_argument("--one-device", action="store_true",
                     help="every rank uses device 0 (RCCL test of the N > 1 path on a single-GPU box; RCCL may refuse it)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE.json configs[3]: 6,980 queries x 1000 candidates split over 8 ranks with sharding.shard_range "
+                         "(873 / 872 queries per rank), scored + gathered by the PADDED all-gather of sharding.all_gather_scores, "
+                         "final stable sort timed separately.  Default when --gpus 8; with fewer ranks every rank still holds an "
+                         "eighth of the 6,980 (the total shrinks: weak scaling)")
+    ap.add_argument("--total-queries", type=int, default=6980, help="--config4: queries of the whole 8-rank job (tests shrink it)")
+    ap.add_argument("--dot-passages", type=int, default=8841823, help="--only dot_topk with a process group: passages of the WHOLE "
+                                                                       "collection (each rank indexes its shard_range slice)")
     ap.add_argument("--dry", action="store_true",
                     help="launch + collective plumbing only (fabricated scores, value = null); for GPU-less machines")
     args = ap.parse_args()
@@ -742,6 +1208,9 @@ def main():
         torch.cuda.set_device(dev)
     else:
         dev = torch.device("cpu")
+    if args.only == "dot_topk" and (world > 1 or args.force_dist):
+        sharded_dot_topk(args, dev, world, rank, backend)
+        return
     if args.only and args.only != "headline":
         assert world == 1 and dev.type == "cuda", "--only legs are single-GPU measurements"
         from matchmaker_amd import _lib
@@ -758,19 +1227,18 @@ def main():
         return
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        # the GPU boxes export NCCL_DEBUG=VERSION and RCCL prints to STDOUT (its banner would follow the JSON line, once
-        # per rank; WARN is noisier still): no RCCL logging unless MM_NCCL_DEBUG asks for it — the version is reported
-        # in the line itself
-        os.environ.pop("NCCL_DEBUG", None)
-        if os.environ.get("MM_NCCL_DEBUG"):
-            os.environ["NCCL_DEBUG"] = os.environ["MM_NCCL_DEBUG"]
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(free_port()))
-        kw = {"device_id": dev} if dev.type == "cuda" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        init_dist(args, dev, world, rank, backend)
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
 
+    # configs[3] (6,980 queries over 8 ranks) is what an 8-GPU launch runs unless --queries says otherwise
+    config4 = (args.config4 or (world == 8 and "--queries" not in sys.argv)) and not args.dry
     nq = args.queries if not args.dry else min(args.queries, 2)
+    n_total_q = None
+    if config4:
+        from matchmaker_amd.sharding import shard_range
+        lo, hi = shard_range(args.total_queries, 8, rank % 8)
+        nq = hi - lo
+        n_total_q = sum(shard_range(args.total_queries, 8, r)[1] - shard_range(args.total_queries, 8, r)[0] for r in range(world))
     B = nq * CANDS
     if args.dry:
         score_shard = lambda: torch.arange(B, dtype=torch.float32, device=dev) + rank * B     # rank-tagged, checkable
@@ -780,16 +1248,35 @@ def main():
         q, d, q_len, d_len = synth.colbert_batch(nq, CANDS, Q, D, E, torch.bfloat16, dev, seed=4004 + rank,
                                                  lengths=args.lengths)
         score_shard = lambda: ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
-    gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if use_dist else None
+    gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if use_dist and not config4 else None
+    if config4:
+        from matchmaker_amd.sharding import all_gather_scores, rank_candidates
+
+    def merge(s):
+        """the ranking merge: RCCL over xGMI.  config 4: unequal shards (873 / 872 queries) -> the padded all-gather of
+        sharding.all_gather_scores, [n_total, 1000] on every rank; otherwise equal shards, one raw all_gather_into_tensor"""
+        if config4:
+            return all_gather_scores(s.view(nq, CANDS), n_total_q, force=use_dist)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, s)
+        return gathered
 
     def step():
         s = score_shard()
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, s)     # RCCL over xGMI: the ranking merge
+        if use_dist or config4:
+            merge(s)
         return s
 
     for _ in range(args.warmup):
         step()
+    # steady state before the K timed steps: ~40 ms of untimed launches (the first ten launches after an idle period run
+    # ~10 % slow on the clock ramp; the legs have been timed this way since round 3, gpu_time_ms)
+    if dev.type == "cuda" and not args.dry:
+        a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(); step(); b0.record()
+        sync()
+        for _ in range(min(200, int(40.0 / max(a0.elapsed_time(b0), 1e-3)))):
+            step()
 
     def barrier():
         sync()
@@ -808,14 +1295,27 @@ def main():
         s = score_shard()
         if use_ev:
             ev[i][1].record()
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, s)
+        if use_dist or config4:
+            all_scores = merge(s)
     barrier()
     t = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev) if use_ev else None
 
     gather_matches = None
-    if use_dist and not args.dry:      # the gathered tensor's slice of this rank must BE its local scores
+    sort_info = None
+    if config4:
+        # this rank's rows of the gathered matrix must BE its local scores; the final ranking (core_metrics.py:502-511:
+        # stable descending sort per query) is timed on its own, and a sampled query's ranking must equal the ranking of
+        # its local scores alone (what a single rank would have produced)
+        row0 = sum(shard_range(args.total_queries, 8, r)[1] - shard_range(args.total_queries, 8, r)[0] for r in range(rank))
+        gather_matches = bool(torch.equal(all_scores[row0:row0 + nq].reshape(-1), s))
+        sort_ms = gpu_time_ms(lambda: rank_candidates(all_scores), 3, warm_ms=10.0, timed_ms=10.0)
+        order = rank_candidates(all_scores)
+        qs = nq // 2
+        same = bool(torch.equal(order[row0 + qs], rank_candidates(s.view(nq, CANDS)[qs:qs + 1])[0]))
+        sort_info = {"ms": sort_ms, "rows": int(all_scores.shape[0]), "what": "torch.sort(stable, descending) of the gathered "
+                     "[n_total, 1000] scores, outside the timed steps", "ranking_equals_single_rank": same}
+    elif use_dist and not args.dry:      # the gathered tensor's slice of this rank must BE its local scores
         gather_matches = bool(torch.equal(gathered[rank * B:(rank + 1) * B], s))
     tt = torch.tensor([t], dtype=torch.float64, device=dev)
     if use_dist:
@@ -827,29 +1327,30 @@ def main():
         gather_ok = bool(torch.equal(gathered, want))
 
     if rank == 0:
-        total_pairs = world * B * args.steps
+        total_pairs = (n_total_q * CANDS if config4 else world * B) * args.steps
         coll = None
         if use_dist:
-            ver = None
-            if backend == "nccl":
-                try:
-                    ver = ".".join(str(x) for x in torch.cuda.nccl.version())
-                except Exception:
-                    ver = "unknown"
-            coll = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "version": ver, "world_size": world,
-                    "op": "all_gather_into_tensor of fp32 scores, once per step, inside the timed region",
-                    "bytes_per_rank": 4 * B, "bytes_total": 4 * B * world,
+            coll = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "version": nccl_version(backend), "world_size": world,
+                    "op": ("sharding.all_gather_scores: shards padded to ceil(n_total / world) rows, ONE all_gather_into_tensor, rows "
+                           "re-assembled; once per step, inside the timed region" if config4 else
+                           "all_gather_into_tensor of fp32 scores, once per step, inside the timed region"),
+                    "bytes_per_rank": 4 * B, "bytes_total": 4 * (n_total_q * CANDS if config4 else B * world),
                     "gathered_slice_equals_local_scores": gather_matches,
                     "devices": "all ranks on device 0 (--one-device)" if args.one_device else "one device per rank"}
+            if sort_info:
+                coll["final_sort"] = sort_info
         out = {
             "metric": "query-doc pairs scored/sec (ColBERT MaxSim, Q32/D180/dim128)",
             "value": None if args.dry else total_pairs / t, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * t / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "world_size": world, "collective": coll,
-            "config": {"workload": f"BASELINE.json configs[1]: ColBERT MaxSim re-rank, dim=128, Q=32/D=180, "
-                                   f"1000 candidates/query, bf16; {nq} queries x 1000 candidates resident per GPU "
-                                   f"per step; doc lengths = {args.lengths}",
+            "config": {"workload": (f"BASELINE.json configs[3]: ColBERT MaxSim, {args.total_queries}-query batch x 1000 candidates "
+                                    f"sharded over 8 ranks ({n_total_q} queries on the {world} rank(s) of this job, {nq} on rank 0), "
+                                    f"dim=128, Q=32/D=180, bf16, RCCL score all-gather; doc lengths = {args.lengths}" if config4 else
+                                    f"BASELINE.json configs[1]: ColBERT MaxSim re-rank, dim=128, Q=32/D=180, "
+                                    f"1000 candidates/query, bf16; {nq} queries x 1000 candidates resident per GPU "
+                                    f"per step; doc lengths = {args.lengths}"),
                        "queries_per_gpu": nq, "cands_per_query": CANDS, "Q": Q, "D": D, "E": E,
                        "parallelism": f"query-sharded x{world}" + (f", {backend} all-gather of scores" if world > 1 else "")},
         }
@@ -894,13 +1395,22 @@ def main():
             if busy is not None:
                 out["roofline"]["mfma_util"]["pmc_busy_frac"] = busy[0]
                 out["roofline"]["mfma_util"]["pmc_source"] = f"profiles/{busy[1]} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), tools/summarize_rocprof.py)"
+            out["timing"] = ("W warm-up steps, then ~40 ms of untimed steps (steady-state clocks), then the K timed steps between "
+                             "barrier + synchronize pairs; kernel_ms = mean HIP-event time of the K scoring launches")
             if world == 1:      # CPU leg and extras are N = 1 figures; ranks > 0 would idle through them
+                try:            # what this box's memory system gives the same access pattern, in the same process
+                    cal = extra_hbm_calibration(d, 10, achieved)
+                    out["roofline"]["frac_of_calibrated"] = cal["headline_over_read_stream"]
+                    out["roofline"]["calibrated_stream_GBps"] = cal["lds_dma_read_stream_nt"]["GBps"]
+                    out.setdefault("extra", {})["hbm_calibration"] = cal
+                except Exception as e:
+                    out.setdefault("extra", {})["hbm_calibration"] = {"error": repr(e)}
                 if not args.no_cpu_baseline:
                     nsamp = min(nq, 24)
                     out["cpu_baseline"] = cpu_baseline(q[:nsamp].cpu(), d[:nsamp * CANDS].cpu(), q_len[:nsamp].cpu(),
                                                        d_len[:nsamp * CANDS].cpu(), CANDS)
                 if not args.no_extras:
-                    extra = {}
+                    extra = out.setdefault("extra", {})
                     cpu_b = 0.0 if args.no_cpu_baseline else 3.0
                     try:
                         extra["sustained"] = extra_sustained(score_shard, B)

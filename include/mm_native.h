@@ -128,6 +128,13 @@ int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int64_t* doc_b
                          int64_t n_pairs, int64_t pairs_per_query, int Q, int E, int dtype, int flags,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Calibration, not scoring: mm_maxsim_fwd's HBM read stream with the arithmetic removed (same launch geometry, LDS-DMA
+ * blocks, ring and counted waits; no MFMA, no maximum) over `bytes` of `src` (16-byte aligned, a multiple of 8192 bytes).
+ * bench.py times it over the headline's document tensor and prints the headline kernel's rate as a fraction of it, so
+ * that a slow box and a slow kernel can be told apart from the benchmark line alone.  nt != 0: non-temporal loads, as
+ * the headline kernel issues them. */
+int mm_hbm_stream_probe(const void* src, int64_t bytes, int nt, void* stream);
+
 /* Backward of the paired MaxSim (pair-per-row layout, the one train.py uses: train.py:347-348,
  * loss.backward() :503-524).  Recomputes the similarities and routes grad_out[p] to the FIRST
  * arg-max document position of every real query token (torch.max's rule); nothing flows through

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mm_maxsim_inbatch_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_maxsim_ragged_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
     "mm_maxsim_ragged_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_hbm_stream_probe": (_i, [_vp, _i64, _i, _vp]),
     "mm_maxsim_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
     "mm_maxsim_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),

@@ -468,7 +468,8 @@ __global__ void __launch_bounds__(256, 2) maxsim_allpairs_wg_kernel(const Maxsim
             wait_vm(2 * (inflight - 1));
           }
           // ... and so have the others'; everyone is also done with the slab before it, whose slot is refilled now
-          asm volatile("s_barrier" ::: "memory");
+          // (lgkmcnt(0): this wavefront's own fragment reads of that slab have RETURNED before anyone's DMA may overwrite it)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           top_up();
           const char* buf = smem + cbuf * kBlkBytes;
 #pragma unroll
@@ -707,6 +708,46 @@ __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Calibration: maxsim_stream_kernel's HBM read stream with the arithmetic taken out — the same launch geometry (one
+// wavefront per workgroup, 4 per CU), the same 8-instruction LDS-DMA blocks into a 2-slot ring, the same counted waits;
+// no fragment reads, no MFMA, no maximum.  What this box's memory system gives THIS access pattern: bench.py prints the
+// headline kernel's rate as a fraction of it (a slow box and a slow kernel look different in that ratio).
+// ---------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ void __launch_bounds__(64) hbm_stream_probe_kernel(const char* src, int64_t n_blocks, int64_t blocks_per_wave,
+                                                              uint32_t* sink) {
+  constexpr int NBUF = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * blocks_per_wave;
+  const int64_t b1 = (b0 + blocks_per_wave < n_blocks) ? b0 + blocks_per_wave : n_blocks;
+  if (b0 >= b1) return;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t voff[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = 4 * k + (lane >> 4);
+    voff[k] = (uint32_t)(row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+  }
+  int64_t pb = b0;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  uint32_t acc = 0;
+  for (int64_t b = b0; b < b1; ++b) {
+    while (pb < b1 && inflight < NBUF) {
+      issue_block<NT>(src + pb * kBlkBytes, voff, lds0 + (uint32_t)pbuf * kBlkBytes);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      ++pb;
+    }
+    wait_block(inflight - 1);
+    acc ^= *(const uint32_t*)(smem + cbuf * kBlkBytes + lane * 4);   // one dword per lane: the block did land
+    cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
+    --inflight;
+  }
+  if (sink && acc == 0x9e3779b9u) sink[blockIdx.x] = acc;            // (keeps the read alive; practically never taken)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -994,6 +1035,22 @@ extern "C" int mm_maxsim_ragged_fwd(const void* q, const void* tokens, const int
                          (E == 128 || E == 256 || E == 384 || E == 512 || E == 768);
   if (stream_ok) return dtype == MM_BF16 ? launch_stream_cfg<MM_BF16, true>(a, stream) : launch_stream_cfg<MM_F16, true>(a, stream);
   return launch_generic(a, dtype, stream);
+}
+
+extern "C" int mm_hbm_stream_probe(const void* src, int64_t bytes, int nt, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!src || bytes <= 0 || (bytes % kBlkBytes) || ((uintptr_t)src & 15))
+    return set_error(MM_EINVAL, "hbm_stream_probe: need a 16-byte aligned buffer of a multiple of %d bytes", kBlkBytes);
+  const int64_t n_blocks = bytes / kBlkBytes;
+  int64_t waves = (int64_t)kCUs * 4;
+  if (waves > n_blocks) waves = n_blocks;
+  const int64_t per = (n_blocks + waves - 1) / waves;
+  waves = (n_blocks + per - 1) / per;
+  if (nt)
+    hipLaunchKernelGGL(hbm_stream_probe_kernel<true>, dim3((unsigned)waves), dim3(64), 2 * kBlkBytes, stream, (const char*)src, n_blocks, per, (uint32_t*)nullptr);
+  else
+    hipLaunchKernelGGL(hbm_stream_probe_kernel<false>, dim3((unsigned)waves), dim3(64), 2 * kBlkBytes, stream, (const char*)src, n_blocks, per, (uint32_t*)nullptr);
+  return check_launch("hbm_stream_probe_kernel");
 }
 
 extern "C" size_t mm_maxsim_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind) {

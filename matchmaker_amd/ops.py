@@ -6,6 +6,7 @@ output (+ a small mask-packing workspace from torch's caching allocator), never 
 keeps no state, so it is re-entrant from nn.DataParallel's per-GPU threads
 (matchmaker/train.py:201).  CPU tensors are rejected: there is no CPU fallback.
 """
+import threading
 from typing import Optional
 
 import torch
@@ -91,6 +92,7 @@ def _stream(dev) -> int:
 # next call may reuse the buffer; eval.py-sized calls (512 pairs) are host-bound and a torch.empty per call is ~2 us
 # of their ~15.  Not used under graph capture (a captured graph must not reference a buffer a later call may replace).
 _WS = {}
+_WS_LOCK = threading.Lock()      # nn.DataParallel drives forward() from one Python thread per GPU (train.py:201)
 
 
 def _workspace(dev, nbytes: int, stream: Optional[int] = None):
@@ -101,11 +103,20 @@ def _workspace(dev, nbytes: int, stream: Optional[int] = None):
     key = (dev.index, _stream(dev) if stream is None else stream)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
-        if len(_WS) > 64:
-            _WS.clear()
-        t = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
-        _WS[key] = t
+        with _WS_LOCK:
+            if len(_WS) > 64:
+                _WS.clear()
+            t = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+            _WS[key] = t
     return t
+
+
+def clear_workspaces() -> None:
+    """Drops the cached mask-packing workspaces (one per (device, stream) that ever called a scoring operator, sized for the
+    largest call seen there, at most 64 of them): they are ordinary torch allocations, so torch.cuda.empty_cache() can
+    return their memory afterwards.  Safe at any time — a call in flight holds its own reference."""
+    with _WS_LOCK:
+        _WS.clear()
 
 
 class _NoCtx:
@@ -199,6 +210,17 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
                              ws.data_ptr() if ws is not None else None, wsb, st)
     _lib.check(rc, "mm_maxsim_fwd")
     return out
+
+
+def hbm_stream_probe(t: torch.Tensor, nt: bool = True) -> None:
+    """Calibration launch (mm_hbm_stream_probe): streams tensor `t` through the MaxSim kernel's LDS-DMA ring with the
+    arithmetic removed.  Returns nothing: it exists to be timed (bench.py extra.hbm_calibration)."""
+    dev = _dev_check(t)
+    t = t if t.is_contiguous() else t.contiguous()
+    nbytes = (t.numel() * t.element_size()) // 8192 * 8192
+    with _on(dev):
+        rc = _lib.lib().mm_hbm_stream_probe(t.data_ptr(), nbytes, 1 if nt else 0, _stream(dev))
+    _lib.check(rc, "mm_hbm_stream_probe")
 
 
 def _check_ranges(doc_begin: torch.Tensor, doc_end: torch.Tensor, n_rows: int):
@@ -493,8 +515,14 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
 
 def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor, chunk_slot: torch.Tensor,
               q_mask: torch.Tensor, params: torch.Tensor, B: int, C: int, K: int, saturation: str = "embedding",
-              return_windows: bool = False):
-    """TKL windowed kernel pooling + region top-k (sigir20_tkl.py:180-286).  See mm_native.h."""
+              return_windows: bool = False, check_order: bool = True):
+    """TKL windowed kernel pooling + region top-k (sigir20_tkl.py:180-286).  See mm_native.h.
+
+    chunk_slot must be strictly ASCENDING (what boolean-mask packing / torch.nonzero produce, sigir20_tkl.py:159-162): the
+    kernels rely on a document's chunks being adjacent and on its last kept chunk coming last.  check_order=True verifies
+    that on the device without a host synchronisation (torch._assert_async: a violation raises at the next
+    synchronisation point instead of silently zeroing live windows); callers that built chunk_slot with
+    tkl.chunk_documents() — the drop-in does — pass False and skip the three small launches."""
     dev = _dev_check(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params)
     q_ctx, chunks = _emb(q_ctx, "q_ctx"), _emb(chunks, "chunks")
     if q_ctx.dtype != torch.float32 or chunks.dtype != torch.float32:
@@ -509,6 +537,9 @@ def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tenso
                           "(reads the undefined `query_idfs`, sigir20_tkl.py:214,236)")
     chunk_mask = chunk_mask.to(torch.float32).contiguous()
     chunk_slot = chunk_slot.to(torch.int32).contiguous()
+    if check_order and P > 1 and not torch.cuda.is_current_stream_capturing():
+        torch._assert_async((chunk_slot[1:] > chunk_slot[:-1]).all(),
+                            "tkl_score: chunk_slot must be strictly ascending (include/mm_native.h, mm_tkl_fwd)")
     q_mask = q_mask.to(torch.float32).contiguous()
     params = params.to(torch.float32).contiguous()
     W = (max(C * 40, 30) - 30) // 2 + 1

@@ -22,10 +22,53 @@ def _to_device(x, device):
     return x
 
 
+class _GraphedForward:
+    """One captured `model.forward` per batch shape (HIP graph): eval.py issues thousands of identical 512-pair steps
+    (defaults.yaml:115), each of which costs ~10 us of Python + launches per kernel when issued eagerly — more than the
+    4 us of HBM time a dim-128 ColBERT batch needs.  The tokenizer tensors of a batch are copied straight into the graph's
+    static input buffers (the H2D copy eval.py:89 makes anyway) and the graph is replayed."""
+
+    def __init__(self, model, use_fp16, output_secondary_output, device):
+        self.model, self.use_fp16, self.sec, self.device = model, use_fp16, output_secondary_output, device
+        self.entries = {}
+
+    def _run(self, static):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.use_fp16):
+            out = self.model.forward(static["query_tokens"], static["doc_tokens"],
+                                     output_secondary_output=self.sec, use_fp16=self.use_fp16)
+        return out[0] if self.sec else out
+
+    def __call__(self, batch_orig):
+        parts = {k: batch_orig[k] for k in ("query_tokens", "doc_tokens")}
+        key = tuple((k, n, tuple(t.shape), t.dtype) for k in parts for n, t in sorted(parts[k].items()))
+        entry = self.entries.get(key)
+        if entry is None:
+            static = _to_device(parts, self.device)
+            static = {k: {n: t.clone() for n, t in v.items()} for k, v in static.items()}
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                      # warm-up outside capture (lazy initialisation, workspaces)
+                self._run(static)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._run(static)
+            entry = self.entries[key] = (g, static, out)
+        g, static, out = entry
+        for k, v in parts.items():
+            for n, t in v.items():
+                static[k][n].copy_(t, non_blocking=True)
+        g.replay()
+        return out
+
+
 def evaluate_batches(model, batches: Iterable[dict], use_fp16: bool = True, device=None,
-                     output_secondary_output: bool = False) -> Dict[str, List[Tuple[str, float]]]:
+                     output_secondary_output: bool = False, graph: bool = False) -> Dict[str, List[Tuple[str, float]]]:
     """batches: dicts with "query_tokens", "doc_tokens" (HF tokenizer dicts), "query_id", "doc_id" (lists),
-    the fields eval.py reads.  Returns the unrolled results of eval.py:189-203."""
+    the fields eval.py reads.  Returns the unrolled results of eval.py:189-203.
+    graph=True: every batch shape's forward is captured once in a HIP graph and replayed (_GraphedForward) — for models
+    whose forward is capturable (no host synchronisation, no data-dependent shapes: ColBERT, TK; not TKL, whose chunk
+    packing is data dependent as in the reference)."""
     if device is None:
         import itertools
         t = next(itertools.chain(model.parameters(), model.buffers()), None)
@@ -33,8 +76,14 @@ def evaluate_batches(model, batches: Iterable[dict], use_fp16: bool = True, devi
             raise ValueError("evaluate_batches: the model has no parameters or buffers; pass device=")
         device = t.device
     validation_results: Dict[str, List[Tuple[str, float]]] = {}
+    graphed = _GraphedForward(model, use_fp16, output_secondary_output, torch.device(device)) if graph else None
     with torch.no_grad():
         for batch_orig in batches:
+            if graphed is not None:
+                output = graphed(batch_orig).cpu()                                       # :161 — in one piece
+                for i, qid in enumerate(batch_orig["query_id"]):
+                    validation_results.setdefault(qid, []).append((batch_orig["doc_id"][i], float(output[i])))
+                continue
             with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):          # eval.py:83
                 batch = _to_device({k: batch_orig[k] for k in ("query_tokens", "doc_tokens")}, device)   # :89
                 output = model.forward(batch["query_tokens"], batch["doc_tokens"],

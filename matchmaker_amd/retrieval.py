@@ -27,10 +27,12 @@ def _pad_dim(E: int) -> int:
 
 
 class FlatIPIndexer:
-    def __init__(self, config, device=None, group=None, topk_fn=None, merge_fn=None):
+    def __init__(self, config, device=None, group=None, topk_fn=None, merge_fn=None, merge_single_rank: bool = False):
         """topk_fn(queries, vectors, k) / merge_fn(scores, ids, k) default to the native operators
         (ops.dot_topk / ops.topk_merge); the CPU test-suite injects oracle stand-ins to exercise the
-        sharding logic under gloo."""
+        sharding logic under gloo.  merge_single_rank: run the two all-gathers + the merge of the sharded search even
+        when the process group has ONE rank (rehearsal of the multi-GPU path on a single-GPU box)."""
+        self.merge_single_rank = bool(merge_single_rank)
         self._topk = topk_fn if topk_fn is not None else ops.dot_topk
         self._merge = merge_fn if merge_fn is not None else ops.topk_merge
         self.token_dim = config["token_dim"]
@@ -77,17 +79,34 @@ class FlatIPIndexer:
         self.vectors = vec
         self.ids = torch.from_numpy(i[lo:hi]).to(self.device)
 
+    def index_resident(self, ids: torch.Tensor, vectors: torch.Tensor):
+        """This rank's shard handed over as device tensors (vectors [n_local, E_pad] float16, ids [n_local] int64) — for
+        collections that are produced on the device (bench.py generates each rank's shard of the 8.8 M synthetic passages in
+        place instead of materialising 13.6 GB of host arrays per rank)."""
+        if vectors.dtype != self.dtype or vectors.dim() != 2 or vectors.shape[1] != self.E_pad or ids.shape[0] != vectors.shape[0]:
+            raise ops.NativeError(f"index_resident: need float16 [n, {self.E_pad}] vectors and [n] ids")
+        self.vectors, self.ids = vectors.contiguous(), ids.to(torch.int64).contiguous()
+
     def search(self, query_vec, top_n: int):
         """faiss_indices.py:29-36: (scores [nq, top_n] float32 descending, ids [nq, top_n] int64)."""
+        s, ids = self.search_device(query_vec, top_n)
+        return s.cpu().numpy(), ids.cpu().numpy()
+
+    def search_device(self, query_vec, top_n: int):
+        """search() without the final copy to the host: device tensors (what a caller that keeps working on the GPU wants,
+        and what bench.py times)."""
         q = torch.as_tensor(query_vec)
         if q.dim() == 1:
             q = q[None, :]
-        qd = torch.zeros((q.shape[0], self.E_pad), dtype=self.dtype, device=self.device)
-        qd[:, : self.token_dim] = q.to(self.device).to(self.dtype)
+        if q.is_cuda and q.dtype == self.dtype and q.shape[1] == self.E_pad and q.is_contiguous():
+            qd = q
+        else:
+            qd = torch.zeros((q.shape[0], self.E_pad), dtype=self.dtype, device=self.device)
+            qd[:, : self.token_dim] = q.to(self.device).to(self.dtype)
         s, idx = self._topk(qd, self.vectors, top_n)
         ids = torch.where(idx >= 0, self.ids[idx.clamp(min=0)], idx)
         world, _ = self._world()
-        if world > 1:
+        if world > 1 or (self.merge_single_rank and dist.is_available() and dist.is_initialized()):
             nq = s.shape[0]
             gs = torch.empty((world * nq, top_n), dtype=s.dtype, device=s.device)        # rank-major concatenation
             gi = torch.empty((world * nq, top_n), dtype=ids.dtype, device=ids.device)
@@ -95,4 +114,4 @@ class FlatIPIndexer:
             dist.all_gather_into_tensor(gi, ids.contiguous(), group=self.group)
             s, ids = self._merge(gs.view(world, nq, top_n).permute(1, 0, 2).reshape(nq, -1),
                                  gi.view(world, nq, top_n).permute(1, 0, 2).reshape(nq, -1), top_n)
-        return s.cpu().numpy(), ids.cpu().numpy()
+        return s, ids

@@ -21,11 +21,12 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_scores(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+def all_gather_scores(local: torch.Tensor, n_total: int, group=None, force: bool = False) -> torch.Tensor:
     """local [n_local, C] fp32 from every rank (shard_range split of n_total rows) -> [n_total, C] on
-    every rank.  One all_gather_into_tensor of equally sized (padded) shards."""
+    every rank.  One all_gather_into_tensor of equally sized (padded) shards.  force: run the padded collective even
+    with ONE rank in the group (rehearsal of the multi-GPU path on a single-GPU box)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return local
     C = local.shape[1]
     per = (n_total + world - 1) // world
@@ -47,7 +48,8 @@ def rank_candidates(scores: torch.Tensor, k: Optional[int] = None) -> torch.Tens
 
 
 def rerank_sharded(q: torch.Tensor, d: torch.Tensor, q_mask, d_mask, cands: int,
-                   score_fn: Optional[Callable] = None, group=None, n_total_queries: Optional[int] = None):
+                   score_fn: Optional[Callable] = None, group=None, n_total_queries: Optional[int] = None,
+                   force_collective: bool = False):
     """Each rank passes ITS shard (q [nq_local,Q,E], d [nq_local*cands,D,E], masks alike); returns
     (scores [n_total, cands], ranking [n_total, cands]) on every rank.
 
@@ -61,5 +63,5 @@ def rerank_sharded(q: torch.Tensor, d: torch.Tensor, q_mask, d_mask, cands: int,
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(n, group=group)
         n_total_queries = int(n.item())
-    scores = all_gather_scores(local, n_total_queries, group)
+    scores = all_gather_scores(local, n_total_queries, group, force=force_collective)
     return scores, rank_candidates(scores)

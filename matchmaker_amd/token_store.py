@@ -24,7 +24,7 @@ from . import ops
 
 class TokenStore:
     def __init__(self, tokens: torch.Tensor, seq_ids: Sequence, begin: np.ndarray, end: np.ndarray):
-        self.tokens = tokens                          # [T, E] on the scoring device
+        self._tokens = tokens                         # [T, E] on the scoring device (read-only: the ranges below were validated against it)
         self.seq_ids = list(seq_ids)
         self._index = {s: i for i, s in enumerate(self.seq_ids)}
         self._begin = np.asarray(begin, dtype=np.int64)   # global row ranges per document
@@ -33,6 +33,12 @@ class TokenStore:
         if self._begin.size and (self._begin.min() < 0 or self._end.max() > tokens.shape[0] or (self._begin > self._end).any()):
             raise ops.NativeError(f"TokenStore: document ranges leave the {tokens.shape[0]}-row token matrix "
                                   "(doc_infos of another store?)")
+
+    @property
+    def tokens(self) -> torch.Tensor:
+        """The resident token matrix.  Read-only: aggregate() skips the per-call range check because the document ranges
+        were validated against THIS matrix in the constructor — build a new TokenStore for another matrix."""
+        return self._tokens
 
     # ------------------------------------------------------------------ construction
     @classmethod

@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE — torch (CPU) port of the reference's scoring blocks, op by op.
+"""TEST INFRASTRUCTURE — torch port of the reference's scoring blocks, op by op (device-agnostic: CPU tensors for the
+CPU baselines and the oracle pins; GPU tensors when bench.py / the GPU tests run the reference's statements eagerly ON THE
+GPU — under torch.autocast for the fp16 mode — as the stated eager baseline / reference-arithmetic checker).
 
 The reference IS a sequence of torch ops; this file repeats exactly those ops (same order, same
 in-place masked assignments) on CPU tensors so that
@@ -118,7 +120,7 @@ def tkl_scoring(query_ctx, centre, centre_mask, packed_indices, batch_size, quer
     cos = cosine_matrix(packed_query, centre).unsqueeze(-1)                                                   # :184, :192
     raw = torch.exp(- torch.pow(cos - p["mu"].view(1, 1, 1, -1), 2) / (2 * torch.pow(p["sigma"].view(1, 1, 1, -1), 2)))  # :193
     masked = raw * centre_mask.unsqueeze(1).unsqueeze(-1)                                                     # :194
-    act = torch.zeros((packed_indices.shape[0], Q, centre.shape[1], K), dtype=centre.dtype)                   # :196
+    act = torch.zeros((packed_indices.shape[0], Q, centre.shape[1], K), dtype=centre.dtype, device=centre.device)                   # :196
     act[packed_indices] = masked                                                                              # :197
     act = act.transpose(1, 2).reshape(batch_size, -1, Q, K).transpose(2, 1)                                   # :199
     if act.shape[2] < 30:                                                                                     # :206-207
@@ -141,9 +143,9 @@ def tkl_scoring(query_ctx, centre, centre_mask, packed_indices, batch_size, quer
         score = torch.nn.functional.pad(score, (0, 3 - score.shape[1]))
     score[score == 0] = -9900                                                                                 # :257
     orig = score
-    top = torch.zeros((orig.shape[0], 3), dtype=torch.long)
+    top = torch.zeros((orig.shape[0], 3), dtype=torch.long, device=orig.device)
     work = orig.clone()
-    r = torch.arange(work.shape[1])
+    r = torch.arange(work.shape[1], device=work.device)
     for c in range(3):                                                                                        # :268-273
         best = torch.argmax(work, dim=1)
         top[:, c] = best

@@ -325,3 +325,30 @@ def test_shared_query_candidate_lists_every_pair(Q):
     rep = ops.kernel_pool(t(q.repeat_interleave(C, 0).contiguous()), t(d), t(qm.repeat_interleave(C, 0).contiguous()), t(dm), t(mu), t(sg),
                           t(alpha), t(w), pairs_per_query=1)
     np.testing.assert_allclose(rep.cpu().numpy(), out.cpu().numpy(), rtol=2e-6, atol=2e-5)
+
+
+def test_scores_of_a_pair_do_not_depend_on_the_batch_it_arrives_in_beyond_fp32_rounding():
+    """Calls of <= 512 pairs split every pair's document blocks over TWO wavefronts (eval.py-sized batches) and add the
+    partial document sums afterwards; larger calls sum them in one wavefront.  The same (query, document) pair can
+    therefore differ in the last bits between a final partial evaluation batch and a full one — fp32 summation order,
+    nothing else: bounded here (relative 4e-6 on the score) and rank-neutral wherever two scores differ by more than it."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(77)
+    B, Q, D, E = 1536, 20, 200, 300
+    q = torch.randn(B, Q, E, generator=g).to(dev)
+    d = torch.randn(B, D, E, generator=g).to(dev)
+    qm = (torch.arange(Q)[None] < torch.randint(3, Q + 1, (B,), generator=g)[:, None]).float().to(dev)
+    dm = (torch.arange(D)[None] < torch.randint(40, D + 1, (B,), generator=g)[:, None]).float().to(dev)
+    prm = [torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev), torch.ones(11, device=dev),
+           torch.linspace(-0.5, 0.5, 11, device=dev)]
+    big = ops.kernel_pool(q, d, qm, dm, *prm)[:512]                       # one wavefront per pair
+    small = ops.kernel_pool(q[:512], d[:512], qm[:512], dm[:512], *prm)   # two wavefronts per pair
+    scale = float(big.abs().max())
+    diff = float((big - small).abs().max())
+    assert diff <= 4e-6 * scale, (diff, scale)
+    a, b = big.cpu().numpy(), small.cpu().numpy()
+    order_a, order_b = np.argsort(-a, kind="stable"), np.argsort(-b, kind="stable")
+    gaps = np.abs(np.diff(a[order_a]))
+    decided = np.concatenate([[True], gaps > 2 * diff]) & np.concatenate([gaps > 2 * diff, [True]])
+    assert (order_a[decided] == order_b[decided]).all() and decided.mean() > 0.98

@@ -75,3 +75,38 @@ def test_rccl_all_gather_two_ranks_on_one_device():
     c = j["collective"]
     assert c["world_size"] == 2 and c["gathered_slice_equals_local_scores"] is True, c
     print("[rccl] world 2 on one device:", json.dumps(c))
+
+
+def test_config4_rehearsal_world_size_1_under_nccl():
+    """BASELINE.json configs[3] as `bench.py --gpus 8` runs it, on one rank: this rank's eighth of the query list
+    (sharding.shard_range), the PADDED all-gather of sharding.all_gather_scores under backend nccl, the final stable sort
+    timed separately, a sampled query's ranking compared with the ranking of its local scores.  (The query total is
+    shrunk so the shard is 2 GB instead of 40.)"""
+    util.require_gpu()
+    rc, out, err = _run([sys.executable, "bench.py", "--config4", "--total-queries", "349", "--force-dist", "--steps", "3",
+                         "--warmup", "1", "--no-extras", "--no-cpu-baseline"], 400)
+    assert rc == 0, err[-2000:]
+    j = _line(out)
+    assert j is not None, out[-2000:]
+    c = j["collective"]
+    assert "configs[3]" in j["config"]["workload"] and j["config"]["queries_per_gpu"] == 44      # shard_range(349, 8, 0)
+    assert c["backend"].startswith("nccl") and c["gathered_slice_equals_local_scores"] is True, c
+    assert c["final_sort"]["ranking_equals_single_rank"] is True and c["final_sort"]["rows"] == 44, c
+    assert j["value"] and j["self_check"]["ok"], j.get("self_check")
+    print("[rccl] config 4 rehearsal:", json.dumps(c))
+
+
+def test_sharded_flat_index_world_size_1_under_nccl():
+    """BASELINE.json configs[4]'s search path (retrieval.FlatIPIndexer.search_device: local exact top-1000, two RCCL
+    all-gathers of the (score, id) lists, mm_topk_merge) on one rank under backend nccl — the collectives and the merge run
+    even with a single rank (merge_single_rank).  The collection is shrunk to 1.6 M passages (200 k on this rank)."""
+    util.require_gpu()
+    rc, out, err = _run([sys.executable, "bench.py", "--only", "dot_topk", "--force-dist", "--dot-passages", "1600000",
+                         "--steps", "2"], 400)
+    assert rc == 0, err[-2000:]
+    j = _line(out)
+    assert j is not None and j.get("sharded") is True, out[-2000:]
+    r = j["result"]
+    assert r["backend"].startswith("nccl") and r["world_size"] == 1
+    assert r["merged_lists_sorted_and_contain_the_local_top1"] is True, r
+    print("[rccl] sharded flat index:", json.dumps({k: r[k] for k in ("ms", "queries_per_s", "version")}))

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.tkl_window_reference import selected_window_scores
+
 from oracle import np_oracle as O
 from tests import util
 
@@ -249,7 +251,7 @@ def test_tkl_full_model_trains_end_to_end():
 @pytest.mark.parametrize("sat", ["embedding", "log"])
 @pytest.mark.parametrize("B,Q,D,E", [(4, 20, 2048, 300), (3, 7, 120, 64), (2, 32, 41, 128)])
 def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, D, E):
-    """mm_tkl_bwd vs autograd through `_selected_window_scores` (the same 15-window computation in torch ops, itself pinned on
+    """mm_tkl_bwd vs autograd through `tests/tkl_window_reference.selected_window_scores` (the same 15-window computation in torch ops, itself pinned on
     the real class's gradients above): gradients w.r.t. the contextualised query, the contextualised chunks and every
     scoring parameter, on documents long enough for three separate regions, short ones (clamped / duplicate neighbour
     indices) and ragged lengths."""
@@ -291,7 +293,7 @@ def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, 
         else:
             with torch.no_grad():
                 _, win = ops_tkl(q_ctx, chunks, cmask, slot, qm, m, B, C, sat)
-            s = m._selected_window_scores(q_ctx, chunks, cmask, slot, qm, win, C)
+            s = selected_window_scores(m, q_ctx, chunks, cmask, slot, qm, win, C)
         (s * go).sum().backward()
         return s.detach(), q_ctx.grad, chunks.grad, {k: params[k].grad.clone() for k in names}
 
@@ -306,3 +308,34 @@ def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, 
 def ops_tkl(q_ctx, chunks, cmask, slot, qm, m, B, C, sat):
     from matchmaker_amd import ops
     return ops.tkl_score(q_ctx.detach(), chunks.detach(), cmask, slot, qm, m.pack_params(), B, C, 11, sat, return_windows=True)
+
+
+def test_unordered_chunk_slots_are_refused_on_the_device():
+    """mm_tkl_fwd needs ascending chunk_slot (a document's chunks adjacent, its last kept chunk last); ops.tkl_score checks
+    that with a device-side assert — no host synchronisation — unless the caller vouches for the order."""
+    import subprocess, sys, os
+    code = r'''
+import torch, sys
+sys.path.insert(0, %r)
+from matchmaker_amd import ops
+from matchmaker_amd.tkl import TKL_sigir20, chunk_documents
+dev = torch.device("cuda:0")
+m = TKL_sigir20(64, [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9], [0.1] * 11, 4, 1, 64, 500, True, True, "embedding").to(dev)
+q = torch.randn(2, 8, 64, device=dev); d = torch.randn(2, 300, 64, device=dev)
+qm = torch.ones(2, 8, device=dev); dm = torch.ones(2, 300, device=dev)
+ch, cm, sl, C = chunk_documents(d, dm)
+ok = ops.tkl_score(q, ch, cm, sl, qm, m.pack_params(), 2, C, 11)
+torch.cuda.synchronize()
+perm = torch.arange(sl.numel() - 1, -1, -1, device=dev)
+try:
+    ops.tkl_score(q, ch[perm].contiguous(), cm[perm].contiguous(), sl[perm].contiguous(), qm, m.pack_params(), 2, C, 11)
+    torch.cuda.synchronize()
+except Exception as e:
+    print("REFUSED", type(e).__name__)
+    sys.exit(0)
+print("ACCEPTED")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # a device-side assert poisons the process's HIP context: run it in a child
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in r.stdout or r.returncode != 0, (r.stdout[-300:], r.stderr[-300:])
+    assert "ACCEPTED" not in r.stdout

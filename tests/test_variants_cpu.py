@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.tkl_window_reference import selected_window_scores
+
 from oracle import np_oracle as O
 from oracle import torch_port as TP
 from tests import util
@@ -148,7 +150,7 @@ def check_tkl_grads(m, g, q, d, tol=2e-4):
 
 
 def test_tkl_gradient_carrier_matches_gradients_of_the_real_class():
-    """grad_tkl_*.npz: gradients of the REAL TKL_sigir20.forward.  The carrier (tkl._selected_window_scores) is pure
+    """grad_tkl_*.npz: gradients of the REAL TKL_sigir20.forward.  The carrier (tests/tkl_window_reference.selected_window_scores) is pure
     torch, so it runs on the CPU here, fed with the fixture's window scores in place of the native ones."""
     from matchmaker_amd.tkl import chunk_documents
     g = util.load("grad_tkl_d333_e64_embedding.npz")
@@ -158,7 +160,7 @@ def test_tkl_gradient_carrier_matches_gradients_of_the_real_class():
     q_ctx, _ = m.forward_representation(q, t("q_mask"))
     chunks, chunk_mask, chunk_slot, C = chunk_documents(d, t("d_mask"))
     chunks_ctx, _ = m.forward_representation(chunks, chunk_mask)
-    s = m._selected_window_scores(q_ctx, chunks_ctx, chunk_mask, chunk_slot, t("q_mask"), t("orig_score"), C)
+    s = selected_window_scores(m, q_ctx, chunks_ctx, chunk_mask, chunk_slot, t("q_mask"), t("orig_score"), C)
     np.testing.assert_allclose(s.detach().numpy(), g["score"], atol=1e-4, rtol=1e-5)
     (s * t("grad_out")).sum().backward()
     check_tkl_grads(m, g, q, d)
@@ -226,3 +228,52 @@ def test_idcm_without_sampling_equals_the_live_reference_class():
     mine.train()
     mine.forward(query, doc, use_fp16=False).sum().backward()
     assert mine._classification_layer.weight.grad.abs().sum() > 0
+
+
+@pytest.mark.skipif(not __import__("oracle.ref_harness", fromlist=["available"]).available(),
+                    reason="patching needs the reference tree")
+def test_patch_matchmaker_installs_a_thin_idcm_subclass_of_the_real_class(monkeypatch):
+    """patch_matchmaker() rebinds sigir21_idcm.IDCM to a subclass of the REFERENCE'S OWN class whose only override is
+    forward = matchmaker_amd.idcm.forward_native: the reference's constructor / from_config build it, the real class's
+    state_dict loads into it, and on the same inputs it reproduces the real class (CPU: oracle in the operator's place)."""
+    import importlib
+    from oracle import ref_harness as R
+    from matchmaker_amd import idcm as product, ops, patch
+    R.install_shims()
+    ref_mod = importlib.import_module("matchmaker.models.published.sigir21_idcm")
+    real = ref_mod.IDCM
+    saved = {}
+    for ref_m, ref_attr, _, _ in patch._TABLE:
+        try:
+            saved[(ref_m, ref_attr)] = getattr(importlib.import_module(ref_m), ref_attr)
+        except Exception:
+            pass
+    try:
+        done = patch.patch_matchmaker()
+        assert "matchmaker.models.published.sigir21_idcm.IDCM" in done
+        patched = ref_mod.IDCM
+        assert patched is not real and issubclass(patched, real) and patched.forward is product.forward_native
+        assert [k for k in vars(patched) if not k.startswith("__")] == ["forward"]            # nothing else overridden
+        assert patch.patch_matchmaker() and ref_mod.IDCM is patched                            # idempotent: no stacking
+        torch.manual_seed(5)
+        mine = patched(_tiny_distilbert(), sample_train_type="mseloss", sample_n=3, sample_context="ck-small", top_k_chunks=3,
+                       chunk_size=50, overlap=7, padding_idx=0)          # the reference's constructor (:27-108)
+        ref = real(_tiny_distilbert(), sample_train_type="mseloss", sample_n=3, sample_context="ck-small", top_k_chunks=3,
+                   chunk_size=50, overlap=7, padding_idx=0)
+        mine.load_state_dict(ref.state_dict(), strict=True)
+        mine.eval(), ref.eval()
+        monkeypatch.setattr(ops, "kernel_pool", _oracle_kernel_pool)
+        g = torch.Generator().manual_seed(3)
+        B, LQ, LD = 3, 10, 260
+        q_mask = (torch.arange(LQ)[None] < torch.tensor([10, 4, 7])[:, None]).long()
+        d_mask = (torch.arange(LD)[None] < torch.tensor([260, 33, 150])[:, None]).long()
+        query = {"input_ids": torch.randint(1, 200, (B, LQ), generator=g) * q_mask, "attention_mask": q_mask}
+        doc = {"input_ids": torch.randint(1, 200, (B, LD), generator=g) * d_mask, "attention_mask": d_mask}
+        with torch.no_grad():
+            want = ref.forward(query, doc, use_fp16=False, output_secondary_output=True)
+            got = mine.forward(query, doc, use_fp16=False, output_secondary_output=True)
+        np.testing.assert_allclose(got[2]["sampling_scores"].numpy(), want[2]["sampling_scores"].numpy(), atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(got[0].numpy(), want[0].numpy(), atol=1e-5)
+    finally:                                             # other tests drive the real classes
+        for (ref_m, ref_attr), obj in saved.items():
+            setattr(importlib.import_module(ref_m), ref_attr, obj)
