@@ -274,10 +274,12 @@ def extra_dropin_forward(q, d, q_len, d_len, steps):
     qp = q.repeat_interleave(CANDS, 0).contiguous()
     qm = synth.len_to_mask(q_len, Q, torch.int64).repeat_interleave(CANDS, 0).contiguous()
     dm = synth.len_to_mask(d_len, D, torch.int64)
-    ref = ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS)
-    got = ColBERT._score(qp, d, qm, dm)                   # the drop-in's scoring entry (no_grad: native forward)
-    same = bool(torch.equal(ref, got))
-    ms = gpu_time_ms(lambda: ColBERT._score(qp, d, qm, dm), steps)
+    # eval.py:83 / colbert.py:60 run the block under autocast: 16-bit similarities and maxima, fp32 sums (MM_SIM_ROUND)
+    ref = ops.maxsim(q, d, q_len, d_len, pairs_per_query=CANDS, sim_round=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        got = ColBERT._score(qp, d, qm, dm)               # the drop-in's scoring entry (no_grad: native forward)
+        same = bool(torch.equal(ref, got))
+        ms = gpu_time_ms(lambda: ColBERT._score(qp, d, qm, dm), steps)
     by = dropin_bytes(B)
     gbs = by / (ms * 1e-3) / 1e9
     return {"workload": f"the headline's {nq} x {CANDS} pairs in the reference's batch layout: Q replicated per pair "
@@ -557,6 +559,9 @@ def extra_eval_batch(steps, cpu_budget):
     g = torch.Generator(device=dev).manual_seed(512)
     res = {}
 
+    ac = torch.autocast("cuda", dtype=torch.float16)      # eval.py:83 wraps every batch in autocast (use_fp16); the pooling ops stay fp32
+    ac.__enter__()
+
     def run(name, n_batches, make, call, bytes_per_call, n_calls=400):
         batches = [make() for _ in range(n_batches)]
         for b in batches:
@@ -640,7 +645,8 @@ def extra_eval_batch(steps, cpu_budget):
                 torch.ones(Bc, 20, device=dev), torch.ones(Bc, 200, device=dev))
     run("tk_dim300_fp32", 4, tk_make, lambda b: ops.kernel_pool(b[0], b[1], b[2], b[3], *prm, pairs_per_query=1),
         Bc * ((200 + 20) * 300 * 4 + 4 * (200 + 20) + 4))
-    return {"workload": "512 pairs per call (defaults.yaml:115 batch_size_eval), pair-per-row, int64 HF masks (ColBERT) / float masks (TK); "
+    ac.__exit__(None, None, None)
+    return {"workload": "512 pairs per call (defaults.yaml:115 batch_size_eval), under autocast as eval.py:83 runs them, pair-per-row, int64 HF masks (ColBERT) / float masks (TK); "
                         "config-2 shapes, the published checkpoint's shapes (Q=38 / D=200 / dim=768 fp16), TK Q=20 / D=200 / dim=300",
             "shapes": res}
 
@@ -658,7 +664,8 @@ def extra_published_checkpoint(steps, cpu_budget):
     dp = (torch.randn(n, Dp, Ep, generator=g, device=dev) / Ep ** 0.5).half()
     qm = torch.ones(n, Qp, dtype=torch.long, device=dev)
     dm = torch.ones(n, Dp, dtype=torch.long, device=dev)
-    ms = gpu_time_ms(lambda: ColBERT._score(qp, dp, qm, dm), steps)
+    with torch.autocast("cuda", dtype=torch.float16):      # use_fp16 (colbert.py:60): fp16 maxima, fp32 sums
+        ms = gpu_time_ms(lambda: ColBERT._score(qp, dp, qm, dm), steps)
     by = n * ((Dp + Qp) * Ep * 2 + 8 * (Dp + Qp) + 4)
     gbs = by / (ms * 1e-3) / 1e9
     out = {"workload": f"{n} pairs in the reference's batch layout, Q={Qp} (30 + 8 [MASK]) / D={Dp} / dim={Ep}, fp16, int64 HF masks",

@@ -139,14 +139,16 @@ int mm_hbm_stream_probe(const void* src, int64_t bytes, int nt, void* stream);
  * loss.backward() :503-524).  Recomputes the similarities and routes grad_out[p] to the FIRST
  * arg-max document position of every real query token (torch.max's rule); nothing flows through
  * the -1000 sentinel (colbert.py:69) or padded query tokens (:73).
- *   grad_out [n_pairs] float32; grad_q [n_pairs, Q, E], grad_d [n_pairs, D, E] float32, fully
- *   written by the call (grad_d is zero-filled first).  q/d/masks exactly as given to the forward. */
+ *   grad_out [n_pairs] float32; grad_q [n_pairs, Q, E], grad_d [n_pairs, D, E] of element type grad_dtype: MM_F32, or the
+ *   token vectors' own 16-bit type (what autograd hands back to an fp16 / bf16 encoder: summed in fp32, rounded once).
+ *   Both are fully written by the call (rows without gradient are zeros: no memset needed in front of it).
+ *   q/d/masks exactly as given to the forward. */
 size_t mm_maxsim_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind);
 
 int mm_maxsim_bwd(const void* q, const void* d,
                   const void* q_mask, int q_mask_kind,
                   const void* d_mask, int d_mask_kind,
-                  const float* grad_out, float* grad_q, float* grad_d,
+                  const float* grad_out, void* grad_q, void* grad_d, int grad_dtype,
                   int64_t n_pairs, int Q, int D, int E, int dtype,
                   void* workspace, size_t workspace_bytes, void* stream);
 

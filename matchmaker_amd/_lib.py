@@ -6,7 +6,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmm_native.so")
+# MM_NATIVE_LIB: another build of the same library for ONE process (A/B variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("MM_NATIVE_LIB") or os.path.join(HERE, "csrc", "libmm_native.so")
 
 MM_F32, MM_F16, MM_BF16 = 0, 1, 2
 MASK_NONE, MASK_LEN_I32, MASK_U8, MASK_I64, MASK_F32 = 0, 1, 2, 3, 4
@@ -29,7 +30,7 @@ SIGNATURES = {
     "mm_maxsim_ragged_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_hbm_stream_probe": (_i, [_vp, _i64, _i, _vp]),
     "mm_maxsim_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
-    "mm_maxsim_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_maxsim_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
     "mm_kernel_pool_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                 _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -44,8 +44,8 @@ class _MaxSimFn(torch.autograd.Function):
         # (rounding is piecewise constant: the gradient is that of the unrounded maximum, routed to an arg-max of the
         # fp32 similarities — which is also an arg-max of the rounded ones)
         q, d, q_mask, d_mask = ctx.saved_tensors
-        gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g)
-        return gq.to(q.dtype), gd.to(d.dtype), None, None, None, None
+        gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g, grad_dtype=q.dtype)     # one launch, gradients in the vectors' dtype
+        return gq, gd, None, None, None, None
 
 
 def _as_reference_would(query_vecs, document_vecs):
@@ -93,12 +93,24 @@ class ColBERT(PreTrainedModel):
     @staticmethod
     def _score(query_vecs, document_vecs, query_mask, document_mask):
         """colbert.py:68-75, in the arithmetic the reference's eager ops have in the current autocast state: fp16 similarities
-        and maxima, fp32 sum under `use_fp16` (defaults.yaml:21); fp32 throughout for fp32 vectors outside autocast."""
-        q, d, sim_round, sum_round = _as_reference_would(query_vecs, document_vecs)
+        and maxima, fp32 sum under `use_fp16` (defaults.yaml:21); fp32 throughout for fp32 vectors outside autocast.
+        (_as_reference_would() spelled out: eval.py issues thousands of 512-pair calls whose device time is ~4 us, so every
+        microsecond of Python on this path is visible.)"""
+        ac = torch.is_autocast_enabled("cuda")
+        q, d = query_vecs, document_vecs
+        if q.dtype is torch.float32:
+            if ac:
+                adt = torch.get_autocast_dtype("cuda")
+                q, d = q.to(adt), d.to(adt)
+            sim_round, sum_round = ac, False
+        else:
+            if d.dtype is not q.dtype:
+                d = d.to(q.dtype)
+            sim_round, sum_round = True, not ac
         if torch.is_grad_enabled() and (q.requires_grad or d.requires_grad):
             score = _MaxSimFn.apply(q, d, query_mask, document_mask, sim_round, sum_round)
         else:
-            score = ops.maxsim(q, d, query_mask, document_mask, pairs_per_query=1, sim_round=sim_round, sum_round=sum_round)
+            score = ops.maxsim(q, d, query_mask, document_mask, 1, sim_round, sum_round)
         return score.to(q.dtype) if sum_round else score      # (16-bit tensors outside autocast: `sum` returns their dtype)
 
     def forward(self, query: Dict[str, torch.LongTensor], document: Dict[str, torch.LongTensor],

@@ -25,6 +25,17 @@
 // (profiles/r03_experiments/tk_schedule_ab.txt); TKL's stage 1 does not care (0.135-0.138 ms for 3 .. 12).
 constexpr int kShadowValu = 5;
 
+// The split-bf16 dot product of the TK pooling kernel is  hi.hi + lo.hi + hi.lo  (three MFMAs per K step): the fourth
+// product lo.lo is below 2^-16 of the result and was kept through round 3 on a 1e-6-scale criterion on exact duplicates;
+// against the contract (scores within 1e-3, decided ranks) it changes nothing that can be measured — max |score - fp64|
+// 5.2745e-6 without it, 5.2733e-6 with it on the 16 x 1000 rank lists, 15,984 vs 15,986 of 16,000 positions equal to the
+// stable sort of the fp32 reference (tests/test_rank_order_gpu.py, profiles/r04_rank_parity/) — and it costs 4.5 % of the
+// call on a kernel that runs into the board's power limit.  -DMM_KP_LOLO=1 (tools/build_variant.sh) builds
+// the four-product kernel for A/B runs.
+#ifndef MM_KP_LOLO
+#define MM_KP_LOLO 0
+#endif
+
 namespace mm {
 
 // TKL: the wavefront that processes packed chunk p publishes its slot-map entry (see KpArgs::slot2p)
@@ -609,7 +620,7 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
           acc_hh = mfma_bf16(ah, qhi[s][p], acc_hh);
           acc_xl = mfma_bf16(al, qhi[s][p], acc_xl);
           acc_xl = mfma_bf16(ah, qlo[s][p], acc_xl);
-          acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
+          if (MM_KP_LOLO) acc_xl = mfma_bf16(al, qlo[s][p], acc_xl);
           {
             const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
             const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
@@ -640,7 +651,7 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
         acc_hh = mfma_bf16(ah, qhiL, acc_hh);
         acc_xl = mfma_bf16(al, qhiL, acc_xl);
         acc_xl = mfma_bf16(ah, qloL, acc_xl);
-        acc_xl = mfma_bf16(al, qloL, acc_xl);
+        if (MM_KP_LOLO) acc_xl = mfma_bf16(al, qloL, acc_xl);
       }
       float ss = ss2[0] + ss2[1];
       f32x16 acc;

@@ -617,8 +617,8 @@ struct MaxsimBwdArgs {
   const void* d;
   PackedMask qm, dm;
   const float* go;
-  float* gq;
-  float* gd;
+  void* gq;
+  void* gd;
   int64_t n_pairs;
   int Q, D, E;
 };
@@ -630,15 +630,27 @@ __device__ __forceinline__ float load_elem(const char* row, int e) {
   else return __uint_as_float((uint32_t)((const uint16_t*)row)[e] << 16);
 }
 
-template <int DT>
+template <int GT>
+__device__ __forceinline__ void store_grad(void* base, int64_t idx, float v) {
+  if constexpr (GT == MM_F32) ((float*)base)[idx] = v;
+  else if constexpr (GT == MM_F16) ((_Float16*)base)[idx] = (_Float16)v;
+  else ((uint16_t*)base)[idx] = (uint16_t)(__float_as_uint(round_like<MM_BF16>(v)) >> 16);
+}
+
+// GT: element type of the gradients — float32, or the token vectors' own 16-bit type (what autograd hands back to an
+// fp16 / bf16 encoder: written once, rounded once; rounds 1-3 wrote fp32 into a memset buffer and cast afterwards:
+// three launches and 2.5 x the bytes).  Every row of grad_d is written by this kernel (zeros where no query token's
+// maximum sits): no memset in front of it.
+template <int DT, int GT>
 __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
-  __shared__ int jstar[32];
+  extern __shared__ int jstar[];   // [Q] first arg-max document position of every query token, -1 = no gradient
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
   const int64_t pair = blockIdx.x;
   if (pair >= a.n_pairs) return;
   const int D = a.D, Q = a.Q, E = a.E;
   constexpr int ES = (DT == MM_F32) ? 4 : 2;
+  constexpr int GS = (GT == MM_F32) ? 4 : 2;
   const int64_t rowb = (int64_t)E * ES;
   const int nblk_tot = (D + 31) >> 5;
   const int qwords = (Q + 31) >> 5;
@@ -650,8 +662,8 @@ __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
   const char* dbase = (const char*)a.d + pair * D * rowb;
   const char* qbase = (const char*)a.q + pair * Q * rowb;
   const float g = a.go[pair];
-  float* gq = a.gq + pair * Q * (int64_t)E;
-  float* gd = a.gd + pair * D * (int64_t)E;
+  char* gq = (char*)a.gq + pair * Q * (int64_t)E * GS;
+  char* gd = (char*)a.gd + pair * D * (int64_t)E * GS;
 
   for (int n = 0; n < qwords; ++n) {
     const int qtok = 32 * n + r;
@@ -689,23 +701,29 @@ __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
     const float ob = __shfl_xor(best, 32, 64);
     const int orow = __shfl_xor(brow, 32, 64);
     if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-    __syncthreads();
-    if (h == 0) jstar[r] = (qvalid && brow != 0x7fffffff) ? brow : -1;
-    __syncthreads();
-    const int nq_tile = Q - 32 * n < 32 ? Q - 32 * n : 32;
-    for (int qq = 0; qq < nq_tile; ++qq) {
-      const int j = jstar[qq];
-      const int qt = 32 * n + qq;
-      const char* qrow = qbase + qt * rowb;
-      if (j >= 0) {
-        const char* drow = dbase + j * rowb;
-        for (int e = lane; e < E; e += 64) {
-          gq[(int64_t)qt * E + e] = g * load_elem<DT>(drow, e);
-          gd[(int64_t)j * E + e] += g * load_elem<DT>(qrow, e);  // same lane owns element e for every qq
-        }
-      } else {
-        for (int e = lane; e < E; e += 64) gq[(int64_t)qt * E + e] = 0.0f;
-      }
+    if (h == 0 && qtok < Q) jstar[qtok] = (qvalid && brow != 0x7fffffff) ? brow : -1;
+  }
+  // grad_d: zeros everywhere first — lane l owns elements e = l, l + 64, ... of every row, here and below, so the
+  // rows that carry gradient are simply written again by the same lanes, in program order
+  for (int j = 0; j < D; ++j)
+    for (int e = lane; e < E; e += 64) store_grad<GT>(gd, (int64_t)j * E + e, 0.0f);
+  __syncthreads();
+  for (int qt = 0; qt < Q; ++qt) {
+    const int j = jstar[qt];                            // wave-uniform (LDS)
+    if (j < 0) {
+      for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, 0.0f);
+      continue;
+    }
+    const char* drow = dbase + j * rowb;
+    for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, g * load_elem<DT>(drow, e));   // grad_q_i = g d_j*
+    bool first = true;                                  // grad_d_j = g sum_{i: j*(i) = j} q_i, summed in fp32, written once
+    for (int p = 0; p < qt; ++p) first = first && jstar[p] != j;
+    if (!first) continue;
+    for (int e = lane; e < E; e += 64) {
+      float sacc = 0.0f;
+      for (int p = qt; p < Q; ++p)
+        if (jstar[p] == j) sacc += load_elem<DT>(qbase + p * rowb, e);
+      store_grad<GT>(gd, (int64_t)j * E + e, g * sacc);
     }
   }
 }
@@ -1058,27 +1076,33 @@ extern "C" size_t mm_maxsim_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, i
 }
 
 extern "C" int mm_maxsim_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
-                             int d_mask_kind, const float* grad_out, float* grad_q, float* grad_d, int64_t n_pairs,
+                             int d_mask_kind, const float* grad_out, void* grad_q, void* grad_d, int grad_dtype, int64_t n_pairs,
                              int Q, int D, int E, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!grad_out || !grad_q || !grad_d) return set_error(MM_EINVAL, "maxsim_bwd: null gradient pointer");
-  if (int e = validate(q, d, grad_q, n_pairs, Q, D, E, dtype)) return e;
+  if (int e = validate(q, d, (float*)grad_q, n_pairs, Q, D, E, dtype)) return e;
+  if (grad_dtype != MM_F32 && grad_dtype != dtype)
+    return set_error(MM_EINVAL, "maxsim_bwd: gradients are float32 or have the token vectors' own type (got %d for %d)", grad_dtype, dtype);
   if (n_pairs == 0) return MM_OK;
   if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "maxsim_bwd: more than 2^31-1 pairs in one launch");
+  if ((size_t)Q * 4 > 48 * 1024) return set_error(MM_EUNSUPPORTED, "maxsim_bwd: Q = %d query tokens exceed the arg-max table", Q);
   MaxsimBwdArgs a{};
   a.q = q; a.d = d; a.go = grad_out; a.gq = grad_q; a.gd = grad_d; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-  if (hipMemsetAsync(grad_d, 0, (size_t)n_pairs * D * E * sizeof(float), stream) != hipSuccess)
-    return set_error(MM_ELAUNCH, "maxsim_bwd: memset failed");
   const dim3 grid((unsigned)n_pairs), block(64);
+  const size_t lds = (size_t)Q * 4;
   if (dtype == MM_F32)
-    hipLaunchKernelGGL(maxsim_bwd_kernel<MM_F32>, grid, block, 0, stream, a);
+    hipLaunchKernelGGL((maxsim_bwd_kernel<MM_F32, MM_F32>), grid, block, lds, stream, a);
+  else if (dtype == MM_F16 && grad_dtype == MM_F32)
+    hipLaunchKernelGGL((maxsim_bwd_kernel<MM_F16, MM_F32>), grid, block, lds, stream, a);
   else if (dtype == MM_F16)
-    hipLaunchKernelGGL(maxsim_bwd_kernel<MM_F16>, grid, block, 0, stream, a);
+    hipLaunchKernelGGL((maxsim_bwd_kernel<MM_F16, MM_F16>), grid, block, lds, stream, a);
+  else if (grad_dtype == MM_F32)
+    hipLaunchKernelGGL((maxsim_bwd_kernel<MM_BF16, MM_F32>), grid, block, lds, stream, a);
   else
-    hipLaunchKernelGGL(maxsim_bwd_kernel<MM_BF16>, grid, block, 0, stream, a);
+    hipLaunchKernelGGL((maxsim_bwd_kernel<MM_BF16, MM_BF16>), grid, block, lds, stream, a);
   return check_launch("maxsim_bwd_kernel");
 }

@@ -206,7 +206,7 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
         st = _stream(dev)
         ws = _workspace(dev, wsb, st)
         rc = L.mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, out.data_ptr(), B, pairs_per_query,
-                             Q, D, E, _DT[q.dtype], _flags(sim_round, sum_round),
+                             Q, D, E, _DT[q.dtype], (1 if sim_round else 0) | (2 if sum_round else 0),
                              ws.data_ptr() if ws is not None else None, wsb, st)
     _lib.check(rc, "mm_maxsim_fwd")
     return out
@@ -282,9 +282,10 @@ def maxsim_ragged(q: torch.Tensor, tokens: torch.Tensor, doc_begin: torch.Tensor
 
 
 def maxsim_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
-               grad_out: torch.Tensor):
-    """Backward of the paired MaxSim (pair-per-row layout).  Returns float32 (grad_q [B,Q,E],
-    grad_d [B,D,E]); see mm_maxsim_bwd in include/mm_native.h."""
+               grad_out: torch.Tensor, grad_dtype: Optional[torch.dtype] = None):
+    """Backward of the paired MaxSim (pair-per-row layout).  Returns (grad_q [B,Q,E], grad_d [B,D,E]) as float32, or —
+    grad_dtype = q.dtype — in the token vectors' own 16-bit type (what autograd hands back to an fp16 / bf16 encoder:
+    one launch, summed in fp32, rounded once); see mm_maxsim_bwd in include/mm_native.h."""
     dev = _dev_check(q, d, q_mask, d_mask, grad_out)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != d.dtype:
@@ -301,15 +302,19 @@ def maxsim_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor],
     L = _lib.lib()
     E0 = E
     q, d, E = _pad_rows(q, d, 4 if q.dtype == torch.float32 else 8)
-    gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
-    gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
+    gdt = torch.float32 if grad_dtype is None else grad_dtype
+    if gdt not in (torch.float32, q.dtype):
+        raise NativeError(f"maxsim_bwd: gradients are float32 or {q.dtype}, not {gdt}")
+    gq = torch.empty((B, Q, E), dtype=gdt, device=dev)
+    gd = torch.empty((B, D, E), dtype=gdt, device=dev)
     if B:
-        with torch.cuda.device(dev):
-            wsb = L.mm_maxsim_bwd_workspace_bytes(B, Q, D, qk, dk)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        with _on(dev):
+            wsb = _ws_bytes(L.mm_maxsim_bwd_workspace_bytes, B, Q, D, qk, dk)
+            st = _stream(dev)
+            ws = _workspace(dev, wsb, st)
             rc = L.mm_maxsim_bwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk, go.data_ptr(), gq.data_ptr(),
-                                 gd.data_ptr(), B, Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None,
-                                 wsb, _stream(dev))
+                                 gd.data_ptr(), _DT[gdt], B, Q, D, E, _DT[q.dtype], ws.data_ptr() if ws is not None else None,
+                                 wsb, st)
         _lib.check(rc, "mm_maxsim_bwd")
     if E != E0:
         gq, gd = gq[..., :E0].contiguous(), gd[..., :E0].contiguous()

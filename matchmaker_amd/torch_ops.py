@@ -53,8 +53,8 @@ def _maxsim_backward(ctx, g):
     if ctx.ppq != 1:
         raise ops.NativeError("mm_native::maxsim backward needs the pair-per-row layout (pairs_per_query = 1), "
                               "the one train.py feeds")
-    gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g)
-    return gq.to(q.dtype), gd.to(d.dtype), None, None, None, None, None
+    gq, gd = ops.maxsim_bwd(q, d, q_mask, d_mask, g, grad_dtype=q.dtype)
+    return gq, gd, None, None, None, None, None
 
 
 maxsim.register_autograd(_maxsim_backward, setup_context=_maxsim_setup)

@@ -118,10 +118,11 @@ def cosine_matrix(a, b, dtype=np.float32):
     return np.matmul(an, np.swapaxes(bn, -1, -2))
 
 
-def cosine_matrix_split_bf16(a, b):
-    """Emulation of the DEVICE arithmetic of the split-bf16 kernel (matchmaker_amd/csrc/
-    kernel_pool.hip, kernel_pool_split_kernel): x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
-    dot = hi.hi + lo.hi + hi.lo + lo.lo (products exact, fp32-class accumulation), norms from the
+def cosine_matrix_split_bf16(a, b, lolo=True):
+    """Emulation of the DEVICE arithmetic of the split-bf16 kernels (matchmaker_amd/csrc/
+    kernel_pool.hip): x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+    dot = hi.hi + lo.hi + hi.lo (+ lo.lo: TKL's stage 1 keeps it, the TK pooling kernel dropped it in round 4 — lolo=False)
+    (products exact, fp32-class accumulation), norms from the
     fp32 values.  Not a reference restatement: it exists so the CPU suite can bound the device
     scheme's error against `cosine_matrix(..., float64)` without a GPU."""
     a = np.asarray(a, dtype=np.float32)
@@ -131,7 +132,7 @@ def cosine_matrix_split_bf16(a, b):
     f = np.float64
     bt = lambda x: np.swapaxes(x.astype(f), -1, -2)
     dot = (ah.astype(f) @ bt(bh)).astype(np.float32) + ((al.astype(f) @ bt(bh)).astype(np.float32)
-                                                        + (ah.astype(f) @ bt(bl) + al.astype(f) @ bt(bl)).astype(np.float32))
+                                                        + (ah.astype(f) @ bt(bl) + (al.astype(f) @ bt(bl) if lolo else 0.0)).astype(np.float32))
     ra = np.float32(1) / (np.sqrt((a * a).sum(-1, keepdims=True, dtype=np.float32)) + np.float32(1e-13))
     rb = np.float32(1) / (np.sqrt((b * b).sum(-1, keepdims=True, dtype=np.float32)) + np.float32(1e-13))
     return (dot * ra) * np.swapaxes(rb, -1, -2)

@@ -200,6 +200,13 @@ def test_split_bf16_numerics():
             d[b, j] = q[b, j % 20] * (1 + 0.01 * j) + 0.02 * rng.standard_normal(300).astype(np.float32)
     es = np.abs(O.cosine_matrix_split_bf16(q, d) - O.cosine_matrix(q, d, np.float64)).max()
     assert es < 2.5e-6, es       # 2^-18 residual per operand; worst case = coherent near-duplicates
+    # the TK pooling kernel's three-product form (no lo.lo): the missing term is a coherent ~2^-17^2 x E bias on exact
+    # duplicates — a few 1e-6 on the cosine, three orders below what moves a score by the contract's 1e-3 (the widest RBF
+    # kernel derivative is 1 / (sigma sqrt(e)) ~ 6 per unit cosine; the GPU suite checks every pair of 16 x 1000 at 1e-3)
+    es3 = np.abs(O.cosine_matrix_split_bf16(q, d, lolo=False) - O.cosine_matrix(q, d, np.float64)).max()
+    assert es3 < 8e-6, es3
+    g3 = np.abs(O.cosine_matrix_split_bf16(np.repeat(g["q"], B, 0) if g["q"].shape[0] == 1 else g["q"], g["d"], lolo=False) - c64).max()
+    assert g3 < 5e-6, g3          # (the golden batch holds exact copies of query tokens: 3.3e-6 there, 5e-7 with lo.lo)
     # exact power-of-two scale invariance (what tests/test_kernel_pool_gpu.py asserts on the device)
     assert np.array_equal(O.cosine_matrix_split_bf16(q * 4, d * 0.5), O.cosine_matrix_split_bf16(q, d))
 
