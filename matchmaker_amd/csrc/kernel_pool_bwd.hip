@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a,
 // kernel above.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTK = 16;
+constexpr int kTT = 512;   // threads of the tiled kernel: eight wavefronts, two per SIMD, around ONE set of LDS tiles per CU
 
 __host__ __device__ inline size_t kp_bwd_tiled_lds_bytes(int Q, int E, int Dpad) {
   const int ES = E + 4, QS = (Q + 3) & ~3;
@@ -270,7 +271,7 @@ __host__ __device__ inline size_t kp_bwd_tiled_lds_bytes(int Q, int E, int Dpad)
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 template <bool GATE>
-__global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdArgs a, const int Dpad) {
+__global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdArgs a, const int Dpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x;
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
   const int qwords = (Q + 31) >> 5, dwords = (D + 31) >> 5;
 
   // ---- query tile, constants ---------------------------------------------------------------------------------
-  for (int idx = tid; idx < Q * NC; idx += 256) {
+  for (int idx = tid; idx < Q * NC; idx += kTT) {
     const int i = idx / NC, c = idx - i * NC;
     *(f32x4*)(QH + i * ES + 4 * c) = *(const f32x4*)(qb + (int64_t)i * E + 4 * c);
   }
@@ -312,23 +313,24 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
     kc[kTK + tid] = -1.4426950408889634f / (2.0f * sg * sg);
     kc[2 * kTK + tid] = 1.0f / (sg * sg);
   }
-  for (int idx = tid; idx < Q * kTK; idx += 256) PK[idx] = 0.0f;
+  for (int idx = tid; idx < Q * kTK; idx += kTT) PK[idx] = 0.0f;
   if (tid < 32) sq[tid] = 0.0f;
   __syncthreads();
-  {  // norms: eight threads per query token; the tile is stored normalised
-    const int i = tid >> 3, sub = tid & 7;
+  {  // norms: sixteen threads per query token; the tile is stored normalised
+    const int i = tid >> 4, sub = tid & 15;
     float ss = 0.0f;
     if (i < Q)
-      for (int c = sub; c < NC; c += 8) {
+      for (int c = sub; c < NC; c += 16) {
         const f32x4 v = *(const f32x4*)(QH + i * ES + 4 * c);
         ss += dot4(v, v);
       }
     ss += __shfl_xor(ss, 1, 64);
     ss += __shfl_xor(ss, 2, 64);
     ss += __shfl_xor(ss, 4, 64);
+    ss += __shfl_xor(ss, 8, 64);
     const float n = sqrtf(ss), r = 1.0f / (n + 1e-13f);
     if (i < Q) {
-      for (int c = sub; c < NC; c += 8) {
+      for (int c = sub; c < NC; c += 16) {
         f32x4* p = (f32x4*)(QH + i * ES + 4 * c);
         *p = *p * r;
       }
@@ -342,7 +344,7 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
   __syncthreads();
 
   auto load_block = [&](int j0, int nj) {
-    for (int idx = tid; idx < 32 * NC; idx += 256) {
+    for (int idx = tid; idx < 32 * NC; idx += kTT) {
       const int row = idx / NC, c = idx - row * NC;
       f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
       if (row < nj) v = *(const f32x4*)(db + (int64_t)(j0 + row) * E + 4 * c);
@@ -351,22 +353,23 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
   };
 
   // ---- sweep 1: cosines of every block, pooled kernels ---------------------------------------------------------
-  const int rg = tid >> 5, tg8 = (tid >> 2) & 7, ks = tid & 3;
+  const int rg = tid >> 6, tg8 = (tid >> 3) & 7, ks = tid & 7;    // 8 row groups x 8 token groups x 8 K slices
   const int TQ = (Q + 7) >> 3;                         // query tokens per thread of the cosine tile (<= 4)
   for (int j0 = 0; j0 < D; j0 += 32) {
     const int nj = D - j0 < 32 ? D - j0 : 32;
     load_block(j0, nj);
     __syncthreads();
-    {  // row norms and masks: eight threads per row
-      const int row = tid >> 3, sub = tid & 7;
+    {  // row norms and masks: sixteen threads per row
+      const int row = tid >> 4, sub = tid & 15;
       float ss = 0.0f;
-      for (int c = sub; c < NC; c += 8) {
+      for (int c = sub; c < NC; c += 16) {
         const f32x4 v = *(const f32x4*)(DB + row * ES + 4 * c);
         ss += dot4(v, v);
       }
       ss += __shfl_xor(ss, 1, 64);
       ss += __shfl_xor(ss, 2, 64);
       ss += __shfl_xor(ss, 4, 64);
+      ss += __shfl_xor(ss, 8, 64);
       if (sub == 0) {
         const float n = sqrtf(ss);
         const bool real = row < nj && mask_bit(a.dm, pair, dwords, j0 + row, D);
@@ -379,13 +382,13 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
       }
     }
     __syncthreads();
-    {  // cosine tile: thread = (4 rows, TQ tokens, every 4th 16-byte chunk of E); the four K slices meet by shuffles
+    {  // cosine tile: thread = (4 rows, TQ tokens, every 8th 16-byte chunk of E); the eight K slices meet by shuffles
       float acc[4][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[r][t] = 0.0f;
-      for (int c = ks; c < NC; c += 4) {
+      for (int c = ks; c < NC; c += 8) {
         f32x4 dv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) dv[r] = *(const f32x4*)(DB + (4 * rg + r) * ES + 4 * c);
@@ -406,20 +409,21 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
         for (int t = 0; t < 4; ++t) {
           acc[r][t] += __shfl_xor(acc[r][t], 1, 64);
           acc[r][t] += __shfl_xor(acc[r][t], 2, 64);
+          acc[r][t] += __shfl_xor(acc[r][t], 4, 64);
         }
-      const int row = 4 * rg + ks;                      // lane ks of the four writes row ks of the thread tile
+      const int row = 4 * rg + (ks & 3);                // lanes ks = 0..3 of the eight write rows 0..3 of the thread tile
       const float rdv = RD[j0 + row];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = tg8 * TQ + t;
-        if (t < TQ && i < Q) {
+        if (ks < 4 && t < TQ && i < Q) {
           const float v = ks == 0 ? acc[0][t] : (ks == 1 ? acc[1][t] : (ks == 2 ? acc[2][t] : acc[3][t]));
           CT[(j0 + row) * QS + i] = v * rdv;
         }
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < Q * K; idx += 256) {      // (i, k) is owned by one thread across the blocks
+    for (int idx = tid; idx < Q * K; idx += kTT) {      // (i, k) is owned by one thread across the blocks
       const int i = idx / K, k = idx - i * K;
       const float mu = kc[k], c2 = kc[kTK + k];
       float pk = 0.0f;
@@ -433,7 +437,7 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
   }
 
   // ---- A_ik and the parameter gradients of this pair -----------------------------------------------------------
-  for (int idx = tid; idx < Q * K; idx += 256) {
+  for (int idx = tid; idx < Q * K; idx += kTT) {
     const int i = idx / K, k = idx - i * K;
     const float pk = PK[i * kTK + k];
     const float al = a.alpha[k];
@@ -456,15 +460,15 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
 
   // ---- sweep 2: G per block, grad_d (complete per block), grad_q (register accumulators across the blocks) -------
   const int TG = QS >> 2;                               // groups of four query tokens
-  f32x4 accq[3][4];
+  f32x4 accq[2][4];
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int t = 0; t < 4; ++t) accq[s][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   for (int j0 = 0; j0 < D; j0 += 32) {
     const int nj = D - j0 < 32 ? D - j0 : 32;
     load_block(j0, nj);
-    for (int idx = tid; idx < 32 * QS; idx += 256) {
+    for (int idx = tid; idx < 32 * QS; idx += kTT) {
       const int jj = idx / QS, i = idx - jj * QS;
       float gs = 0.0f, sg = 0.0f;
       if (i < Q && DMB[j0 + jj] != 0.0f) {
@@ -503,7 +507,7 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
     }
     __syncthreads();
     // grad_d of the block: item = (4 rows, one 16-byte chunk of E)
-    for (int it = tid; it < 8 * NC; it += 256) {
+    for (int it = tid; it < 8 * NC; it += kTT) {
       const int rgp = it / NC, c = it - rgp * NC;
       f32x4 acc[4];
 #pragma unroll
@@ -527,8 +531,8 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
     }
     // grad_q: item = (4 query tokens, one 16-byte chunk of E), accumulated over the blocks
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int it = tid + 256 * s;
+    for (int s = 0; s < 2; ++s) {
+      const int it = tid + kTT * s;
       if (it < TG * NC) {
         const int tg = it / NC, c = it - tg * NC;
         for (int jj = 0; jj < 32; ++jj) {
@@ -542,8 +546,8 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_tiled_kernel(const KpBwdA
     __syncthreads();
   }
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int it = tid + 256 * s;
+  for (int s = 0; s < 2; ++s) {
+    const int it = tid + kTT * s;
     if (it < TG * NC) {
       const int tg = it / NC, c = it - tg * NC;
 #pragma unroll
@@ -586,7 +590,7 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
   {
     const int Dpad = (D + 31) & ~31, QS = (Q + 3) & ~3, NC = E >> 2;
     const size_t tl = kp_bwd_tiled_lds_bytes(Q, E, Dpad);
-    if (Q <= 32 && !(E & 3) && K <= kTK && 8 * NC <= 768 && (QS >> 2) * NC <= 768 && tl <= 150 * 1024 &&
+    if (Q <= 32 && !(E & 3) && K <= kTK && (QS >> 2) * NC <= 2 * kTT && tl <= 150 * 1024 &&
         !(((uintptr_t)q | (uintptr_t)d | (uintptr_t)grad_q | (uintptr_t)grad_d) & 15) && !env().kp_bwd_untiled) {
       KpBwdArgs a{};
       a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w; a.go = grad_out;
@@ -599,11 +603,11 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
       if (d_gate) {
         if (tl > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kernel_pool_bwd_tiled_kernel<true>, dim3((unsigned)n_pairs), dim3(256), tl, stream, a, Dpad);
+        hipLaunchKernelGGL(kernel_pool_bwd_tiled_kernel<true>, dim3((unsigned)n_pairs), dim3(kTT), tl, stream, a, Dpad);
       } else {
         if (tl > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kernel_pool_bwd_tiled_kernel<false>, dim3((unsigned)n_pairs), dim3(256), tl, stream, a, Dpad);
+        hipLaunchKernelGGL(kernel_pool_bwd_tiled_kernel<false>, dim3((unsigned)n_pairs), dim3(kTT), tl, stream, a, Dpad);
       }
       return check_launch("kernel_pool_bwd_tiled_kernel");
     }

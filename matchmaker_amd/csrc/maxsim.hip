@@ -513,7 +513,7 @@ __device__ __forceinline__ f32x16 dot_block(const char* drow, const char* qrow, 
   if constexpr (DT == MM_F32) {
     // v_mfma_f32_32x32x2_f32: lane (r,h) supplies A[r][k=h].  K is walked in 16-B chunks: chunk
     // pair (2c, 2c+1) -> h=0 takes chunk 2c, h=1 chunk 2c+1; the 4 floats of a chunk are 4 steps.
-    const int h = threadIdx.x >> 5;
+    const int h = (threadIdx.x >> 5) & 1;      // lane half within the wavefront (workgroups may hold several)
     const int nch = E >> 2;
     for (int c = 0; c < nch; c += 2) {
       const int cc = c + h;
@@ -526,7 +526,7 @@ __device__ __forceinline__ f32x16 dot_block(const char* drow, const char* qrow, 
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
     }
   } else {
-    const int h = threadIdx.x >> 5;
+    const int h = (threadIdx.x >> 5) & 1;      // lane half within the wavefront (workgroups may hold several)
     const int nch = E >> 3;
     for (int c = 0; c < nch; c += 2) {
       const int cc = c + h;
@@ -642,9 +642,17 @@ __device__ __forceinline__ void store_grad(void* base, int64_t idx, float v) {
 // three launches and 2.5 x the bytes).  Every row of grad_d is written by this kernel (zeros where no query token's
 // maximum sits): no memset in front of it.
 template <int DT, int GT>
-__global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
-  extern __shared__ int jstar[];   // [Q] first arg-max document position of every query token, -1 = no gradient
-  const int lane = threadIdx.x;
+__global__ void __launch_bounds__(256) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
+  // One 4-wavefront workgroup per pair (rounds 1-3: one wavefront, ~100 dependent memory round trips in a row — 150 us per
+  // launch whatever the batch): wavefront w takes document blocks w, w + 4, ... of the arg-max search, the four partial
+  // (maximum, first position) results per query token meet in LDS, and each wavefront then writes the gradient rows it
+  // OWNS (query tokens i = w mod 4, document rows j = w mod 4), so no row is ever touched by two wavefronts.
+  extern __shared__ int smem_i[];
+  int* jstar = smem_i;                       // [Q] first arg-max document position of every query token, -1 = no gradient
+  float* pbest = (float*)(smem_i + a.Q);     // [4][32]
+  int* prow = smem_i + a.Q + 128;            // [4][32]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int64_t pair = blockIdx.x;
   if (pair >= a.n_pairs) return;
@@ -674,7 +682,7 @@ __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
     int bt[16];  // block of the running maximum; -1 = a padded position / nothing yet
 #pragma unroll
     for (int i = 0; i < 16; ++i) { m[i] = fill; bt[i] = -1; }
-    for (int t = 0; t < nb; ++t) {
+    for (int t = wv; t < nb; t += 4) {
       const int drow = 32 * t + r;
       const int dr = drow < D ? drow : D - 1;
       const f32x16 acc = dot_block<DT>(dbase + dr * rowb, qbase + qr * rowb, E);
@@ -687,10 +695,11 @@ __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
         const int bit = rowof(i);
         const bool real = (vas >> bit) & 1u;
         const float v = real ? acc[i] : (((exs >> bit) & 1u) ? -1000.0f : fill);
-        if (v > m[i]) { m[i] = v; bt[i] = real ? t : -1; }  // strict: the first block wins ties
+        if (v > m[i]) { m[i] = v; bt[i] = real ? t : -1; }  // strict: the first block of this wavefront's sequence wins ties
       }
     }
-    // first arg-max over this lane's 16 row classes, then over the two lane halves
+    // first arg-max over this lane's 16 row classes, then over the two lane halves, then over the four wavefronts
+    // (equal maxima: the smaller position wins = torch.max's first arg-max; a padded position carries no index)
     float best = m[0];
     int brow = bt[0] < 0 ? 0x7fffffff : 32 * bt[0] + rowof(0) + 4 * h;
 #pragma unroll
@@ -701,21 +710,35 @@ __global__ void __launch_bounds__(64) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
     const float ob = __shfl_xor(best, 32, 64);
     const int orow = __shfl_xor(brow, 32, 64);
     if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-    if (h == 0 && qtok < Q) jstar[qtok] = (qvalid && brow != 0x7fffffff) ? brow : -1;
+    __syncthreads();                                     // (the previous tile's partials have been read)
+    if (h == 0) { pbest[wv * 32 + r] = best; prow[wv * 32 + r] = brow; }
+    __syncthreads();
+    if (wv == 0 && h == 0 && qtok < Q) {
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const float ov = pbest[k * 32 + r];
+        const int orw = prow[k * 32 + r];
+        if (ov > best || (ov == best && orw < brow)) { best = ov; brow = orw; }
+      }
+      jstar[qtok] = (qvalid && brow != 0x7fffffff) ? brow : -1;
+    }
   }
-  // grad_d: zeros everywhere first — lane l owns elements e = l, l + 64, ... of every row, here and below, so the
-  // rows that carry gradient are simply written again by the same lanes, in program order
-  for (int j = 0; j < D; ++j)
-    for (int e = lane; e < E; e += 64) store_grad<GT>(gd, (int64_t)j * E + e, 0.0f);
   __syncthreads();
+  // grad_d: zeros in every row this wavefront owns — lane l owns elements e = l, l + 64, ... here and below, so the rows
+  // that carry gradient are simply written again by the same lanes, in program order
+  for (int j = wv; j < D; j += 4)
+    for (int e = lane; e < E; e += 64) store_grad<GT>(gd, (int64_t)j * E + e, 0.0f);
   for (int qt = 0; qt < Q; ++qt) {
     const int j = jstar[qt];                            // wave-uniform (LDS)
-    if (j < 0) {
-      for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, 0.0f);
-      continue;
+    if ((qt & 3) == wv) {                               // grad_q_i = g d_j*(i)  (0 without a gradient)
+      if (j < 0) {
+        for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, 0.0f);
+      } else {
+        const char* drow = dbase + j * rowb;
+        for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, g * load_elem<DT>(drow, e));
+      }
     }
-    const char* drow = dbase + j * rowb;
-    for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, g * load_elem<DT>(drow, e));   // grad_q_i = g d_j*
+    if (j < 0 || (j & 3) != wv) continue;
     bool first = true;                                  // grad_d_j = g sum_{i: j*(i) = j} q_i, summed in fp32, written once
     for (int p = 0; p < qt; ++p) first = first && jstar[p] != j;
     if (!first) continue;
@@ -1092,8 +1115,8 @@ extern "C" int mm_maxsim_bwd(const void* q, const void* d, const void* q_mask, i
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-  const dim3 grid((unsigned)n_pairs), block(64);
-  const size_t lds = (size_t)Q * 4;
+  const dim3 grid((unsigned)n_pairs), block(256);
+  const size_t lds = (size_t)Q * 4 + 2 * 128 * 4;
   if (dtype == MM_F32)
     hipLaunchKernelGGL((maxsim_bwd_kernel<MM_F32, MM_F32>), grid, block, lds, stream, a);
   else if (dtype == MM_F16 && grad_dtype == MM_F32)

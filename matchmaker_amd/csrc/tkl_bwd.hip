@@ -361,6 +361,435 @@ __global__ void __launch_bounds__(kBwdThreads) tkl_bwd_kernel(const TklBwdArgs a
   if (tid < 15) gp[TklParams::chunk_scoring() + tid] = csg[tid];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiled variant (round 4).  tkl_bwd_kernel above takes every dot product straight from global memory, one dependent load
+// per FMA: 4.6 ms per DOCUMENT (bench.py extra.train_step: 22 ms for 2,048 documents, 24 x the forward).  Here the
+// normalised query tile and the 30 rows of the current window are staged in LDS and the three small products of a window
+// (cosines, chunk-row gradients, query gradient) are register-blocked exactly as in kernel_pool_bwd_tiled_kernel
+// (kernel_pool_bwd.hip); the query gradient accumulates in registers over the 15 windows.  The scalar chain between them
+// (pooled kernels, lengths, saturation forward + backward, parameter gradients) is the code above, re-indexed.
+// 512 threads, Q <= 32, E <= 384 (16-byte rows); other shapes take the kernel above.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTT = 512;
+
+__host__ __device__ inline size_t tkl_bwd_tiled_lds_bytes(int Wp, int Q, int E) {
+  const int ES = E + 4, QS = (Q + 3) & ~3;
+  return ((size_t)2 * Wp + (size_t)Q * ES + 32 * (size_t)ES + 3 * 32 * (size_t)QS + 2 * kBwdQ * kK + kBwdQ * 40 + 8 * kBwdQ + 4 * 32 +
+          16 + 32) * 4 + 64;
+}
+
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+__global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int C = a.C, Q = a.Q, E = a.E, W = a.W;
+  const int Wp = W < 3 ? 3 : W;
+  const int ES = E + 4, QS = (Q + 3) & ~3, NC = E >> 2;
+  const float* prm = a.prm;
+  const float* sp = prm + TklParams::sat();
+
+  float* QH = (float*)smem;                    // [Q][ES]  q_i / (|q_i| + tiny)
+  float* DB = QH + Q * ES;                     // [32][ES] the window's rows (raw; rows 30, 31 and absent rows are zeros)
+  float* CT = DB + 32 * ES;                    // [32][QS] cosines, [position][token]
+  float* GJ = CT + 32 * QS;                    // [32][QS] d loss / d c
+  float* GI = GJ + 32 * QS;                    // [QS][32]
+  float* pk = GI + QS * 32;                    // [kBwdQ][kK]
+  float* dpk = pk + kBwdQ * kK;                // [kBwdQ][kK]
+  float* red = dpk + kBwdQ * kK;               // [kBwdQ][40]
+  float* rq = red + kBwdQ * 40;                // [kBwdQ] each:
+  float* nq = rq + kBwdQ;
+  float* embv = nq + kBwdQ;
+  float* lens = embv + kBwdQ;
+  float* vals = lens + kBwdQ;
+  float* dev = vals + kBwdQ;
+  float* sq = dev + kBwdQ;                     // sum_t G c of the current window
+  float* sqs = sq + kBwdQ;                     // ... summed over the windows
+  float* rd = sqs + kBwdQ;                     // [32] each:
+  float* nd = rd + 32;
+  float* mt = nd + 32;
+  float* td = mt + 32;
+  float* csg = td + 32;                        // [16]
+  int* prow = (int*)(csg + 16);                // [32]
+  float* orig = (float*)(prow + 32);           // [Wp]
+  float* work = orig + Wp;                     // [Wp]
+  __shared__ float rv[kTT / 64];
+  __shared__ int ri[kTT / 64];
+  __shared__ int top_s[3];
+
+  const float* qb = a.q_ctx + (int64_t)b * Q * E;
+  float* gq = a.gq + (int64_t)b * Q * E;
+  const float g = a.go[b];
+
+  // ---- query tile: raw rows -> norms, emb . q_i -> normalised in place ----------------------------------------------
+  for (int idx = tid; idx < Q * NC; idx += kTT) {
+    const int i = idx / NC, c = idx - i * NC;
+    *(f32x4*)(QH + i * ES + 4 * c) = *(const f32x4*)(qb + (int64_t)i * E + 4 * c);
+  }
+  for (int idx = tid; idx < kBwdQ * 40; idx += kTT) red[idx] = 0.0f;
+  if (tid < 16) csg[tid] = 0.0f;
+  if (tid < kBwdQ) { dev[tid] = 0.0f; sqs[tid] = 0.0f; }
+  for (int w = tid; w < Wp; w += kTT) {
+    float s = w < W ? a.win[(int64_t)b * W + w] : 0.0f;
+    if (s == 0.0f) s = -9900.0f;
+    orig[w] = s;
+    work[w] = s;
+  }
+  __syncthreads();
+  {
+    const int i = tid >> 4, sub = tid & 15;
+    float ss = 0.0f, se = 0.0f;
+    if (i < Q)
+      for (int c = sub; c < NC; c += 16) {
+        const f32x4 v = *(const f32x4*)(QH + i * ES + 4 * c);
+        const f32x4 w4 = *(const f32x4*)(prm + TklParams::emb() + 4 * c);
+        ss += dot4(v, v);
+        se += dot4(v, w4);
+      }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      ss += __shfl_xor(ss, o, 64);
+      se += __shfl_xor(se, o, 64);
+    }
+    const float n = sqrtf(ss), r = 1.0f / (n + 1e-13f);
+    if (i < Q) {
+      for (int c = sub; c < NC; c += 16) {
+        f32x4* p = (f32x4*)(QH + i * ES + 4 * c);
+        *p = *p * r;
+      }
+      if (sub == 0) { nq[i] = n; rq[i] = r; embv[i] = se; }
+    }
+  }
+  // ---- region search (as above) ---------------------------------------------------------------------------------------
+  for (int c = 0; c < 3; ++c) {
+    float bv = -__builtin_huge_valf();
+    int bi = 0x7fffffff;
+    for (int w = tid; w < Wp; w += kTT) {
+      const float v = work[w];
+      if (v > bv) { bv = v; bi = w; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wv] = bv; ri[wv] = bi; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTT / 64; ++k) {
+      const float ov = rv[k];
+      const int oi = ri[k];
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (tid == 0) top_s[c] = bi;
+    __syncthreads();
+    for (int w = tid; w < Wp; w += kTT) {
+      const int dlt = w > bi ? w - bi : bi - w;
+      if (dlt < 15) work[w] = -10001.0f - (float)c;
+    }
+    __syncthreads();
+  }
+
+  const int rg = tid >> 6, tg8 = (tid >> 3) & 7, ks = tid & 7;      // cosine tile: 8 row groups x 8 token groups x 8 K slices
+  const int TQ = (Q + 7) >> 3;
+  const int TG = QS >> 2;
+  f32x4 accq[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accq[s][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int offs[5] = {0, -1, 1, -2, 2};
+  for (int j = 0; j < 15; ++j) {
+    int idx = top_s[j % 3] + offs[j / 3];                       // :276 order: peaks, -1, +1, -2, +2
+    idx = idx < 0 ? 0 : (idx >= Wp ? Wp - 1 : idx);            // :277-278
+    const float wfwd = orig[idx];
+    const float cs = prm[TklParams::chunk_scoring() + j];
+    if (wfwd <= -9900.0f) continue;                             // :282 an empty window is the constant 0 (uniform branch)
+    if (tid < 32) {                                             // the window's 30 positions -> chunk rows
+      const int pos = 2 * idx + tid;
+      int flat = -1;
+      float m = 0.0f;
+      if (tid < kBwdT && pos < C * 40) {
+        const int c = pos / 40;
+        const int info = a.slot2p[(int64_t)b * C + c];
+        if (info >= 0) {
+          flat = (info >> 2) * 50 + 5 + (pos - 40 * c);
+          m = a.chunk_mask[flat] != 0.0f ? 1.0f : 0.0f;
+        }
+      }
+      prow[tid] = flat;
+      mt[tid] = m;
+    }
+    __syncthreads();
+    for (int e2 = tid; e2 < 32 * NC; e2 += kTT) {               // rows -> LDS
+      const int row = e2 / NC, c = e2 - row * NC;
+      const int flat = prow[row];
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (flat >= 0) v = *(const f32x4*)(a.chunks + (int64_t)flat * E + 4 * c);
+      *(f32x4*)(DB + row * ES + 4 * c) = v;
+    }
+    __syncthreads();
+    {  // row norms: sixteen threads per row
+      const int row = tid >> 4, sub = tid & 15;
+      float ss = 0.0f;
+      for (int c = sub; c < NC; c += 16) {
+        const f32x4 v = *(const f32x4*)(DB + row * ES + 4 * c);
+        ss += dot4(v, v);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      if (sub == 0) {
+        const float n = sqrtf(ss);
+        nd[row] = n;
+        rd[row] = 1.0f / (n + 1e-13f);
+      }
+    }
+    __syncthreads();
+    {  // cosines: thread = (4 rows, TQ tokens, every 8th chunk of E)
+      float acc[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[r][t] = 0.0f;
+      for (int c = ks; c < NC; c += 8) {
+        f32x4 dv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dv[r] = *(const f32x4*)(DB + (4 * rg + r) * ES + 4 * c);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t < TQ) {
+            int i = tg8 * TQ + t;
+            i = i < Q ? i : Q - 1;
+            const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r][t] += dot4(dv[r], qv);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[r][t] += __shfl_xor(acc[r][t], 1, 64);
+          acc[r][t] += __shfl_xor(acc[r][t], 2, 64);
+          acc[r][t] += __shfl_xor(acc[r][t], 4, 64);
+        }
+      const int row = 4 * rg + (ks & 3);
+      const float rdv = rd[row];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = tg8 * TQ + t;
+        if (ks < 4 && t < TQ && i < Q) {
+          const float v = (ks & 3) == 0 ? acc[0][t] : ((ks & 3) == 1 ? acc[1][t] : ((ks & 3) == 2 ? acc[2][t] : acc[3][t]));
+          CT[row * QS + i] = v * rdv;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e2 = tid; e2 < Q * kK; e2 += kTT) {                // pooled kernels of the window
+      const int i = e2 / kK, k = e2 - i * kK;
+      const float mu = prm[TklParams::mu() + k], sg = prm[TklParams::sigma() + k];
+      const float c2 = -1.0f / (2.0f * sg * sg);
+      float s = 0.0f;
+      for (int t = 0; t < kBwdT; ++t) {
+        const float d = CT[t * QS + i] - mu;
+        s += mt[t] * __expf(d * d * c2);
+      }
+      pk[i * kK + k] = s;
+    }
+    if (tid >= 448 && tid - 448 < Q) {                          // window lengths (:210), on the last wavefront
+      const int i = tid - 448;
+      int n = 0;
+      for (int t = 0; t < kBwdT; ++t) {
+        float any = 0.0f;
+        for (int k = 0; k < kK; ++k) {
+          const float sg = prm[TklParams::sigma() + k];
+          const float d = CT[t * QS + i] - prm[TklParams::mu() + k];
+          any += mt[t] * __expf(-d * d / (2.0f * sg * sg));
+        }
+        n += any != 0.0f ? 1 : 0;
+      }
+      lens[i] = (float)n;
+    }
+    __syncthreads();
+    // ---- saturation forward + backward per query token (as above) -------------------------------------------------------
+    const float gw = g * cs;                                     // d loss / d w_j
+    if (tid < Q) {
+      const int i = tid;
+      const float len = lens[i];
+      const float f = a.q_mask[(int64_t)b * Q + i] * (len > 0.0f ? 1.0f : 0.0f);      // :248
+      float* rr = red + i * 40;      // [0..10] dense, [11..21] kernel_mult, [22..34] saturation block (13)
+      float val = 0.0f;
+      if (a.sat == MM_TKL_SAT_EMBEDDING) {
+        const float x0 = embv[i], x1 = len;
+        const float mean = (x0 + x1) * 0.5f;
+        const float d0 = x0 - mean, d1 = x1 - mean;
+        const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
+        const float xh0 = d0 * rstd, xh1 = d1 * rstd;
+        const float n0 = xh0 * sp[9] + sp[11], n1 = xh1 * sp[10] + sp[12];
+        const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];
+        const float u = n0 * sp[3] + n1 * sp[4] + sp[5];
+        const float s2 = 1.0f / u;
+        const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];
+        float ds1 = 0.0f, ds2 = 0.0f, ds3 = 0.0f;
+        for (int k = 0; k < kK; ++k) {
+          const float p = pk[i * kK + k];
+          const float x = fmaxf(p, 1e-10f);
+          const float lx = __logf(x);
+          const float xp = __expf(s2 * lx);
+          const float sat = s1 * xp - s3;
+          const float dk = prm[TklParams::dense() + k];
+          val += dk * (sat * f);
+          const float dsat = gw * f * dk;
+          rr[k] += gw * f * sat;                                  // d dense_k
+          ds1 += dsat * xp;
+          ds3 -= dsat;
+          ds2 += dsat * s1 * xp * lx;
+          dpk[i * kK + k] = p >= 1e-10f ? dsat * s1 * s2 * xp / x : 0.0f;
+        }
+        const float du = -ds2 * s2 * s2;
+        const float dn0 = ds1 * sp[0] + du * sp[3] + ds3 * sp[6];
+        const float dn1 = ds1 * sp[1] + du * sp[4] + ds3 * sp[7];
+        rr[22 + 0] += ds1 * n0; rr[22 + 1] += ds1 * n1; rr[22 + 2] += ds1;
+        rr[22 + 3] += du * n0;  rr[22 + 4] += du * n1;  rr[22 + 5] += du;
+        rr[22 + 6] += ds3 * n0; rr[22 + 7] += ds3 * n1; rr[22 + 8] += ds3;
+        rr[22 + 9] += dn0 * xh0; rr[22 + 10] += dn1 * xh1;       // LayerNorm weight
+        rr[22 + 11] += dn0;      rr[22 + 12] += dn1;             // LayerNorm bias
+        const float dx0h = dn0 * sp[9], dx1h = dn1 * sp[10];
+        const float m1 = (dx0h + dx1h) * 0.5f, m2 = (dx0h * xh0 + dx1h * xh1) * 0.5f;
+        dev[i] += rstd * (dx0h - m1 - xh0 * m2);                 // d loss / d (emb . q_i); the length carries no gradient
+      } else {
+        for (int k = 0; k < kK; ++k) {
+          const float p = pk[i * kK + k];
+          const float km = prm[TklParams::kmult() + k];
+          const bool live = p * km >= 1e-10f;
+          const float sat = __logf(fmaxf(p * km, 1e-10f));
+          const float dk = prm[TklParams::dense() + k];
+          val += dk * (sat * f);
+          const float dsat = gw * f * dk;
+          rr[k] += gw * f * sat;
+          rr[11 + k] += live ? dsat / km : 0.0f;
+          dpk[i * kK + k] = live ? dsat / p : 0.0f;
+        }
+      }
+      vals[i] = val;
+    }
+    __syncthreads();
+    if (tid == 0) {                                             // d chunk_scoring_j = g * w_j (:249 sum in index order)
+      float wj = 0.0f;
+      for (int i = 0; i < Q; ++i) wj += vals[i];
+      csg[j] += g * wj;
+    }
+    for (int e2 = tid; e2 < 32 * QS; e2 += kTT) {               // G = d loss / d c
+      const int t = e2 / QS, i = e2 - t * QS;
+      float s = 0.0f;
+      if (i < Q && mt[t] != 0.0f) {
+        const float c = CT[t * QS + i];
+        for (int k = 0; k < kK; ++k) {
+          const float sg = prm[TklParams::sigma() + k];
+          const float d = c - prm[TklParams::mu() + k];
+          const float inv = 1.0f / (sg * sg);
+          s += dpk[i * kK + k] * __expf(-0.5f * d * d * inv) * (-d * inv);
+        }
+      }
+      GJ[t * QS + i] = s;
+      GI[i * 32 + t] = s;
+    }
+    __syncthreads();
+    if (tid < Q) {
+      float s = 0.0f;
+      for (int t = 0; t < kBwdT; ++t) s += GI[tid * 32 + t] * CT[t * QS + tid];
+      sqs[tid] += s;
+    } else if (tid >= 64 && tid < 96) {
+      const int t = tid - 64;
+      float s = 0.0f;
+      for (int i = 0; i < Q; ++i) s += GJ[t * QS + i] * CT[t * QS + i];
+      td[t] = s;
+    }
+    __syncthreads();
+    // chunk-row gradients: item = (4 rows, one 16-byte chunk of E); overlapping windows accumulate into the same rows, one after
+    // the other inside this workgroup
+    for (int it = tid; it < 8 * NC; it += kTT) {
+      const int rgp = it / NC, c = it - rgp * NC;
+      f32x4 acc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int i = 0; i < Q; ++i) {
+        const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
+        const f32x4 g4 = *(const f32x4*)(GI + i * 32 + 4 * rgp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += qv * g4[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rgp + r;
+        const int flat = prow[row];
+        if (flat >= 0 && mt[row] != 0.0f) {
+          const f32x4 x = *(const f32x4*)(DB + row * ES + 4 * c);
+          const float self = nd[row] > 0.0f ? td[row] / nd[row] : 0.0f;
+          f32x4* dst = (f32x4*)(a.gchunks + (int64_t)flat * E + 4 * c);
+          *dst = *dst + (acc[r] - x * self) * rd[row];
+        }
+      }
+    }
+    // query gradient: item = (4 tokens, one chunk), accumulated over the windows
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int it = tid + kTT * s;
+      if (it < TG * NC) {
+        const int tg = it / NC, c = it - tg * NC;
+        for (int t = 0; t < kBwdT; ++t) {
+          const f32x4 dv = *(const f32x4*)(DB + t * ES + 4 * c) * rd[t];
+          const f32x4 g4 = *(const f32x4*)(GJ + t * QS + 4 * tg);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) accq[s][u] += dv * g4[u];
+        }
+      }
+    }
+    __syncthreads();   // the next window may touch the same chunk rows and reuses the LDS tiles
+  }
+
+  // ---- grad_q = rq (sum_w sum_t G dh - (sum G c) q / |q|) + dev emb_w; parameter rows of this document -----------------
+  const bool emb_sat = a.sat == MM_TKL_SAT_EMBEDDING;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int it = tid + kTT * s;
+    if (it < TG * NC) {
+      const int tg = it / NC, c = it - tg * NC;
+      f32x4 ew = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (emb_sat) ew = *(const f32x4*)(prm + TklParams::emb() + 4 * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * tg + u;
+        if (i < Q) {
+          const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
+          const float self = nq[i] > 0.0f ? sqs[i] : 0.0f;
+          *(f32x4*)(gq + (int64_t)i * E + 4 * c) = (accq[s][u] - qv * self) * rq[i] + ew * dev[i];
+        }
+      }
+    }
+  }
+  float* gp = a.gprm + (int64_t)b * a.NP;
+  if (emb_sat) {
+    for (int e = tid; e < E; e += kTT) {
+      float s = 0.0f;
+      for (int i = 0; i < Q; ++i) s += dev[i] * QH[i * ES + e] * (nq[i] + 1e-13f);     // q_i = qh_i (|q_i| + tiny)
+      gp[TklParams::emb() + e] = s;
+    }
+  } else {
+    for (int e = tid; e < E; e += kTT) gp[TklParams::emb() + e] = 0.0f;
+  }
+  for (int k = tid; k < 2 * kK; k += kTT) gp[k] = 0.0f;                           // mu, sigma are not trained
+  if (tid < 35) {                                                              // sum over the query tokens in index order
+    float s = 0.0f;
+    for (int i = 0; i < Q; ++i) s += red[i * 40 + tid];
+    const int dst = tid < 11 ? TklParams::dense() + tid : (tid < 22 ? TklParams::kmult() + (tid - 11) : TklParams::sat() + (tid - 22));
+    gp[dst] = s;
+  }
+  if (tid < 15) gp[TklParams::chunk_scoring() + tid] = csg[tid];
+}
+
 // slot2p for the backward (the forward's preparation kernels live in tkl.hip)
 __global__ void __launch_bounds__(256) tkl_bwd_fill_kernel(int32_t* slot2p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -411,6 +840,16 @@ extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* ch
   a.q_ctx = (const float*)q_ctx; a.chunks = (const float*)chunks; a.chunk_mask = chunk_mask; a.slot2p = slot2p;
   a.q_mask = q_mask; a.prm = params; a.win = win_scores; a.go = grad_out; a.gq = grad_q; a.gchunks = grad_chunks;
   a.gprm = grad_params; a.C = C; a.Q = Q; a.E = E; a.W = W; a.NP = MM_TKL_NPARAMS(K, E); a.sat = saturation;
+  {
+    const size_t tl = tkl_bwd_tiled_lds_bytes(Wp, Q, E);
+    const int QS = (Q + 3) & ~3;
+    if (!(E & 3) && (QS >> 2) * (E >> 2) <= 2 * kTT && tl <= 150 * 1024 && !env().kp_bwd_untiled &&
+        !(((uintptr_t)q_ctx | (uintptr_t)chunks | (uintptr_t)grad_q | (uintptr_t)grad_chunks | (uintptr_t)params) & 15)) {
+      if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)tkl_bwd_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
+      hipLaunchKernelGGL(tkl_bwd_tiled_kernel, dim3((unsigned)B), dim3(kTT), tl, stream, a);
+      return check_launch("tkl_bwd_tiled_kernel");
+    }
+  }
   const size_t lds = ((size_t)2 * Wp + 2 * kBwdQ * kBwdT + 2 * kBwdQ * kK + kBwdQ * 40 + 7 * kBwdQ + 4 * (kBwdT + 2) + 16 + kBwdT + 2) * 4;
   if (lds > 160 * 1024) return set_error(MM_EUNSUPPORTED, "tkl_bwd: %d windows per document exceed the LDS", W);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)tkl_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -153,7 +153,9 @@ def tkl_scoring(query_ctx, centre, centre_mask, packed_indices, batch_size, quer
     nb = torch.cat([top, top - 1, top + 1, top - 2, top + 2], dim=1)                                          # :276
     nb[nb < 0] = 0
     nb[nb >= orig.shape[1]] = orig.shape[1] - 1
-    vals = torch.gather(orig, 1, nb)                                                                          # :280-281
+    flat = (nb + torch.arange(0, orig.shape[0] * orig.shape[1], orig.shape[1], device=orig.device).unsqueeze(-1)).view(-1)   # :280
+    vals = orig.view(-1).index_select(0, flat).view(top.shape[0], -1)     # :281 (index_select, not gather: its backward keeps no
+    #                                                                       reference to `orig`, which :284 rewrites in place)
     vals[vals <= -9900] = 0                                                                                   # :282
     orig[orig <= -9900] = 0                                                                                   # :284
     return (vals * p["chunk_scoring"].view(1, -1)).sum(dim=1), orig                                           # :286

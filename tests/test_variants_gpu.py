@@ -98,7 +98,9 @@ def test_gated_kernel_pool_vs_oracle(B, Q, D, E):
     ones = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev), alpha.to(dev),
                            w.to(dev), d_gate=torch.ones(B, D, device=dev))
     plain = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev), alpha.to(dev), w.to(dev))
-    np.testing.assert_allclose(ones.cpu().numpy(), plain.cpu().numpy(), atol=1e-5, rtol=1e-6)
+    # (two wavefronts per pair on the ungated call of a 2-pair batch, one on the gated one: fp32 summation order over up to
+    # 4,100 positions — 1.1e-4 on a score of 56 at D = 4100, a tenth of the contract's 1e-3)
+    np.testing.assert_allclose(ones.cpu().numpy(), plain.cpu().numpy(), atol=3e-4 if D > 1000 else 1e-5, rtol=1e-6)
 
 
 @pytest.mark.parametrize("B,Q,D,E", [(4, 20, 200, 300), (3, 30, 47, 64), (3, 12, 64, 128), (2, 25, 1500, 100)])
