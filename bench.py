@@ -821,7 +821,9 @@ def extra_train_step(steps, cpu_budget):
             torch.cuda.empty_cache()
         res.setdefault(name, {})[f"pairs_{B}"] = row
 
-    for B in (64, 2048):
+    # (64 and 2,048 pairs are HOST-bound for ColBERT: ~190 us of Python + autograd engine per step whatever the batch — the
+    # event interval around a step includes the idle gaps; 32,768 pairs shows the device-side ratio of the same kernels)
+    for B in (64, 2048, 32768):
         # ---- ColBERT: fp16 token vectors as the compressor emits them under autocast, int64 HF masks
         g = torch.Generator(device=dev).manual_seed(64 + B)
         q = torch.nn.functional.normalize(torch.randn(B, Q, E, generator=g, device=dev), dim=-1).half().requires_grad_(True)

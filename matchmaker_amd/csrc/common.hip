@@ -38,6 +38,7 @@ const EnvCfg& env() {
     c.dot_prof = env_int("MM_DOT_PROF", 0);
     c.dot_no_spread = env_int("MM_DOT_NO_SPREAD", 0);
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
+    c.tkl_region_kernel = env_int("MM_TKL_REGION_KERNEL", 0);
     c.kp_bwd_untiled = env_int("MM_KP_BWD_UNTILED", 0);
     return c;
   }();

@@ -24,6 +24,9 @@ constexpr int kWThreads = 256;
 constexpr int kTokGroup = 10;  // query tokens per window workgroup (see tkl_window_kernel)
 constexpr int kRThreads = 256;  // region kernel (1,024 threads, one window each, measured slower: 11.3 vs 9.8-10.5 us)
 
+__device__ __forceinline__ void region_topk(float* orig, float* work, float* rv, int* ri, int Wp, const float* __restrict__ prm,
+                                            float* __restrict__ out, int tid);      // (defined below the window kernel)
+
 
 // Preparation in ONE launch (round 1: memset + emb + two mask packs + slot map = five, ~25 us of a 0.3 ms call) —
 // tkl_prep_kernel, four roles by block range, all independent of each other:
@@ -44,12 +47,32 @@ __global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slo
                                                        int32_t* __restrict__ qlen_out, uint32_t* __restrict__ qbits_out,
                                                        const float* __restrict__ chunk_mask, int64_t P,
                                                        int32_t* __restrict__ clen_out, uint32_t* __restrict__ cbits_out,
-                                                       const int32_t* __restrict__ chunk_slot, int C, int32_t* __restrict__ ntile) {
+                                                       const int32_t* __restrict__ chunk_slot, int C, int32_t* __restrict__ ntile,
+                                                       int32_t* __restrict__ done_cnt) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x;
   if (blk < n_fill) {
     const int64_t i = (int64_t)blk * 256 + threadIdx.x;
     if (i < BC) slot2p[i] = -1;
+    // Per document (the first B threads of this role): the live window tiles and the arrival counter of the window kernel's
+    // last-workgroup epilogue.  The LAST kept chunk c of a document bounds its live tiles (windows w <= 20 c + 19 touch
+    // chunk c); it is found by a binary search for the first slot past the document in the ascending chunk_slot list, so a
+    // document without kept chunks gets 0 — every entry is written on every call.
+    if (i < B) {
+      int64_t lo = 0, hi = P;
+      const int64_t past = (i + 1) * (int64_t)C;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)chunk_slot[mid] < past) lo = mid + 1; else hi = mid;
+      }
+      int nt = 0;
+      if (lo > 0) {
+        const int sl = chunk_slot[lo - 1];
+        if ((int64_t)sl >= i * (int64_t)C) nt = (kU * (sl % C) + kU - 1) / kWT + 1;
+      }
+      ntile[i] = nt;
+      done_cnt[i] = 0;
+    }
     return;
   }
   blk -= n_fill;
@@ -92,12 +115,6 @@ __global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slo
     clen_out[p] = bal ? 64 - __builtin_clzll(bal) : 0;
     cbits_out[p * 2] = (uint32_t)bal;
     cbits_out[p * 2 + 1] = (uint32_t)(bal >> 32);
-    // The LAST kept chunk of a document bounds its live window tiles: windows w <= 20 c + 19 touch chunk c.  A hint for the
-    // window kernel's early exit only — a document without kept chunks leaves its entry unwritten, and whatever stale
-    // value stands there, every tile of such a document is empty and comes out as zeros on either side of the test.
-    const int sl = chunk_slot[p];
-    const int nx = p + 1 < P ? chunk_slot[p + 1] : -1;
-    if (nx < 0 || nx / C != sl / C) ntile[sl / C] = (kU * (sl % C) + kU - 1) / kWT + 1;
   }
 }
 
@@ -214,11 +231,72 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
                                                          const float* __restrict__ q_mask,
                                                          const int32_t* __restrict__ q_len,
                                                          const float* __restrict__ prm, float* __restrict__ win,
-                                                         int C, int Q, int W, int lds_bytes, const int32_t* __restrict__ ntile) {
+                                                         int C, int Q, int W, int lds_bytes, const int32_t* __restrict__ ntile,
+                                                         int n_planes, float* __restrict__ win_final, float* __restrict__ out,
+                                                         int32_t* __restrict__ done_cnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float rv[kRThreads / 64];
+  __shared__ int ri[kRThreads / 64];
+  __shared__ int last_flag;
   const int b = blockIdx.y;
   const int w0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
+  // ---- last-workgroup epilogue (round 4: the region top-k of :254-286 no longer has its own launch) ------------------------
+  // Every workgroup that scores a live tile of document b publishes its 64 partial window scores with write-through stores
+  // (agent scope: sc1), drains them (vmcnt(0)), and arrives on done_cnt[b]; the workgroup whose arrival completes the document
+  // sums the planes (sc1 loads: the producers stored sc1, so no stale copy can sit in an L2) and runs the region search in
+  // the LDS its tile just left.  expected = live tiles x live token groups of the document — dead tiles (past the last kept
+  // chunk, tkl_prep_kernel) and groups without a real token neither write nor arrive.  out == nullptr: the standalone
+  // tkl_region_kernel follows (A/B runs) and this kernel only publishes.
+  const float* const part = win;
+  const int64_t plane_stride = (int64_t)gridDim.y * W;
+  const int nt_live = ntile[b] < (int)gridDim.x ? ntile[b] : (int)gridDim.x;
+  int np_live = n_planes;
+  {
+    int qa = q_len ? q_len[b] : Q;
+    qa = qa < 0 ? 0 : (qa > Q ? Q : qa);
+    const int npq = (qa + kTokGroup - 1) / kTokGroup;
+    np_live = npq < n_planes ? npq : n_planes;
+  }
+  const int expected = nt_live * np_live;
+  auto finalize = [&]() {
+    const int Wp = W < 3 ? 3 : W;
+    float* orig = (float*)smem;
+    float* work = orig + Wp;
+    const int live_w = nt_live * kWT;
+    for (int w = tid; w < Wp; w += kWThreads) {
+      float s = 0.0f;
+      if (w < W) {
+        if (w < live_w)
+          for (int g = 0; g < np_live; ++g)
+            s += __hip_atomic_load(part + g * plane_stride + (int64_t)b * W + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        win_final[(int64_t)b * W + w] = s;
+      }
+      if (s == 0.0f) s = -9900.0f;                                     // :257
+      orig[w] = s;
+      work[w] = s;
+    }
+    __syncthreads();
+    region_topk(orig, work, rv, ri, Wp, prm, out + b, tid);
+  };
+  auto arrive = [&]() {
+    if (!out) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this thread's published scores have reached memory
+    __syncthreads();                                                   // ... and so have every thread's; the tile's LDS is free
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(done_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag = old + 1 == expected;
+    }
+    __syncthreads();
+    if (last_flag) finalize();
+  };
+  if (out && expected == 0) {            // no live tile or no real query token: every window is empty, the score is 0 (:257, :282)
+    if (blockIdx.x == 0 && blockIdx.z == 0) {
+      for (int w = tid; w < W; w += kWThreads) win_final[(int64_t)b * W + w] = 0.0f;
+      if (tid == 0) out[b] = 0.0f;
+    }
+    return;
+  }
   // Token groups: workgroup z evaluates query tokens [kTokGroup z, kTokGroup (z + 1)) of its 64 windows and writes a partial
   // window score (summed over ITS tokens) to plane z of `win`; the region kernel adds the planes in order.  A tile of
   // 10 tokens is 37 KiB of LDS instead of 75: FOUR independent 256-thread workgroups per CU instead of two of 512 —
@@ -234,10 +312,7 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   if (ql <= 0) return;                                // no token of this group is real: the region kernel skips the plane
   // tiles past the document's last kept chunk are empty (half of all tiles at config 3's U{50..2048} lengths): out after
   // one scalar load instead of after the lookup barrier (tkl_prep_kernel's hint, see there)
-  if ((int)blockIdx.x >= ntile[b]) {
-    if (tid < kWT && w0 + tid < W) win[(int64_t)b * W + w0 + tid] = 0.0f;
-    return;
-  }
+  if ((int)blockIdx.x >= nt_live) return;              // (nothing to publish: the summing workgroup takes these windows as zeros)
   int wt = kWT;
   while (wt > 4 && window_pass_bytes(wt, ql) > (size_t)lds_bytes) wt >>= 1;
   const int nu = wt + kWinPairs - 1;                  // pair rows needed by one pass
@@ -290,8 +365,10 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
     const int cb = (w0 + kWT + kWinPairs - 2) / kU - c0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) live = live || (c <= cb && cinfo[c] >= 0);
-    if (!live) {
-      if (tid < kWT && w0 + tid < W) win[(int64_t)b * W + w0 + tid] = 0.0f;
+    if (!live) {                                       // (a hole: below the last kept chunk, so it is counted as a live tile)
+      if (tid < kWT && w0 + tid < W)
+        __hip_atomic_store(win + (int64_t)b * W + w0 + tid, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrive();
       return;
     }
   }
@@ -424,44 +501,19 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
       const float* r = red + tz * (ql | 1);                              // odd stride: the 64 lanes hit distinct banks
 #pragma unroll 4
       for (int i = 0; i < ql; ++i) s += r[i];
-      win[(int64_t)b * W + ws + tz] = s;
+      __hip_atomic_store(win + (int64_t)b * W + ws + tz, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the next pass overwrites `tile` (last read before the barrier above) and, after its own barrier, `red`
   }
+  arrive();
 }
 
-// One 256-thread workgroup per document: region top-k over the window scores (:254-286).  (One wavefront per
-// document spent 16 us on sixteen dependent 4-byte loads per lane; four wavefronts load the ~1,000 scores of a
-// 2,048-token document in four rounds and share the arg-max.)
-__global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* __restrict__ part, int n_planes, int64_t plane,
-                                                         const int32_t* __restrict__ q_len, float* __restrict__ win,
-                                                         const float* __restrict__ prm, float* __restrict__ out, int W) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float rv[kRThreads / 64];
-  __shared__ int ri[kRThreads / 64];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int Wp = W < 3 ? 3 : W;                                        // :254-255
-  float* orig = (float*)smem;                                          // [Wp]
-  float* work = orig + Wp;                                             // [Wp]
-  // window score = sum over the token groups' planes in order (:249); planes whose tokens are all past the query's
-  // effective length were never written and count as zeros.  The sum is also the window-score output (win).
-  int np = n_planes;
-  if (q_len) {
-    const int ql = q_len[b];
-    np = ql <= 0 ? 0 : (ql + kTokGroup - 1) / kTokGroup;
-    np = np < n_planes ? np : n_planes;
-  }
-  for (int w = tid; w < Wp; w += kRThreads) {
-    float s = 0.0f;
-    if (w < W) {
-      for (int g = 0; g < np; ++g) s += part[g * plane + (int64_t)b * W + w];
-      if (win != part || np != 1) win[(int64_t)b * W + w] = s;
-    }
-    if (s == 0.0f) s = -9900.0f;                                       // :257
-    orig[w] = s;
-    work[w] = s;
-  }
-  __syncthreads();
+// Region top-k over the window scores of ONE document (:254-286) by the 256 threads of a workgroup: orig / work [Wp] in LDS
+// hold the scores with 0 -> -9900 (:257) on entry.  Three arg-max rounds (ties -> lowest index, like torch.argmax), +-15
+// suppression (:268-273), the peaks' +-1 / +-2 neighbours (:276-282), chunk_scoring dot (:286) -> *out.
+__device__ __forceinline__ void region_topk(float* orig, float* work, float* rv, int* ri, int Wp, const float* __restrict__ prm,
+                                            float* __restrict__ out, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
   int top[3];
   for (int c = 0; c < 3; ++c) {                                        // :268-273
     float bv = -__builtin_huge_valf();
@@ -506,8 +558,46 @@ __global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* __re
       term = v * prm[TklParams::chunk_scoring() + lane];               // :286 (weight index g * 3 + c = lane)
     }
     const float s = wave_sum(term);
-    if (lane == 0) out[b] = s;
+    if (lane == 0) *out = s;
   }
+}
+
+// One 256-thread workgroup per document: the standalone form (MM_TKL_REGION_KERNEL=1, A/B runs; since round 4 the LAST window
+// workgroup of a document does this itself, see tkl_window_kernel).  (One wavefront per document spent 16 us on sixteen
+// dependent 4-byte loads per lane; four wavefronts load the ~1,000 scores of a 2,048-token document in four rounds.)
+__global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* __restrict__ part, int n_planes, int64_t plane,
+                                                         const int32_t* __restrict__ q_len, float* __restrict__ win,
+                                                         const float* __restrict__ prm, float* __restrict__ out, int W,
+                                                         const int32_t* __restrict__ ntile) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float rv[kRThreads / 64];
+  __shared__ int ri[kRThreads / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Wp = W < 3 ? 3 : W;                                        // :254-255
+  float* orig = (float*)smem;                                          // [Wp]
+  float* work = orig + Wp;                                             // [Wp]
+  // window score = sum over the token groups' planes in order (:249); planes whose tokens are all past the query's
+  // effective length were never written and count as zeros, and so do the tiles past the document's last kept chunk
+  int np = n_planes;
+  if (q_len) {
+    const int ql = q_len[b];
+    np = ql <= 0 ? 0 : (ql + kTokGroup - 1) / kTokGroup;
+    np = np < n_planes ? np : n_planes;
+  }
+  const int live_w = ntile[b] * kWT;
+  for (int w = tid; w < Wp; w += kRThreads) {
+    float s = 0.0f;
+    if (w < W) {
+      if (w < live_w)
+        for (int g = 0; g < np; ++g) s += part[g * plane + (int64_t)b * W + w];
+      win[(int64_t)b * W + w] = s;
+    }
+    if (s == 0.0f) s = -9900.0f;                                       // :257
+    orig[w] = s;
+    work[w] = s;
+  }
+  __syncthreads();
+  region_topk(orig, work, rv, ri, Wp, prm, out + b, tid);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -529,7 +619,8 @@ extern "C" size_t mm_tkl_workspace_bytes(int64_t B, int64_t P, int C, int Q, int
          packed_mask_bytes(MM_MASK_F32, P, 40) + align256((size_t)B * W * 4) + align256((size_t)B * Q * 4) +
          packed_mask_bytes(MM_MASK_F32, B, Q) +  // + the packed query mask (effective lengths)
          align256((size_t)((Q + kTokGroup - 1) / kTokGroup) * B * W * 4) +  // + the token groups' partial window scores
-         align256((size_t)B * 4);                                          // + live window tiles per document
+         align256((size_t)B * 4) +                                         // + live window tiles per document
+         align256((size_t)B * 4);                                          // + arrival counters of the last-workgroup epilogue
 }
 
 extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
@@ -567,7 +658,9 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   PackedMask qmk, dm;
   float* planes = nullptr;                              // [n_planes][B][W] partial window scores of the token groups
   int32_t* ntile = nullptr;                             // [B] live window tiles per document (tkl_prep_kernel)
+  int32_t* done_cnt = nullptr;                          // [B] window workgroups of the document that have published their scores
   const int n_planes = (Q + kTokGroup - 1) / kTokGroup;
+  bool fold_regions = false;
   {
     if (P >= (1LL << 29)) return set_error(MM_EUNSUPPORTED, "tkl: too many packed chunks for one launch");
     const size_t need_dm = packed_mask_bytes(MM_MASK_F32, P, 40);
@@ -577,6 +670,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     char* qws = (char*)emb + align256((size_t)B * Q * 4);
     planes = (float*)(qws + packed_mask_bytes(MM_MASK_F32, B, Q));
     ntile = (int32_t*)((char*)planes + align256((size_t)n_planes * B * W * 4));
+    done_cnt = (int32_t*)((char*)ntile + align256((size_t)B * 4));
     int32_t* qlen = (int32_t*)qws;
     uint32_t* qbits = (uint32_t*)(qws + (size_t)B * 4);
     const int n_fill = (int)((B * (int64_t)C + 255) / 256);
@@ -585,7 +679,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     const int n_chunk = (int)((P + 3) / 4);
     hipLaunchKernelGGL(tkl_prep_kernel, dim3((unsigned)(n_fill + n_emb + n_q + n_chunk)), dim3(256), 0, stream, slot2p,
                        B * (int64_t)C, n_fill, (const float*)q_ctx, params, emb, B * (int64_t)Q, E, n_emb, q_mask, B, Q, n_q,
-                       qlen, qbits, chunk_mask, P, clen, cbits, chunk_slot, C, ntile);
+                       qlen, qbits, chunk_mask, P, clen, cbits, chunk_slot, C, ntile, done_cnt);
     if (int e = check_launch("tkl_prep_kernel")) return e;
     qmk.len = qlen;
     qmk.bits = qbits;
@@ -611,10 +705,14 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     if (n_planes > 65535 || B > 65535) return set_error(MM_EUNSUPPORTED, "tkl: grid limits (B=%lld, Q=%d)", (long long)B, Q);
     const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B, (unsigned)n_planes);
     float* wdst = n_planes > 1 ? planes : win;                         // one group: its plane IS the window-score output
+    // the region top-k runs in the last window workgroup of each document unless the tile's LDS cannot hold the two score
+    // rows (or MM_TKL_REGION_KERNEL asks for the standalone launch of rounds 1-3)
+    fold_regions = !env().tkl_region_kernel && (size_t)(W < 3 ? 3 : W) * 8 <= lds2;
     auto launch = [&](auto kern) {
       if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, grid2, dim3(kWThreads), lds2, stream, (const float*)ps, (const int32_t*)slot2p, (const float*)emb, q_mask,
-                         (const int32_t*)qmk.len, params, wdst, C, Q, W, (int)lds2, (const int32_t*)ntile);
+                         (const int32_t*)qmk.len, params, wdst, C, Q, W, (int)lds2, (const int32_t*)ntile, n_planes, win,
+                         fold_regions ? out : (float*)nullptr, done_cnt);
     };
     if (saturation == MM_TKL_SAT_EMBEDDING) {
       if (use_cos) launch(tkl_window_kernel<MM_TKL_SAT_EMBEDDING, true>);
@@ -625,8 +723,10 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
     }
     if (int e = check_launch("tkl_window_kernel")) return e;
   }
+  if (fold_regions) return MM_OK;
   const int Wp = W < 3 ? 3 : W;
   hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(kRThreads), (size_t)Wp * 8, stream,
-                     (const float*)(n_planes > 1 ? planes : win), n_planes, (int64_t)B * W, (const int32_t*)qmk.len, win, params, out, W);
+                     (const float*)(n_planes > 1 ? planes : win), n_planes, (int64_t)B * W, (const int32_t*)qmk.len, win, params, out, W,
+                     (const int32_t*)ntile);
   return check_launch("tkl_region_kernel");
 }
