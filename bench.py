@@ -812,6 +812,8 @@ def extra_train_step(steps, cpu_budget):
                "roofline": {"bound": "hbm", "achieved": by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         try:
+            if LEAN:
+                raise RuntimeError("skipped (--lean: the profiled run holds the native kernels only)")
             e_ms = gpu_time_ms(step_eager, max(3, n_timed // 2), warm_ms=20.0, timed_ms=15.0, max_calls=50)
             row["eager_gpu_baseline"] = {"step_us": 1e3 * e_ms, "kind": "port",
                                          "what": "oracle/torch_port.py statements + torch autograd on this GPU",

@@ -78,20 +78,27 @@ def test_dot_topk_one_rank_shard_of_config5():
     assert (s[:, :-1] >= s[:, 1:]).all() and (idx >= 0).all() and (idx < N).all()
     s2, idx2 = ops.dot_topk(q, c, k)
     assert torch.equal(s, s2) and torch.equal(idx, idx2), "non-deterministic"
-    sel = torch.tensor([0, 123, 3490, 6979], device=dev)
-    full = q[sel].float() @ c.float().T if False else torch.cat(
-        [q[sel].float() @ c[lo:lo + (1 << 18)].float().T for lo in range(0, N, 1 << 18)], dim=1)
+    # 256 sampled queries (every 27th + the planted one) against an fp32 checker: torch.topk over the fp32 products, formed
+    # in slabs of 2^18 passages (the full [256, 1.1 M] fp32 score matrix is 1.1 GB and stays on the device)
+    sel = torch.unique(torch.cat([torch.arange(0, nq, 27, device=dev)[:255], torch.tensor([123], device=dev)]))
+    full = torch.cat([q[sel].float() @ c[lo:lo + (1 << 18)].float().T for lo in range(0, N, 1 << 18)], dim=1)
     ref_s, ref_i = torch.topk(full, k, dim=1)
     np.testing.assert_allclose(s[sel].cpu().numpy(), ref_s.cpu().numpy(), atol=2e-3, rtol=1e-3)
-    for r in range(sel.numel()):
+    same = idx[sel] == ref_i                                            # identical rows in identical order
+    differing = torch.nonzero(~same.all(dim=1)).flatten().tolist()
+    for r in differing:
         got, want = set(idx[sel[r]].tolist()), set(ref_i[r].tolist())
-        # the sets agree except for candidates within accumulation noise of the k-th score
+        # the sets agree except for candidates within accumulation noise of the k-th score; inside the list two rows may
+        # swap places only when their fp32 scores are that close
         kth = float(ref_s[r, -1])
         for j in got ^ want:
             assert abs(float(full[r, j]) - kth) < 2e-3, (int(sel[r]), j)
+        pos = torch.nonzero(~same[r]).flatten()
+        assert float((full[r, idx[sel[r], pos]] - ref_s[r, pos]).abs().max()) < 2e-3, int(sel[r])
+    print(f"[dot top-k] {sel.numel()} sampled queries: {sel.numel() - len(differing)} lists identical to the fp32 checker's, "
+          f"{len(differing)} differ only among near-ties")
     # every returned score is the inner product of its row
-    rows = idx[sel]
-    chk = torch.stack([(c[rows[r]].float() @ q[sel[r]].float()) for r in range(sel.numel())])
+    chk = torch.gather(full, 1, idx[sel])
     np.testing.assert_allclose(s[sel].cpu().numpy(), chk.cpu().numpy(), atol=2e-3, rtol=1e-3)
 
 
