@@ -287,7 +287,7 @@ def extra_dropin_forward(q, d, q_len, d_len, steps):
             "dtype": "bf16", "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
             "bytes_per_pair": by // B, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                     "frac": gbs / HBM_PEAK_GBS},
-            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r03_dropin_forward_trace.json"}
+            "bit_identical_to_shared_q_scores": same, "profile": "profiles/r04_dropin_forward_trace.json"}
 
 
 def extra_sustained(score_shard, B, seconds=4.0):
@@ -349,10 +349,10 @@ def extra_tk(steps, cpu_budget):
     gbs = by / (ms * 1e-3) / 1e9
     out = {"workload": f"TK kernel pooling (ecai20_tk.py:105-124), {nq} queries x {C} candidates, Q={Qt}/D={Dt}/dim={Et}, "
                        f"all positions real, shared query tile, int32 lengths",
-           "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms,
+           "dtype": "fp32 (split-bf16 operands: x = hi + lo, 3 bf16 MFMAs hi.hi + lo.hi + hi.lo, fp32 accumulation)", "ms": ms,
            "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by, "flop": B * (2 * Qt * Dt * Et + 2 * (Qt + Dt) * Et),
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r03_tk_pmc.json, profiles/r03_tk_trace.json"}
+           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r04_tk_pmc.json, profiles/r04_tk_trace.json"}
     del q, d
     torch.cuda.empty_cache()
     try:
@@ -426,8 +426,8 @@ def extra_tkl(steps, cpu_budget):
            "dtype": "fp32 (split-bf16 operands: x = hi + lo, 4 bf16 MFMAs, fp32 accumulation)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "needed_bytes": by_needed, "frac_needed_bytes": by_needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> + tkl_region_kernel (whole mm_tkl_fwd call)",
-           "profile": "profiles/r03_tkl_pmc.json, profiles/r03_tkl_trace.json (full documents: profiles/r03_tklfull_pmc.json)"}
+           "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> (region top-k in its last workgroups): the whole mm_tkl_fwd call",
+           "profile": "profiles/r04_tkl_pmc.json, profiles/r04_tkl_trace.json (full documents: profiles/r04_tklfull_pmc.json)"}
     try:
         if not LEAN:
             out["exact_f32_mfma"] = tkl_exact_f32_subprocess()
@@ -672,7 +672,7 @@ def extra_published_checkpoint(steps, cpu_budget):
            "dtype": "f16", "ms": ms, "pairs_per_s": n / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
            "kernel": "pack_mask_kernel + maxsim_stream_kernel with two query tiles (NSL = 6, NQT = 2)",
-           "profile": "profiles/r03_published_checkpoint_trace.json"}
+           "profile": "profiles/r04_published_checkpoint_trace.json"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         m = 256
@@ -802,12 +802,17 @@ def extra_train_step(steps, cpu_budget):
     dev = torch.device("cuda", torch.cuda.current_device())
     res = {}
 
-    def leg(name, B, fwd, step_native, step_eager, fwd_bytes, grad_bytes, n_timed):
+    def leg(name, B, fwd, step_native, step_eager, fwd_bytes, grad_bytes, n_timed, bwd_op=None):
         with torch.no_grad():
             f_ms = gpu_time_ms(fwd, n_timed)
+            b_ms = gpu_time_ms(bwd_op, n_timed) if bwd_op is not None else None
         s_ms = gpu_time_ms(step_native, n_timed)
         by = 2 * fwd_bytes + grad_bytes
         row = {"pairs": B, "forward_us": 1e3 * f_ms, "step_us": 1e3 * s_ms, "backward_over_forward": (s_ms - f_ms) / f_ms,
+               # the backward operator called directly (no autograd engine around it): what the device spends once the
+               # call is large enough to hide the host (the `step` of a 64- or 2,048-pair ColBERT batch is host-bound)
+               "backward_op_us": None if b_ms is None else 1e3 * b_ms,
+               "backward_op_over_forward": None if b_ms is None else b_ms / f_ms,
                "algorithmic_bytes": by,
                "roofline": {"bound": "hbm", "achieved": by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -848,7 +853,7 @@ def extra_train_step(steps, cpu_budget):
             with torch.autocast("cuda", dtype=torch.float16):
                 TP.maxsim_forward(q, d, qm, dm).backward(go)
         leg("colbert_fp16_autocast_q32_d180_e128", B, c_fwd, c_native, c_eager, B * ((D + Q) * E * 2 + 8 * (D + Q) + 4),
-            B * (D + Q) * E * 4, steps)
+            B * (D + Q) * E * 2, steps, bwd_op=lambda: ops.maxsim_bwd(q, d, qm, dm, go, grad_dtype=q.dtype))
         del q, d
 
         # ---- TK pooling (tk.yaml: fp32, Q = 20 / D = 200 / dim = 300)
@@ -877,7 +882,7 @@ def extra_train_step(steps, cpu_budget):
             zero()
             TP.tk_kernel_pool(tq, td, tqm, tdm, mu.view(1, 1, 1, -1), sg.view(1, 1, 1, -1), al.view(1, 1, -1), w.view(1, -1)).backward(go)
         leg("tk_pooling_q20_d200_e300", B, t_fwd, t_native, t_eager, B * ((Dt + Qt) * Et * 4 + 4 * (Dt + Qt) + 4),
-            B * (Dt + Qt) * Et * 4 + 2 * B * 11 * 4, steps)
+            B * (Dt + Qt) * Et * 4 + 2 * B * 11 * 4, steps, bwd_op=lambda: ops.kernel_pool_bwd(tq, td, tqm, tdm, mu, sg, al, w, go))
         del tq, td
         torch.cuda.empty_cache()
 
@@ -927,7 +932,10 @@ def extra_train_step(steps, cpu_budget):
             TP.tkl_scoring(q_ctx, chunks[:, 5:-5], cm40, packed_idx, B, qm, prm, "embedding")[0].backward(go)
         fwd_bytes = P * 50 * Et * 4 + B * Qt * Et * 4 + P * 50 * 4 + 4 * B
         # the exact gradient touches at most 15 windows x 30 positions per document; grad_chunks is a full zero-filled tensor
-        leg("tkl_scoring_d2048_e300", B, l_fwd, l_native, l_eager, fwd_bytes, P * 50 * Et * 4 + B * Qt * Et * 4, max(3, steps // 2))
+        with torch.no_grad():
+            win0 = ops.tkl_score(q_ctx, chunks, cmask, slot, qm, packed, B, C, 11, "embedding", return_windows=True, check_order=False)[1]
+        leg("tkl_scoring_d2048_e300", B, l_fwd, l_native, l_eager, fwd_bytes, P * 50 * Et * 4 + B * Qt * Et * 4, max(3, steps // 2),
+            bwd_op=lambda: ops.tkl_bwd(q_ctx, chunks, cmask, slot, qm, packed, win0, go, B, C, 11, "embedding"))
         del chunks, q_ctx
         torch.cuda.empty_cache()
     res["note"] = ("step = forward + backward of the scoring block alone (encoders / contextualisers are PyTorch on both sides and "
