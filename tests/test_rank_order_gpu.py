@@ -335,7 +335,10 @@ def run_tkl_rank(name, nq=4, C=64):
     print(f"[rank parity] {name}: window error device {aw:.3e} / fp32 oracle {bw:.3e}; unstable documents {int((~stable).sum())} of {B}")
     assert (~stable).sum() <= B // 20, f"{name}: {int((~stable).sum())} of {B} documents differ beyond the window noise"
     assert aw <= 16 * bw + 1e-6
-    assert frac >= 0.98, f"{name}: only {frac:.4f} of the rank positions are decided"
+    # 256 positions: one borderline document is 0.4 %.  The fp32 ORACLE's own error (torch on the host's cores: its summation
+    # order follows the thread count) moves between boxes — 3.9e-5 on one, 8.7e-5 on another for these lists — and with it the
+    # tie bound and the set of documents that count as stable: 0.977-1.0 observed with identical device scores
+    assert frac >= 0.95, f"{name}: only {frac:.4f} of the rank positions are decided"
     return rows
 
 
