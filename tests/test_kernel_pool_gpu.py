@@ -352,3 +352,43 @@ def test_scores_of_a_pair_do_not_depend_on_the_batch_it_arrives_in_beyond_fp32_r
     gaps = np.abs(np.diff(a[order_a]))
     decided = np.concatenate([[True], gaps > 2 * diff]) & np.concatenate([gaps > 2 * diff, [True]])
     assert (order_a[decided] == order_b[decided]).all() and decided.mean() > 0.98
+
+
+@pytest.mark.parametrize("E,ppq,nq,D", [(300, 37, 70, 200), (100, 1000, 3, 64), (200, 5, 900, 40)])
+def test_candidate_lists_as_one_row_sequence_equal_the_document_by_document_kernel(E, ppq, nq, D):
+    """kernel_pool_cont_kernel (shared query tile + prefix lengths: the real rows of a wavefront's consecutive pairs form one
+    row sequence cut into 32-row blocks wherever they fall) against the pair-per-row call of the same pairs (each pair its own
+    query copy: kernel_pool_split_kernel, one document at a time) and against the oracle.  Lengths are chosen to hit every
+    seam: empty documents (also several in a row, at list ends and wavefront ends), 1 / 31 / 32 / 33 rows, full length, many
+    8-row documents (more than four segments per block), lists that straddle wavefront ranges."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(E + ppq)
+    Q = 20
+    B = nq * ppq
+    q = torch.randn(nq, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    special = torch.tensor([0, 0, 0, 1, 31, 32, 33, D, D, 8, 8, 8, 8, 8, 8, 2, 0, D - 1, 7, 0][: max(4, min(20, D))]).clamp(max=D)
+    d_len = torch.randint(0, D + 1, (B,), generator=g)
+    pos = torch.randint(0, B, (min(B, 400),), generator=g)
+    d_len[pos] = special[torch.arange(pos.numel()) % special.numel()]
+    d_len[:3] = 0
+    d_len[-2:] = 0
+    d_len[ppq - 1] = 0                                                 # the last document of the first list
+    q_len = torch.randint(1, Q + 1, (nq,), generator=g)
+    q_len[0] = Q
+    prm = [torch.tensor(MU), torch.tensor(SIGMA), torch.rand(11, generator=g) + 0.5, torch.randn(11, generator=g) * 0.3]
+    dp = [t.to(dev) for t in prm]
+    out, pk = ops.kernel_pool(q.to(dev), d.to(dev), q_len.to(dev), d_len.to(dev), *dp, pairs_per_query=ppq, return_per_kernel=True)
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float().repeat_interleave(ppq, 0)
+    out_pp, pk_pp = ops.kernel_pool(q.repeat_interleave(ppq, 0).contiguous().to(dev), d.to(dev), qm.to(dev), d_len.to(dev), *dp,
+                                    pairs_per_query=1, return_per_kernel=True)
+    # same arithmetic per row; only the summation order over a document's rows differs (blocks fall elsewhere)
+    np.testing.assert_allclose(out.cpu().numpy(), out_pp.cpu().numpy(), atol=3e-5, rtol=2e-6)
+    np.testing.assert_allclose(pk.cpu().numpy(), pk_pp.cpu().numpy(), atol=2e-3, rtol=2e-5)
+    assert torch.equal(out, ops.kernel_pool(q.to(dev), d.to(dev), q_len.to(dev), d_len.to(dev), *dp, pairs_per_query=ppq))
+    sel = torch.cat([torch.arange(0, min(B, 3 * ppq)), torch.arange(max(0, B - 50), B)]).unique()
+    dm = (torch.arange(D)[None] < d_len[sel, None]).float()
+    ref = O.tk_kernel_pool(q[sel // ppq].numpy(), d[sel].numpy(), qm[sel].numpy(), dm.numpy(), MU, SIGMA, prm[2].numpy(), prm[3].numpy(),
+                           dtype=np.float64)
+    np.testing.assert_allclose(out[sel.to(dev)].cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
