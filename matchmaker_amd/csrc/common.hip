@@ -40,7 +40,6 @@ const EnvCfg& env() {
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
     c.tkl_region_kernel = env_int("MM_TKL_REGION_KERNEL", 0);
     c.kp_bwd_untiled = env_int("MM_KP_BWD_UNTILED", 0);
-    c.kp_no_cont = env_int("MM_KP_NO_CONT", 0);
     return c;
   }();
   return cfg;

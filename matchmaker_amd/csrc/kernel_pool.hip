@@ -745,322 +745,6 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
 }
 
 // ---------------------------------------------------------------------------------------------
-// TK pooling over a candidate list as ONE row sequence (round 4).
-//
-// kernel_pool_split_kernel walks a document in 32-row blocks of its own: a 200-token document is 6.25 blocks, so the
-// seventh block's split / MFMA work runs on 8 real rows and its other 24 rows are clamped re-reads of the last row
-// (10.7 % of the issued work and the 1.10 x HBM traffic of profiles/r04_tk_pmc.json); MSMARCO-length passages lose
-// half a block each.  When the pairs of a wavefront share their query tile (the "1 query x C candidates" layout,
-// pairs_per_query > 1) nothing ties a block to one document: here the REAL rows [0, len) of the wavefront's consecutive
-// pairs of one query form one virtual row sequence that is cut into 32-row blocks wherever they fall — a block is up to
-// kContSeg segments of different pairs (LDS-DMA sources are per-lane addresses anyway, as in tkl_stage1_run_kernel) — and
-// the epilogue evaluates a block segment by segment (validity bits = the segment's rows), closing a pair — log, query
-// mask, wave sum, bin weights — where its last row falls.  The slices keep their 13 LDS-DMA instructions each, so the
-// counted vmcnt waits are unchanged.  Producer and consumer walk the same (wave-uniform) cursor over the documents'
-// lengths, each for itself.  Prefix lengths only (int32 lengths / no mask); everything else takes the kernel above.
-// ---------------------------------------------------------------------------------------------
-constexpr int kContSeg = 4;
-
-struct ContCursor {
-  int64_t pair;   // pair the next row comes from
-  int row;        // next row inside it
-  int len;        // its effective length
-};
-
-struct ContBlock {
-  int nseg;       // 0: the run has no rows left
-  int filled;     // rows of the block that exist
-  int done;       // bit j: segment j holds the last row of its pair
-  int64_t pair0;  // pair of segment 0
-  int dp[kContSeg], row0[kContSeg], n[kContSeg], start[kContSeg];   // pair - pair0, first row in the pair, rows, first row in the block
-};
-
-template <typename F>
-__device__ __forceinline__ ContBlock cont_next(ContCursor& c, int64_t run_end, int max_dp, F&& doc_len) {
-  ContBlock b;
-  b.nseg = 0; b.filled = 0; b.done = 0; b.pair0 = c.pair;
-#pragma unroll
-  for (int j = 0; j < kContSeg; ++j) { b.dp[j] = 0; b.row0[j] = 0; b.n[j] = 0; b.start[j] = 32; }
-  while (b.filled < 32 && b.nseg < kContSeg && c.pair < run_end) {
-    if (c.row >= c.len) {                       // this pair has no rows left (or none at all): the next one
-      ++c.pair;
-      c.row = 0;
-      c.len = c.pair < run_end ? doc_len(c.pair) : 0;
-      continue;
-    }
-    if (b.nseg == 0) b.pair0 = c.pair;
-    const int dp = (int)(c.pair - b.pair0);
-    if (dp > max_dp) break;                     // 32-bit source offsets: a long stretch of empty documents ends the block
-    const int take = 32 - b.filled < c.len - c.row ? 32 - b.filled : c.len - c.row;
-    const int last = c.row + take == c.len ? 1 : 0;
-#pragma unroll
-    for (int j = 0; j < kContSeg; ++j)
-      if (j == b.nseg) { b.dp[j] = dp; b.row0[j] = c.row; b.n[j] = take; b.start[j] = b.filled; b.done |= last << j; }
-    b.filled += take;
-    c.row += take;
-    ++b.nseg;
-  }
-  return b;
-}
-
-template <int NS, int K, int NBUF>
-__global__ void __launch_bounds__(64) kernel_pool_cont_kernel(const KpArgs a) {
-  static_assert(NS >= 1 && NS <= 4, "parked-chunk step holds at most 4 chunks");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
-  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
-  if (p0 >= p1) return;
-  constexpr int E = 100 * NS;
-  constexpr int RB = E * 4;
-  const int D = a.D, Q = a.Q;
-  const int max_dp = (int)(0x7fffffffLL / ((int64_t)D * RB)) - 1;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  float* rdbuf = (float*)(smem + NBUF * kSliceBytes);
-
-  int srow[kSliceInstr];
-  uint32_t scol[kSliceInstr];
-#pragma unroll
-  for (int n = 0; n < kSliceInstr; ++n) {
-    int sl = 64 * n + lane;
-    if (sl > 32 * kSC - 1) sl = 32 * kSC - 1;
-    srow[n] = sl / kSC;
-    scol[n] = (uint32_t)((sl - srow[n] * kSC) * 16);
-  }
-  const uint32_t a_off = (uint32_t)(r * (kSC * 16) + h * 32);
-  const uint32_t l_off = (uint32_t)(r * (kSC * 16) + 24 * 16);
-
-  Rbf rbf;
-  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
-  const char* dbase = (const char*)a.d;
-  auto doc_len = [&](int64_t p) -> int {
-    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
-    return len < 0 ? 0 : (len > D ? D : len);
-  };
-  auto run_end = [&](int64_t p) -> int64_t {     // the pairs [p, run_end) share p's query tile
-    const int64_t e = (p / a.ppq + 1) * a.ppq;
-    return e < p1 ? e : p1;
-  };
-
-  // ---- producer: the next block of the row sequence to put in flight ------------------------------------------
-  int64_t pre = run_end(p0);
-  ContCursor pc{p0, 0, doc_len(p0)};
-  ContBlock pb = cont_next(pc, pre, max_dp, doc_len);
-  auto producer_skip_runs = [&]() {
-    while (pb.nseg == 0 && pre < p1) {
-      const int64_t rs = pre;
-      pre = run_end(rs);
-      pc = ContCursor{rs, 0, doc_len(rs)};
-      pb = cont_next(pc, pre, max_dp, doc_len);
-    }
-  };
-  producer_skip_runs();
-  int ps = 0, pbuf = 0, cbuf = 0, inflight = 0;
-  uint32_t vrun[kSliceInstr];
-  auto top_up = [&]() {
-    while (pb.nseg > 0 && inflight < NBUF) {
-      if (ps == 0) {   // per-lane source rows of this block: block row v -> (segment, row of its pair); rows past the end re-read the last real row
-        const int last = pb.filled - 1;
-#pragma unroll
-        for (int n = 0; n < kSliceInstr; ++n) {
-          const int v = srow[n] < last ? srow[n] : last;
-          int dp = pb.dp[0], rw = pb.row0[0] + v - pb.start[0];
-#pragma unroll
-          for (int j = 1; j < kContSeg; ++j)
-            if (v >= pb.start[j]) { dp = pb.dp[j]; rw = pb.row0[j] + v - pb.start[j]; }     // (unused segments start at 32)
-          vrun[n] = (uint32_t)((dp * D + rw) * RB) + scol[n];
-        }
-      }
-      const char* g = dbase + pb.pair0 * D * (int64_t)RB + ps * (kSC * 16);
-      issue_slice<false>(g, vrun, 0u, false, lds0 + (uint32_t)pbuf * kSliceBytes);
-      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
-      ++inflight;
-      if (++ps == NS) {
-        ps = 0;
-        pb = cont_next(pc, pre, max_dp, doc_len);
-        producer_skip_runs();
-      }
-    }
-  };
-  top_up();
-
-  bf16x8 qhi[NS][kSplitSteps], qlo[NS][kSplitSteps], qhiL, qloL;
-  for (int64_t rs = p0; rs < p1;) {
-    const int64_t re = run_end(rs);
-    const int64_t qi = rs / a.ppq;
-    // ---- this run's query tile (as in kernel_pool_split_kernel) ------------------------------------------------
-    float rq;
-    {
-      const int qr = r < Q ? r : Q - 1;
-      const char* qrow = (const char*)a.q + (qi * Q + qr) * RB;
-      float ss = 0.0f;
-      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-      f32x4 raw[NS][13];
-#pragma unroll
-      for (int sl = 0; sl < NS; ++sl)
-        load_q_slice_split<false>(qrow + sl * (kSC * 16) + h * 32, qrow + sl * (kSC * 16) + 24 * 16, raw[sl]);
-      wait_q_slices<NS>(raw);
-#pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
-#pragma unroll
-        for (int p = 0; p < kSplitSteps; ++p) {
-          split8(raw[sl][2 * p], raw[sl][2 * p + 1], qhi[sl][p], qlo[sl][p]);
-          qhi[sl][p] = to_agpr(qhi[sl][p]);
-          qlo[sl][p] = to_agpr(qlo[sl][p]);
-          ss += sumsq4(raw[sl][2 * p]) + sumsq4(raw[sl][2 * p + 1]);
-        }
-        if (h == 0) ss += sumsq4(raw[sl][12]);
-        if (h == (sl >> 1)) park[sl & 1] = raw[sl][12];
-      }
-      split8(park[0], park[1], qhiL, qloL);
-      qhiL = to_agpr(qhiL);
-      qloL = to_agpr(qloL);
-      ss += __shfl_xor(ss, 32, 64);
-      rq = 1.0f / (sqrtf(ss) + 1e-13f);
-    }
-    const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
-    bool qvalid = r < Q && r < qlen;
-    const uint32_t qbits = a.qm.bits ? sload_u32(a.qm.bits, qi) : 0xffffffffu;
-    if (a.qm.bits) qvalid = qvalid && ((qbits >> r) & 1u);
-    const int qn = qlen < Q ? (qlen < 0 ? 0 : qlen) : Q;
-    const int rrows = redist_rows(qn);
-    const int np = rrows ? (32 + rrows - 1) / rrows : 2;
-    const int rtk = lane / np, rsub = lane - rtk * np;
-
-    f32x2 pk2[kMaxK / 2];
-#pragma unroll
-    for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
-    auto finish = [&](int64_t pair) {          // pools pk2 into out[pair] and clears it
-      float pk[kMaxK];
-      if (np > 2) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
-        redist_reduce<K>(pk, np, lane);
-        const bool count = rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u);
-        finish_pool<K>(a, pair, pk, count, lane, rbf);
-      } else {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          pk[k] = pk2[k >> 1][k & 1];
-          pk[k] += __shfl_xor(pk[k], 32, 64);
-        }
-        finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
-      }
-#pragma unroll
-      for (int k = 0; k < kMaxK / 2; ++k) pk2[k] = f32x2{0.0f, 0.0f};
-    };
-
-    ContCursor cc{rs, 0, doc_len(rs)};
-    int64_t fin = rs;                           // pairs below it have been written
-    while (true) {
-      const ContBlock cb = cont_next(cc, re, max_dp, doc_len);
-      if (cb.nseg == 0) break;
-      f32x16 acc_hh = {0}, acc_xl = {0};
-      f32x4 park[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-      f32x2 ss2 = {0.0f, 0.0f};
-#pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
-        top_up();
-        wait_slices(inflight - 1);
-        const char* buf = smem + cbuf * kSliceBytes;
-        f32x4 x[13];
-#pragma unroll
-        for (int p = 0; p < kSplitSteps; ++p) {
-          x[2 * p] = *(const f32x4*)(buf + a_off + p * 64);
-          x[2 * p + 1] = *(const f32x4*)(buf + a_off + p * 64 + 16);
-        }
-        x[12] = *(const f32x4*)(buf + l_off);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool early = sl + 1 < NS;        // (the last slice's slot is the epilogue's scratch)
-        if (early) {
-          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
-          --inflight;
-          top_up();
-        }
-        bf16x8 ah, al;
-        split8(x[0], x[1], ah, al);
-#pragma unroll
-        for (int p = 0; p < kSplitSteps; ++p) {
-          bf16x8 nh = ah, nl = al;
-          if (p + 1 < kSplitSteps) split8(x[2 * p + 2], x[2 * p + 3], nh, nl);
-          acc_hh = mfma_bf16(ah, qhi[sl][p], acc_hh);
-          acc_xl = mfma_bf16(al, qhi[sl][p], acc_xl);
-          acc_xl = mfma_bf16(ah, qlo[sl][p], acc_xl);
-          if (MM_KP_LOLO) acc_xl = mfma_bf16(al, qlo[sl][p], acc_xl);
-          {
-            const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
-            const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
-            ss2 += a0 * a0;
-            ss2 += a1 * a1;
-            ss2 += b0 * b0;
-            ss2 += b1 * b1;
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, kShadowValu, 0);
-          }
-          ah = nh;
-          al = nl;
-        }
-        const f32x4 xl = x[12];
-        if (h == 0) ss2 += f32x2{xl[0] * xl[0] + xl[1] * xl[1], xl[2] * xl[2] + xl[3] * xl[3]};
-        if (h == (sl >> 1)) park[sl & 1] = xl;
-        if (!early) {
-          cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;
-          --inflight;
-        }
-      }
-      {
-        bf16x8 ah, al;
-        split8(park[0], park[1], ah, al);
-        acc_hh = mfma_bf16(ah, qhiL, acc_hh);
-        acc_xl = mfma_bf16(al, qhiL, acc_xl);
-        acc_xl = mfma_bf16(ah, qloL, acc_xl);
-        if (MM_KP_LOLO) acc_xl = mfma_bf16(al, qloL, acc_xl);
-      }
-      float ss = ss2[0] + ss2[1];
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + acc_xl[i];
-      ss += __shfl_xor(ss, 32, 64);
-      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
-      float rdr[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
-        rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
-      }
-      const float* T = (const float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
-      if (np > 2) {   // short queries: the scaled tile transposed once per block, evaluated segment by segment
-        float* Tw = (float*)(smem + (cbuf == 0 ? NBUF - 1 : cbuf - 1) * kSliceBytes);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *(f32x4*)(Tw + r * kTS + 8 * g + 4 * h) = f32x4{(acc[4 * g] * rq) * rdr[4 * g], (acc[4 * g + 1] * rq) * rdr[4 * g + 1],
-                                                        (acc[4 * g + 2] * rq) * rdr[4 * g + 2], (acc[4 * g + 3] * rq) * rdr[4 * g + 3]};
-      }
-#pragma unroll
-      for (int j = 0; j < kContSeg; ++j) {
-        if (j < cb.nseg) {                      // wave-uniform
-          const int64_t pj = cb.pair0 + cb.dp[j];
-          while (fin < pj) finish(fin++);       // documents without a real token in between: pooled from zero sums
-          const uint32_t va = (cb.n[j] >= 32 ? 0xffffffffu : ((1u << cb.n[j]) - 1u)) << cb.start[j];
-          if (np > 2) rbf_redistributed_rows<K, false>(rrows, pk2, T, nullptr, rtk, rsub, va, rbf);
-          else rbf_block<K>(pk2, acc, rdr, rq, va, h, rbf);
-          if ((cb.done >> j) & 1) {
-            finish(pj);
-            fin = pj + 1;
-          }
-        }
-      }
-    }
-    while (fin < re) finish(fin++);
-    rs = re;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // TKL stage 1, grouped (the default TKL path for E == 100*NS, Q <= 32).
 //
 // A chunk contributes its 40 centre rows = one full 32-row MFMA block + an 8-row remainder that costs
@@ -1610,18 +1294,6 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
       }
     }
     if (a.fdm) return set_error(MM_ELAUNCH, "kernel_pool: float masks were left to a kernel that does not read them (internal)");
-    if constexpr (!W) {
-      // candidate lists with a shared query tile and prefix lengths: one row sequence per list (kernel_pool_cont_kernel)
-      if (a.ppq > 1 && !a.pair_q && a.n_md == 0 && !a.dm.bits && !env().kp_no_cont && (int64_t)a.D * a.E * 4 < (1LL << 28)) {
-        if (a.E == 100)
-          hipLaunchKernelGGL((kernel_pool_cont_kernel<1, K, NBUF>), grid, block, lds, stream, a);
-        else if (a.E == 200)
-          hipLaunchKernelGGL((kernel_pool_cont_kernel<2, K, NBUF>), grid, block, lds, stream, a);
-        else
-          hipLaunchKernelGGL((kernel_pool_cont_kernel<3, K, NBUF>), grid, block, lds, stream, a);
-        return check_launch("kernel_pool_cont_kernel");
-      }
-    }
     if (a.E == 100)
       hipLaunchKernelGGL((kernel_pool_split_kernel<1, K, NBUF, false, false, W>), grid, block, lds, stream, a);
     else if (a.E == 200)

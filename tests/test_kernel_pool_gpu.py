@@ -355,12 +355,12 @@ def test_scores_of_a_pair_do_not_depend_on_the_batch_it_arrives_in_beyond_fp32_r
 
 
 @pytest.mark.parametrize("E,ppq,nq,D", [(300, 37, 70, 200), (100, 1000, 3, 64), (200, 5, 900, 40)])
-def test_candidate_lists_as_one_row_sequence_equal_the_document_by_document_kernel(E, ppq, nq, D):
-    """kernel_pool_cont_kernel (shared query tile + prefix lengths: the real rows of a wavefront's consecutive pairs form one
-    row sequence cut into 32-row blocks wherever they fall) against the pair-per-row call of the same pairs (each pair its own
-    query copy: kernel_pool_split_kernel, one document at a time) and against the oracle.  Lengths are chosen to hit every
+def test_candidate_lists_with_a_shared_query_equal_the_pair_per_row_call(E, ppq, nq, D):
+    """The "1 query x C candidates" layout (query tile read once per list, int32 lengths) against the pair-per-row call of
+    the same pairs (each pair its own query copy, float query masks) and against the oracle.  Lengths are chosen to hit every
     seam: empty documents (also several in a row, at list ends and wavefront ends), 1 / 31 / 32 / 33 rows, full length, many
-    8-row documents (more than four segments per block), lists that straddle wavefront ranges."""
+    8-row documents, lists that straddle wavefront ranges.  (Written for round 4's row-sequence kernel, which passed it and
+    was retired as slower: profiles/r04_experiments/tk_row_sequence_ab.txt.)"""
     from matchmaker_amd import ops
     dev = util.require_gpu()
     g = torch.Generator().manual_seed(E + ppq)
@@ -383,7 +383,6 @@ def test_candidate_lists_as_one_row_sequence_equal_the_document_by_document_kern
     qm = (torch.arange(Q)[None] < q_len[:, None]).float().repeat_interleave(ppq, 0)
     out_pp, pk_pp = ops.kernel_pool(q.repeat_interleave(ppq, 0).contiguous().to(dev), d.to(dev), qm.to(dev), d_len.to(dev), *dp,
                                     pairs_per_query=1, return_per_kernel=True)
-    # same arithmetic per row; only the summation order over a document's rows differs (blocks fall elsewhere)
     np.testing.assert_allclose(out.cpu().numpy(), out_pp.cpu().numpy(), atol=3e-5, rtol=2e-6)
     np.testing.assert_allclose(pk.cpu().numpy(), pk_pp.cpu().numpy(), atol=2e-3, rtol=2e-5)
     assert torch.equal(out, ops.kernel_pool(q.to(dev), d.to(dev), q_len.to(dev), d_len.to(dev), *dp, pairs_per_query=ppq))
