@@ -528,14 +528,23 @@ __device__ __forceinline__ f32x16 dot_block(const char* drow, const char* qrow, 
   } else {
     const int h = (threadIdx.x >> 5) & 1;      // lane half within the wavefront (workgroups may hold several)
     const int nch = E >> 3;
-    for (int c = 0; c < nch; c += 2) {
-      const int cc = c + h;
-      short8 av = {0, 0, 0, 0, 0, 0, 0, 0}, bv = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (cc < nch) {
-        av = *(const short8*)(drow + cc * 16);
-        bv = *(const short8*)(qrow + cc * 16);
+    // four K steps per trip: their eight 16-byte loads are issued before the first MFMA waits for any of them (the one
+    // load pair -> one MFMA form ran a row block as nch / 2 dependent memory round trips); same accumulation order
+    for (int c = 0; c < nch; c += 8) {
+      short8 av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c + 2 * u + h;
+        av[u] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+        bv[u] = av[u];
+        if (cc < nch) {
+          av[u] = *(const short8*)(drow + cc * 16);
+          bv[u] = *(const short8*)(qrow + cc * 16);
+        }
       }
-      acc = Mfma32x16<DT == MM_F32 ? MM_BF16 : DT>::run(av, bv, acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c + 2 * u < nch) acc = Mfma32x16<DT == MM_F32 ? MM_BF16 : DT>::run(av[u], bv[u], acc);   // wave-uniform
     }
   }
   return acc;
@@ -621,20 +630,50 @@ struct MaxsimBwdArgs {
   void* gd;
   int64_t n_pairs;
   int Q, D, E;
+  int row_masks;   // 1: LDS holds, per document row, the bit set of the query tokens whose first arg-max it is
 };
 
+// One 16-byte chunk of a token row as floats (4 for float32 rows, 8 for 16-bit rows), and the matching gradient store
+// (16 bytes for 16-bit gradients, 16 or 2 x 16 for float32 ones).
 template <int DT>
-__device__ __forceinline__ float load_elem(const char* row, int e) {
-  if constexpr (DT == MM_F32) return ((const float*)row)[e];
-  else if constexpr (DT == MM_F16) return (float)((const _Float16*)row)[e];
-  else return __uint_as_float((uint32_t)((const uint16_t*)row)[e] << 16);
+__device__ __forceinline__ void load_chunk(const char* p, float* v) {
+  if constexpr (DT == MM_F32) {
+    const f32x4 x = *(const f32x4*)p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x[k];
+  } else if constexpr (DT == MM_F16) {
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    const half8_t x = *(const half8_t*)p;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)x[k];
+  } else {
+    const short8 x = *(const short8*)p;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __uint_as_float((uint32_t)(uint16_t)x[k] << 16);
+  }
 }
 
-template <int GT>
-__device__ __forceinline__ void store_grad(void* base, int64_t idx, float v) {
-  if constexpr (GT == MM_F32) ((float*)base)[idx] = v;
-  else if constexpr (GT == MM_F16) ((_Float16*)base)[idx] = (_Float16)v;
-  else ((uint16_t*)base)[idx] = (uint16_t)(__float_as_uint(round_like<MM_BF16>(v)) >> 16);
+template <int GT, int PER>
+__device__ __forceinline__ void store_chunk(char* base, int64_t elem, const float* v) {
+  if constexpr (GT == MM_F32) {
+    f32x4* o = (f32x4*)(base + elem * 4);
+#pragma unroll
+    for (int k = 0; k < PER / 4; ++k) o[k] = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+  } else {
+    static_assert(PER == 8, "16-bit gradients come from 16-bit rows");
+    if constexpr (GT == MM_F16) {
+      typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+      half8_t o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (_Float16)v[k];
+      *(half8_t*)(base + elem * 2) = o;
+    } else {
+      short8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (short)(uint16_t)(__float_as_uint(round_like<MM_BF16>(v[k])) >> 16);
+      *(short8*)(base + elem * 2) = o;
+    }
+  }
 }
 
 // GT: element type of the gradients — float32, or the token vectors' own 16-bit type (what autograd hands back to an
@@ -645,12 +684,13 @@ template <int DT, int GT>
 __global__ void __launch_bounds__(256) maxsim_bwd_kernel(const MaxsimBwdArgs a) {
   // One 4-wavefront workgroup per pair (rounds 1-3: one wavefront, ~100 dependent memory round trips in a row — 150 us per
   // launch whatever the batch): wavefront w takes document blocks w, w + 4, ... of the arg-max search, the four partial
-  // (maximum, first position) results per query token meet in LDS, and each wavefront then writes the gradient rows it
-  // OWNS (query tokens i = w mod 4, document rows j = w mod 4), so no row is ever touched by two wavefronts.
+  // (maximum, first position) results per query token meet in LDS, and the workgroup then writes the gradient rows as
+  // 16-byte items (one thread per chunk of a row: every byte of grad_q / grad_d is written exactly once).
   extern __shared__ int smem_i[];
   int* jstar = smem_i;                       // [Q] first arg-max document position of every query token, -1 = no gradient
   float* pbest = (float*)(smem_i + a.Q);     // [4][32]
   int* prow = smem_i + a.Q + 128;            // [4][32]
+  uint32_t* rmask = (uint32_t*)(smem_i + a.Q + 256);   // [D][ceil(Q / 32)] when a.row_masks
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -672,6 +712,8 @@ __global__ void __launch_bounds__(256) maxsim_bwd_kernel(const MaxsimBwdArgs a) 
   const float g = a.go[pair];
   char* gq = (char*)a.gq + pair * Q * (int64_t)E * GS;
   char* gd = (char*)a.gd + pair * D * (int64_t)E * GS;
+  if (a.row_masks)                                       // (ordered before the atomicOr below by the loop's barriers)
+    for (int k = threadIdx.x; k < D * qwords; k += 256) rmask[k] = 0u;
 
   for (int n = 0; n < qwords; ++n) {
     const int qtok = 32 * n + r;
@@ -720,34 +762,56 @@ __global__ void __launch_bounds__(256) maxsim_bwd_kernel(const MaxsimBwdArgs a) 
         const int orw = prow[k * 32 + r];
         if (ov > best || (ov == best && orw < brow)) { best = ov; brow = orw; }
       }
-      jstar[qtok] = (qvalid && brow != 0x7fffffff) ? brow : -1;
+      const int js = (qvalid && brow != 0x7fffffff) ? brow : -1;
+      jstar[qtok] = js;
+      if (a.row_masks && js >= 0) atomicOr(&rmask[js * qwords + n], 1u << r);
     }
   }
   __syncthreads();
-  // grad_d: zeros in every row this wavefront owns — lane l owns elements e = l, l + 64, ... here and below, so the rows
-  // that carry gradient are simply written again by the same lanes, in program order
-  for (int j = wv; j < D; j += 4)
-    for (int e = lane; e < E; e += 64) store_grad<GT>(gd, (int64_t)j * E + e, 0.0f);
-  for (int qt = 0; qt < Q; ++qt) {
-    const int j = jstar[qt];                            // wave-uniform (LDS)
-    if ((qt & 3) == wv) {                               // grad_q_i = g d_j*(i)  (0 without a gradient)
-      if (j < 0) {
-        for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, 0.0f);
-      } else {
-        const char* drow = dbase + j * rowb;
-        for (int e = lane; e < E; e += 64) store_grad<GT>(gq, (int64_t)qt * E + e, g * load_elem<DT>(drow, e));
+  // Gradient rows as 16-byte items over the whole workgroup (rounds 1-4/1 wrote them element by element — 2 bytes a lane —
+  // and found a document row's contributors by scanning the arg-max table once per query token).
+  constexpr int PER = 16 / ES;
+  const int nch = E / PER;
+  for (int it = threadIdx.x; it < Q * nch; it += 256) {   // grad_q_i = g d_j*(i)  (0 without a gradient)
+    const int qt = it / nch, c = it - qt * nch;
+    const int j = jstar[qt];
+    float v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = 0.0f;
+    if (j >= 0) {
+      load_chunk<DT>(dbase + j * rowb + c * 16, v);
+#pragma unroll
+      for (int k = 0; k < PER; ++k) v[k] *= g;
+    }
+    store_chunk<GT, PER>(gq, (int64_t)qt * E + c * PER, v);
+  }
+  for (int it = threadIdx.x; it < D * nch; it += 256) {   // grad_d_j = g sum_{i: j*(i) = j} q_i: ascending i, fp32, written once
+    const int j = it / nch, c = it - j * nch;
+    float v[PER], x[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = 0.0f;
+    if (a.row_masks) {
+      for (int n = 0; n < qwords; ++n) {
+        uint32_t mk = rmask[j * qwords + n];
+        while (mk) {
+          const int b = __builtin_ctz(mk);
+          mk &= mk - 1;
+          load_chunk<DT>(qbase + (32 * n + b) * rowb + c * 16, x);
+#pragma unroll
+          for (int k = 0; k < PER; ++k) v[k] += x[k];
+        }
       }
+    } else {                                              // (document x query too large for the LDS masks: scan the table)
+      for (int p = 0; p < Q; ++p)
+        if (jstar[p] == j) {
+          load_chunk<DT>(qbase + p * rowb + c * 16, x);
+#pragma unroll
+          for (int k = 0; k < PER; ++k) v[k] += x[k];
+        }
     }
-    if (j < 0 || (j & 3) != wv) continue;
-    bool first = true;                                  // grad_d_j = g sum_{i: j*(i) = j} q_i, summed in fp32, written once
-    for (int p = 0; p < qt; ++p) first = first && jstar[p] != j;
-    if (!first) continue;
-    for (int e = lane; e < E; e += 64) {
-      float sacc = 0.0f;
-      for (int p = qt; p < Q; ++p)
-        if (jstar[p] == j) sacc += load_elem<DT>(qbase + p * rowb, e);
-      store_grad<GT>(gd, (int64_t)j * E + e, g * sacc);
-    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] *= g;
+    store_chunk<GT, PER>(gd, (int64_t)j * E + c * PER, v);
   }
 }
 
@@ -1115,8 +1179,12 @@ extern "C" int mm_maxsim_bwd(const void* q, const void* d, const void* q_mask, i
   size_t left = workspace ? workspace_bytes : 0;
   if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
   if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (((uintptr_t)grad_q | (uintptr_t)grad_d) & 15) return set_error(MM_EINVAL, "maxsim_bwd: gradients must be 16-byte aligned");
   const dim3 grid((unsigned)n_pairs), block(256);
-  const size_t lds = (size_t)Q * 4 + 2 * 128 * 4;
+  size_t lds = (size_t)Q * 4 + 2 * 128 * 4;
+  const size_t mask_bytes = (size_t)D * ((Q + 31) / 32) * 4;
+  a.row_masks = lds + mask_bytes <= 60 * 1024;
+  if (a.row_masks) lds += mask_bytes;
   if (dtype == MM_F32)
     hipLaunchKernelGGL((maxsim_bwd_kernel<MM_F32, MM_F32>), grid, block, lds, stream, a);
   else if (dtype == MM_F16 && grad_dtype == MM_F32)

@@ -87,6 +87,26 @@ def test_ragged_empty_ranges_query_masks_and_store_helper(tmp_path):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1e-2), (torch.float16, 1e-2)])
+def test_backward_of_a_document_too_long_for_the_lds_row_masks():
+    """mm_maxsim_bwd keeps, per document row, the bit set of the query tokens whose first arg-max it is in LDS; when
+    D x ceil(Q / 32) words do not fit (here 5,200 x 3 x 4 B > 60 KB) it scans the arg-max table instead — same gradients."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(77)
+    B, Q, D, E = 2, 70, 5200, 16
+    q = torch.randn(B, Q, E, generator=g) / E ** 0.5
+    d = torch.randn(B, D, E, generator=g)
+    d[0, 4000] = d[0, 17]                              # an exact tie far apart: the first position takes the gradient
+    qm = (torch.arange(Q)[None] < torch.tensor([[Q], [51]])).long()
+    dm = (torch.arange(D)[None] < torch.tensor([[D], [4999]])).long()
+    go = torch.randn(B, generator=g)
+    _, ref_gq, ref_gd = TP.maxsim_forward_backward(q, d, qm, dm, go)
+    gq, gd = ops.maxsim_bwd(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), go.to(dev))
+    np.testing.assert_allclose(gq.cpu().numpy(), ref_gq.numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(gd.cpu().numpy(), ref_gd.numpy(), atol=1e-5, rtol=1e-5)
+    assert float(gd[0, 4000].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,Q,D,E", [(6, 32, 180, 128), (5, 13, 47, 64), (3, 40, 70, 24), (4, 8, 33, 768)])
 def test_backward_matches_autograd_of_the_reference_ops(dtype, tol, B, Q, D, E):
     from matchmaker_amd import ops
