@@ -248,35 +248,68 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a,
 
 // ---------------------------------------------------------------------------------------------
 // Tiled backward (round 4): the same arithmetic with every operand of the three small matrix products of a pair —
-// cosines C = Dh Qh^T, grad_d = G^T Qh, grad_q = G Dh — staged in LDS and register-blocked.
+// cosines C = Dh Qh^T, grad_d = G^T Qh, grad_q = G Dh — staged in LDS and run on the matrix pipe in exact float32
+// (v_mfma_f32_32x32x2_f32: no operand splitting, the products and sums are fp32 like torch's).
 //
 // kernel_pool_bwd_kernel above takes its dot products straight from global memory, one thread per output element and
 // one dependent load per FMA: 1.5-2 ms per PAIR (bench.py extra.train_step, round 4: 16.6 ms for 2,048 pairs, 2.4 x
 // slower than torch's eager ops on the same GPU).  Here: the normalised query tile [Q][E] and one 32-row document block
 // live in LDS, the cosines of the whole document stay in LDS between the two sweeps (pooled sums need every position
-// before any gradient can be formed), and every thread owns a 4 x TQ (cosines) or 4 x 4 (gradients) register tile fed
-// by 16-byte LDS reads.  The document is read from HBM/L2 twice and its gradient written once; grad_q accumulates in
-// registers across the blocks.  Q <= 32, E <= 384 (16-byte rows), K <= 16, LDS permitting; everything else takes the
-// kernel above.
+// before any gradient can be formed).  Per 32-row block the eight wavefronts of the workgroup
+//   * cosines: split K = E between them (wavefront w takes the 32-byte chunk pairs w, w + 8, ...: A = document rows,
+//     B = query tokens, both read as 16 bytes per lane and four MFMA steps), the eight partial 32 x 32 tiles meet in LDS;
+//   * grad_d block [32 rows x E]: wavefront w owns the 32-column tiles w, w + 8 of E; K = query tokens (A = G[row][token],
+//     B = Qh[token][column]: consecutive lanes read consecutive floats);
+//   * grad_q [Q x E]: the same column tiles, K = the block's 32 rows (A = G[token][row] / (|d_row| + tiny), B = the raw
+//     document block), accumulated in registers across the blocks.
+// (The first version of this kernel ran the three products as register-blocked VALU FMAs out of the same LDS tiles:
+// 1.12 ms for 2,048 pairs, 17 % VALU utilisation — every FMA needed its operands from LDS.)
+// The document is read from HBM/L2 twice and its gradient written once.  Q <= 32, E <= 384 (16-byte rows), K <= 16, LDS
+// permitting; everything else takes the kernel above.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTK = 16;
 constexpr int kTT = 512;   // threads of the tiled kernel: eight wavefronts, two per SIMD, around ONE set of LDS tiles per CU
 
+// Row stride of the [row][E] tiles in floats: an ODD number of 16-byte units, so that the sixteen lanes of a ds_read_b128
+// phase that read one column chunk of sixteen consecutive rows (the A / B operands of the cosine MFMAs) cover all 64 banks.
+// (E + 4 alone is even for E = 300: 304 floats = 48 banks apart, rows r and r + 4 on the same banks, 8-way conflicts.)
+__host__ __device__ inline int kp_bwd_row_stride(int E) { return ((E >> 2) & 1) ? E + 8 : E + 4; }
+
 __host__ __device__ inline size_t kp_bwd_tiled_lds_bytes(int Q, int E, int Dpad) {
-  const int ES = E + 4, QS = (Q + 3) & ~3;
+  const int ES = kp_bwd_row_stride(E), QS = (Q + 3) & ~3;
   return ((size_t)Q * ES + 32 * (size_t)ES + (size_t)Dpad * QS + 3 * 32 * (size_t)QS + 2 * (size_t)Q * kTK + 4 * (size_t)Dpad +
-          5 * 32 + 3 * kTK) * 4;
+          5 * 32 + 4 * kTK + 4 * 1024) * 4;
 }
+
+__device__ __forceinline__ constexpr int mrow(int i) { return (i & 3) + 8 * (i >> 2); }   // C/D layout of the 32x32 MFMA: acc[i] of lane l = row mrow(i) + 4 (l >> 5), column l & 31
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
-template <bool GATE>
+// Phase clocks (tools/build_variant.sh phases kernel_pool_bwd -DMM_KP_BWD_PHASE_TIMES=1; tools/bench_kp_bwd_phases.py): thread 0
+// of every pair sums s_memtime deltas per phase and pair 0 overwrites its grad_w / grad_alpha rows with them.
+#ifndef MM_KP_BWD_PHASE_TIMES
+#define MM_KP_BWD_PHASE_TIMES 0
+#endif
+// KP_KEEP16(v): the sixteen values are computed HERE.  Without it the compiler sinks each value's LDS reads and arithmetic
+// into the lane-conditional block of the store that uses it: per store two dependent LDS round trips behind a branch.  (One
+// statement for all sixteen: a volatile asm per value orders them and serialises the reads just the same — both measured, 35 %
+// and 17 % of the kernel.)
+#define KP_KEEP16(v)                                                                                                          \
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), \
+               "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+#if MM_KP_BWD_PHASE_TIMES
+#define KP_PH(k) do { const long long t_ = clock64(); ph[k] += (float)(t_ - t_last); t_last = t_; } while (0)
+#else
+#define KP_PH(k) do { } while (0)
+#endif
+
+template <bool GATE, int kLB>   // kLB: 16-byte chunks of a document block per thread = ceil(32 (E / 4) / kTT)
 __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdArgs a, const int Dpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x;
   const int Q = a.Q, D = a.D, E = a.E, K = a.K;
-  const int ES = E + 4, QS = (Q + 3) & ~3, NC = E >> 2;
+  const int ES = kp_bwd_row_stride(E), QS = (Q + 3) & ~3, NC = E >> 2;
   float* QH = (float*)smem;          // [Q][ES]    q_i / (|q_i| + tiny)
   float* DB = QH + Q * ES;           // [32][ES]   the current document block (raw rows)
   float* CT = DB + 32 * ES;          // [Dpad][QS] cosines of the whole document, [position][query token]
@@ -294,24 +327,33 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
   float* sq = nq + 32;               // sum_j G c per query token
   float* qmf = sq + 32;
   float* td = qmf + 32;              // sum_i G c per position of the block
-  float* kc = td + 32;               // [3][kTK]: mu, -log2(e) / (2 sigma^2), 1 / sigma^2
+  float* kc = td + 32;               // [kTK][4]: mu, -log2(e) / (2 sigma^2), 1 / sigma^2, -
+  float* PS = kc + 4 * kTK;          // [4][32][32] partial cosine tiles (wavefronts w and w + 4 share a slot), [row][token]
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = tid & 31, lh = (tid >> 5) & 1;           // MFMA lane coordinates within the wavefront
   const float* qb = a.q + pair * Q * (int64_t)E;
   const float* db = a.d + pair * D * (int64_t)E;
   float* gq = a.gq + pair * Q * (int64_t)E;
   float* gd = a.gd + pair * D * (int64_t)E;
   const float g = a.go[pair];
   const int qwords = (Q + 31) >> 5, dwords = (D + 31) >> 5;
+#if MM_KP_BWD_PHASE_TIMES
+  float ph[12] = {0};
+  long long t_last = clock64();
+#endif
 
   // ---- query tile, constants ---------------------------------------------------------------------------------
   for (int idx = tid; idx < Q * NC; idx += kTT) {
     const int i = idx / NC, c = idx - i * NC;
     *(f32x4*)(QH + i * ES + 4 * c) = *(const f32x4*)(qb + (int64_t)i * E + 4 * c);
   }
-  if (tid < K) {
-    const float sg = a.sigma[tid];
-    kc[tid] = a.mu[tid];
-    kc[kTK + tid] = -1.4426950408889634f / (2.0f * sg * sg);
-    kc[2 * kTK + tid] = 1.0f / (sg * sg);
+  if (tid < kTK) {                                      // (entries past K are zeros: the G loop runs in fours)
+    f32x4 kp = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (tid < K) {
+      const float sg = a.sigma[tid];
+      kp = f32x4{a.mu[tid], -1.4426950408889634f / (2.0f * sg * sg), 1.0f / (sg * sg), 0.0f};
+    }
+    *(f32x4*)(kc + 4 * tid) = kp;
   }
   for (int idx = tid; idx < Q * kTK; idx += kTT) PK[idx] = 0.0f;
   if (tid < 32) sq[tid] = 0.0f;
@@ -343,22 +385,47 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
   }
   __syncthreads();
 
-  auto load_block = [&](int j0, int nj) {
-    for (int idx = tid; idx < 32 * NC; idx += kTT) {
-      const int row = idx / NC, c = idx - row * NC;
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (row < nj) v = *(const f32x4*)(db + (int64_t)(j0 + row) * E + 4 * c);
-      *(f32x4*)(DB + row * ES + 4 * c) = v;
+  // A document block travels global -> registers -> LDS in two steps: fetch() issues every load of a thread's share at
+  // once (kLB <= 8 chunks of 16 bytes) and is called one block AHEAD, right after the barrier that opens the
+  // current block's arithmetic; commit() stores them to DB once that arithmetic has read the current block.  With one
+  // workgroup per CU nothing else hides the load latency: issued at the point of use (round 4's first version) it was half
+  // of the kernel's time.  A thread's chunks are the same (row, column) in every block.
+  int frow[kLB], fcol[kLB];
+#pragma unroll
+  for (int u = 0; u < kLB; ++u) {
+    const int idx = tid + u * kTT;
+    frow[u] = 32;
+    fcol[u] = 0;
+    if (idx < 32 * NC) {
+      frow[u] = idx / NC;
+      fcol[u] = 4 * (idx - frow[u] * NC);
+    }
+  }
+  f32x4 nxt[kLB];
+  auto fetch = [&](int j0) {
+    const int nj = D - j0 < 32 ? D - j0 : 32;
+#pragma unroll
+    for (int u = 0; u < kLB; ++u) {
+      nxt[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (frow[u] < nj) nxt[u] = *(const f32x4*)(db + (uint32_t)((j0 + frow[u]) * E + fcol[u]));
     }
   };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < kLB; ++u)
+      if (frow[u] < 32) *(f32x4*)(DB + frow[u] * ES + fcol[u]) = nxt[u];
+  };
+  int dlen = a.dm.len ? a.dm.len[pair] : D;
+  dlen = dlen < D ? dlen : D;
 
   // ---- sweep 1: cosines of every block, pooled kernels ---------------------------------------------------------
-  const int rg = tid >> 6, tg8 = (tid >> 3) & 7, ks = tid & 7;    // 8 row groups x 8 token groups x 8 K slices
-  const int TQ = (Q + 7) >> 3;                         // query tokens per thread of the cosine tile (<= 4)
+  fetch(0);
+  KP_PH(0);
   for (int j0 = 0; j0 < D; j0 += 32) {
     const int nj = D - j0 < 32 ? D - j0 : 32;
-    load_block(j0, nj);
+    commit();
     __syncthreads();
+    KP_PH(1);
     {  // row norms and masks: sixteen threads per row
       const int row = tid >> 4, sub = tid & 15;
       float ss = 0.0f;
@@ -372,68 +439,68 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
       ss += __shfl_xor(ss, 8, 64);
       if (sub == 0) {
         const float n = sqrtf(ss);
-        const bool real = row < nj && mask_bit(a.dm, pair, dwords, j0 + row, D);
+        const int j = j0 + row;
+        bool real = row < nj && j < dlen;
+        if (a.dm.bits) real = real && ((a.dm.bits[pair * dwords + (j >> 5)] >> (j & 31)) & 1u);
         float gate = 1.0f;
-        if (GATE) gate = row < nj ? fmaxf(a.dw[pair * D + j0 + row], 0.0f) : 0.0f;
-        RD[j0 + row] = row < nj ? 1.0f / (n + 1e-13f) : 0.0f;
-        ND[j0 + row] = n;
-        DMB[j0 + row] = real ? 1.0f : 0.0f;
-        DMF[j0 + row] = real ? gate : 0.0f;
+        if (GATE) gate = row < nj ? fmaxf(a.dw[pair * D + j], 0.0f) : 0.0f;
+        RD[j] = row < nj ? 1.0f / (n + 1e-13f) : 0.0f;
+        ND[j] = n;
+        DMB[j] = real ? 1.0f : 0.0f;
+        DMF[j] = real ? gate : 0.0f;
       }
     }
     __syncthreads();
-    {  // cosine tile: thread = (4 rows, TQ tokens, every 8th 16-byte chunk of E); the eight K slices meet by shuffles
-      float acc[4][4];
+    KP_PH(2);
+    fetch(j0 + 32 < D ? j0 + 32 : 0);                   // the next block, or sweep 2's first
+    {  // cosine tile: this wavefront's K slice of the 32 x 32 tile; the eight partial tiles meet in LDS in a fixed order
+      f32x16 acc = {0};
+      const float* arow = DB + ln * ES;
+      const float* brow = QH + (ln < Q ? ln : Q - 1) * ES;
+      for (int p = wv; 2 * p < NC; p += 8) {
+        const int cc = 2 * p + lh;
+        const int cl = cc < NC ? cc : NC - 1;            // (odd NC: the last pair's upper half multiplies zeros)
+        f32x4 av = *(const f32x4*)(arow + 4 * cl);
+        const f32x4 bv = *(const f32x4*)(brow + 4 * cl);
+        if (cc >= NC) av = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[r][t] = 0.0f;
-      for (int c = ks; c < NC; c += 8) {
-        f32x4 dv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dv[r] = *(const f32x4*)(DB + (4 * rg + r) * ES + 4 * c);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (t < TQ) {
-            int i = tg8 * TQ + t;
-            i = i < Q ? i : Q - 1;
-            const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r][t] += dot4(dv[r], qv);
-          }
-        }
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
       }
+      float* ps = PS + (wv & 3) * 1024 + 4 * lh * 32 + ln;
+      if (wv >= 4) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] = acc[i];
+      }
+      __syncthreads();
+      if (wv < 4) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          acc[r][t] += __shfl_xor(acc[r][t], 1, 64);
-          acc[r][t] += __shfl_xor(acc[r][t], 2, 64);
-          acc[r][t] += __shfl_xor(acc[r][t], 4, 64);
-        }
-      const int row = 4 * rg + (ks & 3);                // lanes ks = 0..3 of the eight write rows 0..3 of the thread tile
-      const float rdv = RD[j0 + row];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = tg8 * TQ + t;
-        if (ks < 4 && t < TQ && i < Q) {
-          const float v = ks == 0 ? acc[0][t] : (ks == 1 ? acc[1][t] : (ks == 2 ? acc[2][t] : acc[3][t]));
-          CT[(j0 + row) * QS + i] = v * rdv;
-        }
+        for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] += acc[i];
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < Q * K; idx += kTT) {      // (i, k) is owned by one thread across the blocks
+    KP_PH(3);
+    for (int idx = tid; idx < 1024; idx += kTT) {
+      const int row = idx >> 5, i = idx & 31;
+      const float v = ((PS[idx] + PS[1024 + idx]) + PS[2048 + idx]) + PS[3072 + idx];
+      if (i < Q) CT[(j0 + row) * QS + i] = v * RD[j0 + row];
+    }
+    __syncthreads();
+    KP_PH(4);
+    for (int idx = tid >> 1; idx < Q * K; idx += kTT / 2) {   // (i, k): two threads, sixteen positions each; owned across the blocks
       const int i = idx / K, k = idx - i * K;
-      const float mu = kc[k], c2 = kc[kTK + k];
+      const float mu = kc[4 * k], c2 = kc[4 * k + 1];
+      const int jb = j0 + 16 * (tid & 1);
       float pk = 0.0f;
-      for (int jj = 0; jj < 32; ++jj) {
-        const float t = CT[(j0 + jj) * QS + i] - mu;
-        pk += DMF[j0 + jj] * __builtin_amdgcn_exp2f(t * t * c2);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const float t = CT[(jb + jj) * QS + i] - mu;
+        pk += DMF[jb + jj] * __builtin_amdgcn_exp2f(t * t * c2);
       }
-      PK[i * kTK + k] += pk;
+      pk += __shfl_xor(pk, 1, 64);
+      if (!(tid & 1)) PK[i * kTK + k] += pk;
     }
     __syncthreads();
+    KP_PH(5);
   }
 
   // ---- A_ik and the parameter gradients of this pair -----------------------------------------------------------
@@ -458,109 +525,168 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
   }
   __syncthreads();
 
+  KP_PH(6);
   // ---- sweep 2: G per block, grad_d (complete per block), grad_q (register accumulators across the blocks) -------
-  const int TG = QS >> 2;                               // groups of four query tokens
-  f32x4 accq[2][4];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) accq[s][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  // Everything the matrix pipe is fed with is read unconditionally (clamped addresses, zeros selected afterwards): a
+  // conditional LDS read in front of an MFMA becomes a branch, a wait and an exposed latency per step.
+  const int NT = (E + 31) >> 5;                         // 32-column tiles of E; wavefront w owns tiles w and w + 8
+  const int KQ = (Q + 1) >> 1;                          // MFMA steps over the query tokens
+  f32x16 accq[2];
+  accq[0] = f32x16{0};
+  accq[1] = f32x16{0};
   for (int j0 = 0; j0 < D; j0 += 32) {
     const int nj = D - j0 < 32 ? D - j0 : 32;
-    load_block(j0, nj);
-    for (int idx = tid; idx < 32 * QS; idx += kTT) {
-      const int jj = idx / QS, i = idx - jj * QS;
+    commit();
+    if (j0 + 32 < D) fetch(j0 + 32);
+    for (int idx = tid; idx < 1024; idx += kTT) {
+      const int jj = idx >> 5, i = idx & 31;
+      // every lane runs the arithmetic on a clamped token (reads ahead of the exp chain, no lane-conditional block)
+      const int ic = i < Q ? i : Q - 1;
+      const float c = CT[(j0 + jj) * QS + ic];
+      const bool live = i < Q && DMB[j0 + jj] != 0.0f;
       float gs = 0.0f, sg = 0.0f;
-      if (i < Q && DMB[j0 + jj] != 0.0f) {
-        const float c = CT[(j0 + jj) * QS + i];
-        for (int k = 0; k < K; ++k) {
-          const float t = c - kc[k];
-          const float ae = A[i * kTK + k] * __builtin_amdgcn_exp2f(t * t * kc[kTK + k]);
+      for (int k4 = 0; k4 < K; k4 += 4) {
+        const f32x4 a4 = *(const f32x4*)(A + ic * kTK + k4);        // (rows of A are kTK = 16 floats; K <= kTK)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const f32x4 kp = *(const f32x4*)(kc + 4 * (k4 + kk));      // zeros past K (below): ae = 0
+          const float t = c - kp[0];
+          const float ae = (k4 + kk < K ? a4[kk] : 0.0f) * __builtin_amdgcn_exp2f(t * t * kp[1]);
           sg += ae;
-          gs -= ae * t * kc[2 * kTK + k];
+          gs -= ae * t * kp[2];
         }
       }
-      const float G = gs * DMF[j0 + jj];
-      GJ[jj * QS + i] = G;
-      GI[i * 32 + jj] = G;
-      if (GATE) SG[jj * QS + i] = sg;
-    }
-    __syncthreads();
-    if (tid < 32) {                                     // sum_i G c of every position of the block
-      float s = 0.0f;
-      for (int i = 0; i < Q; ++i) s += GJ[tid * QS + i] * CT[(j0 + tid) * QS + i];
-      td[tid] = s;
-    } else if (tid < 64) {                              // sum_j G c of every query token, over all blocks
-      const int i = tid - 32;
-      if (i < Q) {
-        float s = 0.0f;
-        for (int jj = 0; jj < 32; ++jj) s += GI[i * 32 + jj] * CT[(j0 + jj) * QS + i];
-        sq[i] += s;
-      }
-    } else if (GATE && tid < 96) {                      // gate gradient: sum_ik A_ik e_ijk on real tokens
-      const int jj = tid - 64;
-      if (jj < nj && a.gdw) {
-        float s = 0.0f;
-        for (int i = 0; i < Q; ++i) s += SG[jj * QS + i];
-        a.gdw[pair * D + j0 + jj] = s;
+      const float G = live ? gs * DMF[j0 + jj] : 0.0f;
+      if (i < QS) {
+        GJ[jj * QS + i] = G;
+        GI[i * 32 + jj] = G;
+        if (GATE) SG[jj * QS + i] = live ? sg : 0.0f;
       }
     }
     __syncthreads();
-    // grad_d of the block: item = (4 rows, one 16-byte chunk of E)
-    for (int it = tid; it < 8 * NC; it += kTT) {
-      const int rgp = it / NC, c = it - rgp * NC;
-      f32x4 acc[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      for (int i = 0; i < Q; ++i) {
-        const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
-        const f32x4 g4 = *(const f32x4*)(GI + i * 32 + 4 * rgp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += qv * g4[r];
+    KP_PH(7);
+    {  // sixteen threads per row / per query token, two terms each
+      const int r16 = tid >> 4, sub = tid & 15;
+      float s = 0.0f, u = 0.0f, sgs = 0.0f;
+      for (int i = sub; i < Q; i += 16) {                // sum_i G c of every position of the block
+        s += GJ[r16 * QS + i] * CT[(j0 + r16) * QS + i];
+        if (GATE) sgs += SG[r16 * QS + i];
       }
+      if (r16 < Q)                                       // sum_j G c of every query token, over all blocks
+        for (int jj = sub; jj < 32; jj += 16) u += GI[r16 * 32 + jj] * CT[(j0 + jj) * QS + r16];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * rgp + r;
-        if (row < nj) {
-          const f32x4 x = *(const f32x4*)(DB + row * ES + 4 * c);
-          const float n = ND[j0 + row];
-          const float self = n > 0.0f ? td[row] / n : 0.0f;
-          *(f32x4*)(gd + (int64_t)(j0 + row) * E + 4 * c) = (acc[r] - x * self) * RD[j0 + row];
-        }
+      for (int m = 1; m < 16; m <<= 1) {
+        s += __shfl_xor(s, m, 64);
+        u += __shfl_xor(u, m, 64);
+        if (GATE) sgs += __shfl_xor(sgs, m, 64);
       }
-    }
-    // grad_q: item = (4 query tokens, one 16-byte chunk of E), accumulated over the blocks
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int it = tid + kTT * s;
-      if (it < TG * NC) {
-        const int tg = it / NC, c = it - tg * NC;
-        for (int jj = 0; jj < 32; ++jj) {
-          const f32x4 dv = *(const f32x4*)(DB + jj * ES + 4 * c) * RD[j0 + jj];
-          const f32x4 g4 = *(const f32x4*)(GJ + jj * QS + 4 * tg);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) accq[s][t] += dv * g4[t];
-        }
+      if (sub == 0) {
+        const float n = ND[j0 + r16];
+        td[r16] = n > 0.0f ? s / n : 0.0f;               // the row's own-direction term of the norm's gradient
+        if (r16 < Q) sq[r16] += u;
+        if (GATE && r16 < nj && a.gdw) a.gdw[pair * D + j0 + r16] = sgs;   // gate gradient: sum_ik A_ik e_ijk
       }
     }
     __syncthreads();
+    KP_PH(8);
+    {  // grad_d of the block: A[row][token] = G (K = tokens, two per step; zero past Q), shared by this wavefront's tiles
+      float ga[16];
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const int i = 2 * st + lh;
+        ga[st] = GJ[ln * QS + (i < QS ? i : QS - 1)];
+        if (i >= Q) ga[st] = 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int nt = wv + 8 * t;
+        if (nt >= NT) break;                             // wave-uniform
+        const int col = 32 * nt + ln;
+        const bool cin = col < E;
+        const float* qcol = QH + (cin ? col : 0);
+        const float* dcol = DB + (cin ? col : 0);
+        float bq[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+          const int i = 2 * st + lh;
+          bq[st] = qcol[(i < Q ? i : Q - 1) * ES];       // (multiplied by ga = 0 past Q)
+        }
+        f32x16 acc = {0};
+#pragma unroll
+        for (int g2 = 0; g2 < 8; ++g2) {
+          if (2 * g2 < KQ) {                             // wave-uniform
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[2 * g2], bq[2 * g2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[2 * g2 + 1], bq[2 * g2 + 1], acc, 0, 0, 0);
+          }
+        }
+        const uint32_t o0 = (uint32_t)((j0 + 4 * lh) * E + col);
+        float ov[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = mrow(i) + 4 * lh;
+          ov[i] = (acc[i] - dcol[row * ES] * td[row]) * RD[j0 + row];
+        }
+        if (nj == 32 && 32 * nt + 32 <= E) {             // wave-uniform: a full tile of a full block stores without lane conditions
+#pragma unroll
+          for (int i = 0; i < 16; ++i) gd[o0 + (uint32_t)(mrow(i) * E)] = ov[i];   // 128-byte row segments per store
+        } else {
+          KP_KEEP16(ov);
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (cin && mrow(i) + 4 * lh < nj) gd[o0 + (uint32_t)(mrow(i) * E)] = ov[i];
+        }
+      }
+    }
+    KP_PH(9);
+    {  // grad_q: A[token][row] = G / (|d_row| + tiny) (K = the block's rows), B = the raw document block
+      float gi[16];
+      const int tk = ln < Q ? ln : Q - 1;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const int i = 2 * st + lh;
+        gi[st] = GI[tk * 32 + i] * RD[j0 + i];
+        if (ln >= Q) gi[st] = 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int nt = wv + 8 * t;
+        if (nt >= NT) break;
+        const int col = 32 * nt + ln;
+        const float* dcol = DB + (col < E ? col : 0);
+        float bd[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) bd[st] = dcol[(2 * st + lh) * ES];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) accq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gi[st], bd[st], accq[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    KP_PH(10);
   }
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int it = tid + kTT * s;
-    if (it < TG * NC) {
-      const int tg = it / NC, c = it - tg * NC;
+  for (int t = 0; t < 2; ++t) {
+    const int nt = wv + 8 * t;
+    const int col = 32 * nt + ln;
+    if (nt < NT && col < E) {
+      float ov[16];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = 4 * tg + t;
-        if (i < Q) {
-          const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);       // q_i / |q_i| (to 1e-13)
-          const float self = nq[i] > 0.0f ? sq[i] : 0.0f;
-          *(f32x4*)(gq + (int64_t)i * E + 4 * c) = (accq[s][t] - qv * self) * rq[i];
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int tok = mrow(i) + 4 * lh, tc = tok < Q ? tok : Q - 1;
+        const float self = nq[tc] > 0.0f ? sq[tc] : 0.0f;            // QH holds q_i / |q_i| (to 1e-13)
+        ov[i] = (accq[t][i] - QH[tc * ES + col] * self) * rq[tc];
       }
+      KP_KEEP16(ov);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (mrow(i) + 4 * lh < Q) gq[(uint32_t)((mrow(i) + 4 * lh) * E + col)] = ov[i];
     }
   }
+#if MM_KP_BWD_PHASE_TIMES
+  KP_PH(11);
+  __syncthreads();
+  if (tid == 0 && pair == 0)
+    for (int k = 0; k < 12; ++k) (k < K ? a.gw[k] : a.galpha[k - K]) = ph[k];
+#endif
 }
 
 }  // namespace mm
@@ -588,9 +714,9 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
   if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: too many pairs for one launch");
   // the tiled kernel whenever its tiles fit (every shape the reference's configs train at); the per-element kernel otherwise
   {
-    const int Dpad = (D + 31) & ~31, QS = (Q + 3) & ~3, NC = E >> 2;
+    const int Dpad = (D + 31) & ~31;
     const size_t tl = kp_bwd_tiled_lds_bytes(Q, E, Dpad);
-    if (Q <= 32 && !(E & 3) && K <= kTK && (QS >> 2) * NC <= 2 * kTT && tl <= 150 * 1024 &&
+    if (Q <= 32 && !(E & 3) && E <= 512 && K <= kTK && tl <= 150 * 1024 &&
         !(((uintptr_t)q | (uintptr_t)d | (uintptr_t)grad_q | (uintptr_t)grad_d) & 15) && !env().kp_bwd_untiled) {
       KpBwdArgs a{};
       a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w; a.go = grad_out;
@@ -600,15 +726,13 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
       size_t left = workspace ? workspace_bytes : 0;
       if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
       if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
-      if (d_gate) {
-        if (tl > 64 * 1024)
-          (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kernel_pool_bwd_tiled_kernel<true>, dim3((unsigned)n_pairs), dim3(kTT), tl, stream, a, Dpad);
-      } else {
-        if (tl > 64 * 1024)
-          (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kernel_pool_bwd_tiled_kernel<false>, dim3((unsigned)n_pairs), dim3(kTT), tl, stream, a, Dpad);
-      }
+      auto go = [&](auto kern) {
+        if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3(kTT), tl, stream, a, Dpad);
+      };
+      const bool small = 8 * E <= 5 * kTT;              // a thread's share of a 32-row block: five chunks (E <= 320) or eight
+      if (d_gate) small ? go(kernel_pool_bwd_tiled_kernel<true, 5>) : go(kernel_pool_bwd_tiled_kernel<true, 8>);
+      else small ? go(kernel_pool_bwd_tiled_kernel<false, 5>) : go(kernel_pool_bwd_tiled_kernel<false, 8>);
       return check_launch("kernel_pool_bwd_tiled_kernel");
     }
   }
