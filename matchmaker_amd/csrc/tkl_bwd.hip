@@ -17,7 +17,8 @@
 // layers, the 2-element LayerNorm, sat_emb_reduce1 / kernel_mult).  Exact zeros are constants as in the reference
 // (:257, :282: a window whose score is 0 is rewritten to -9900 and contributes nothing).
 // Per-document parameter gradients are written as rows [B, MM_TKL_NPARAMS] (summed on the host: deterministic);
-// chunk-row gradients are accumulated window after window by one workgroup (no atomics).
+// chunk-row gradients are accumulated window after window by one workgroup (the untiled kernel: read-modify-write; the
+// tiled one: no-return float atomics issued in window order — deterministic either way).
 // Correctness path: training batches are tens of documents.
 #include "mm_internal.h"
 
@@ -363,55 +364,94 @@ __global__ void __launch_bounds__(kBwdThreads) tkl_bwd_kernel(const TklBwdArgs a
 
 // ---------------------------------------------------------------------------------------------
 // Tiled variant (round 4).  tkl_bwd_kernel above takes every dot product straight from global memory, one dependent load
-// per FMA: 4.6 ms per DOCUMENT (bench.py extra.train_step: 22 ms for 2,048 documents, 24 x the forward).  Here the
-// normalised query tile and the 30 rows of the current window are staged in LDS and the three small products of a window
-// (cosines, chunk-row gradients, query gradient) are register-blocked exactly as in kernel_pool_bwd_tiled_kernel
-// (kernel_pool_bwd.hip); the query gradient accumulates in registers over the 15 windows.  The scalar chain between them
-// (pooled kernels, lengths, saturation forward + backward, parameter gradients) is the code above, re-indexed.
-// 512 threads, Q <= 32, E <= 384 (16-byte rows); other shapes take the kernel above.
+// per FMA: 4.6 ms per DOCUMENT (bench.py extra.train_step: 22 ms for 2,048 documents, 24 x the forward).  Here, per
+// document (one 512-thread workgroup):
+//   * the normalised query tile and the 30 rows of the current window live in LDS; the three small products of a window
+//     (cosines, chunk-row gradients, query gradient) run on the matrix pipe in exact fp32 exactly as in
+//     kernel_pool_bwd_tiled_kernel (kernel_pool_bwd.hip: K split over the eight wavefronts for the cosines, 32-column tiles
+//     of E for the gradients); the query gradient accumulates in registers over the 15 windows;
+//   * the 15 windows, their row tables (document position -> packed chunk row, two dependent global reads each) and masks are
+//     resolved ONCE, in parallel, before the window loop; the rows of window n + 1 are fetched into registers while window n
+//     is computed (one workgroup per CU: nothing else hides a load issued at its point of use);
+//   * the scalar chain between the products (pooled kernels, lengths, saturation forward + backward, parameter gradients)
+//     reads its constants from LDS; the window lengths come out of the pooling threads' own activations (a 30-bit set per
+//     query token) instead of a second 30 x 11 exponential loop on one wavefront.
+// (The first tiled version — VALU FMA products, loads at the point of use, global parameter reads inside the loops — took
+// 4.9 ms for 2,048 documents.)  Q <= 32, E <= 512 (16-byte rows); other shapes take the kernel above.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTT = 512;
+constexpr int kKS = 12;        // row stride of the [token][kernel] tables (16-byte rows, the twelfth entry is zero)
+
+__host__ __device__ inline int tkl_bwd_row_stride(int E) { return ((E >> 2) & 1) ? E + 8 : E + 4; }   // odd number of 16-byte units
 
 __host__ __device__ inline size_t tkl_bwd_tiled_lds_bytes(int Wp, int Q, int E) {
-  const int ES = E + 4, QS = (Q + 3) & ~3;
-  return ((size_t)2 * Wp + (size_t)Q * ES + 32 * (size_t)ES + 3 * 32 * (size_t)QS + 2 * kBwdQ * kK + kBwdQ * 40 + 8 * kBwdQ + 4 * 32 +
-          16 + 32) * 4 + 64;
+  const int ES = tkl_bwd_row_stride(E), QS = (Q + 3) & ~3;
+  return ((size_t)Q * ES + 32 * (size_t)ES + 2 * 32 * (size_t)QS + 2 * kBwdQ * kKS + kBwdQ * 40 + 8 * kBwdQ + 4 * 32 + 16 + 4 * kKS +
+          2 * kKS + 16 + 4 * 1024 + 2 * 15 * 32 + 3 * 64 + 44 + 2 * 64 * (size_t)QS + 2 * (size_t)Wp) * 4 + 64;
 }
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+__device__ __forceinline__ constexpr int mrow(int i) { return (i & 3) + 8 * (i >> 2); }   // C/D layout of the 32x32 MFMA: acc[i] of lane l = row mrow(i) + 4 (l >> 5), column l & 31
 
+// Phase clocks (tools/build_variant.sh phases tkl_bwd -DMM_TKL_BWD_PHASE_TIMES=1): thread 0 of document 0 sums s_memtime
+// deltas per phase and overwrites the first entries of its parameter-gradient row with them.
+#ifndef MM_TKL_BWD_PHASE_TIMES
+#define MM_TKL_BWD_PHASE_TIMES 0
+#endif
+#if MM_TKL_BWD_PHASE_TIMES
+#define TKL_PH(k) do { const long long t_ = clock64(); ph[k] += (float)(t_ - t_last); t_last = t_; } while (0)
+#else
+#define TKL_PH(k) do { } while (0)
+#endif
+#define TKL_KEEP8(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]))
+#define TKL_KEEP16(v)                                                                                                         \
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), \
+               "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+
+template <int kLB>   // 16-byte chunks of a window's rows per thread = ceil(32 (E / 4) / kTT)
 __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = tid & 31, lh = (tid >> 5) & 1;          // MFMA lane coordinates within the wavefront
   const int C = a.C, Q = a.Q, E = a.E, W = a.W;
   const int Wp = W < 3 ? 3 : W;
-  const int ES = E + 4, QS = (Q + 3) & ~3, NC = E >> 2;
+  const int ES = tkl_bwd_row_stride(E), QS = (Q + 3) & ~3, NC = E >> 2;
   const float* prm = a.prm;
-  const float* sp = prm + TklParams::sat();
 
   float* QH = (float*)smem;                    // [Q][ES]  q_i / (|q_i| + tiny)
   float* DB = QH + Q * ES;                     // [32][ES] the window's rows (raw; rows 30, 31 and absent rows are zeros)
   float* CT = DB + 32 * ES;                    // [32][QS] cosines, [position][token]
-  float* GJ = CT + 32 * QS;                    // [32][QS] d loss / d c
-  float* GI = GJ + 32 * QS;                    // [QS][32]
-  float* pk = GI + QS * 32;                    // [kBwdQ][kK]
-  float* dpk = pk + kBwdQ * kK;                // [kBwdQ][kK]
-  float* red = dpk + kBwdQ * kK;               // [kBwdQ][40]
+  float* GI = CT + 32 * QS;                    // [QS][32] d loss / d c of the current block of a region, [token][position]
+  float* pk = GI + QS * 32;                    // [kBwdQ][kKS]
+  float* dpk = pk + kBwdQ * kKS;               // [kBwdQ][kKS]
+  float* red = dpk + kBwdQ * kKS;              // [kBwdQ][40]
   float* rq = red + kBwdQ * 40;                // [kBwdQ] each:
   float* nq = rq + kBwdQ;
   float* embv = nq + kBwdQ;
-  float* lens = embv + kBwdQ;
-  float* vals = lens + kBwdQ;
-  float* dev = vals + kBwdQ;
-  float* sq = dev + kBwdQ;                     // sum_t G c of the current window
-  float* sqs = sq + kBwdQ;                     // ... summed over the windows
-  float* rd = sqs + kBwdQ;                     // [32] each:
+  float* qmk = embv + kBwdQ;                   // query mask
+  int* lmask = (int*)(qmk + kBwdQ);            // positions of the window with a non-zero activation, one bit each
+  float* dev = (float*)(lmask + kBwdQ);
+  float* sqs = dev + kBwdQ;                    // sum_t G c, summed over the windows
+  float* vals = sqs + kBwdQ;                   // the window's value per query token
+  float* rd = vals + kBwdQ;                   // [32] each:
   float* nd = rd + 32;
-  float* mt = nd + 32;
-  float* td = mt + 32;
-  float* csg = td + 32;                        // [16]
-  int* prow = (int*)(csg + 16);                // [32]
-  float* orig = (float*)(prow + 32);           // [Wp]
+  float* td = nd + 32;
+  float* wcs = td + 32;                        // [15] chunk_scoring of the window list (+ padding)
+  float* csg = wcs + 32;                       // [16]
+  float* kc = csg + 16;                        // [kKS][4]: mu, -log2(e) / (2 sigma^2), 1 / sigma^2, -
+  float* dkm = kc + 4 * kKS;                   // [2][kKS]: dense, kernel_mult
+  float* spl = dkm + 2 * kKS;                  // [16] the saturation block's 13 parameters
+  float* PS = spl + 16;                        // [4][32][32] partial cosine tiles (wavefronts w and w + 4 share a slot)
+  int* prowA = (int*)(PS + 4 * 1024);          // [15][32] flat chunk row (p * 50 + row) of every position of every window, or -1
+  float* mtA = (float*)(prowA + 15 * 32);      // [15][32] mask x presence
+  int* prowR = (int*)(mtA + 15 * 32);          // [3][64] flat chunk row of every position of every region, -1 = none / a padding token
+  int* wlist = prowR + 3 * 64;                 // [15] the windows that carry gradient, in region order; [15] = their number
+  int* winf = wlist + 16;                      // [15] window index, -1 = an empty window (the constant 0, :282)
+  int* rinf = winf + 16;                       // [3] first position of region r, [4 + r] its number of positions, [8 + r] it overlaps an earlier region
+  float* Gsum = (float*)(rinf + 12);           // [64][QS] d loss / d c summed over the windows of the current region, by position
+  float* CTR = Gsum + 64 * QS;                 // [64][QS] cosines of the region's positions
+  float* orig = CTR + 64 * QS;                 // [Wp]
   float* work = orig + Wp;                     // [Wp]
   __shared__ float rv[kTT / 64];
   __shared__ int ri[kTT / 64];
@@ -420,15 +460,41 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   const float* qb = a.q_ctx + (int64_t)b * Q * E;
   float* gq = a.gq + (int64_t)b * Q * E;
   const float g = a.go[b];
+#if MM_TKL_BWD_PHASE_TIMES
+  float ph[16] = {0};
+  long long t_last = clock64();
+#endif
 
-  // ---- query tile: raw rows -> norms, emb . q_i -> normalised in place ----------------------------------------------
+  // ---- query tile: raw rows -> norms, emb . q_i -> normalised in place; constants -----------------------------------
   for (int idx = tid; idx < Q * NC; idx += kTT) {
     const int i = idx / NC, c = idx - i * NC;
     *(f32x4*)(QH + i * ES + 4 * c) = *(const f32x4*)(qb + (int64_t)i * E + 4 * c);
   }
   for (int idx = tid; idx < kBwdQ * 40; idx += kTT) red[idx] = 0.0f;
-  if (tid < 16) csg[tid] = 0.0f;
-  if (tid < kBwdQ) { dev[tid] = 0.0f; sqs[tid] = 0.0f; }
+  for (int idx = tid; idx < 2 * kBwdQ * kKS; idx += kTT) pk[idx] = 0.0f;      // pk and dpk (their padding stays zero)
+  if (tid < 16) {
+    csg[tid] = 0.0f;
+    spl[tid] = tid < 13 ? prm[TklParams::sat() + tid] : 0.0f;
+  }
+  if (tid < kBwdQ) {
+    dev[tid] = 0.0f;
+    sqs[tid] = 0.0f;
+    qmk[tid] = tid < Q ? a.q_mask[(int64_t)b * Q + tid] : 0.0f;
+  }
+  if (tid >= 64 && tid < 64 + kKS) {
+    const int k = tid - 64;
+    f32x4 kp = {0.0f, 0.0f, 0.0f, 0.0f};
+    float dn = 0.0f, km = 0.0f;
+    if (k < kK) {
+      const float sg = prm[TklParams::sigma() + k];
+      kp = f32x4{prm[TklParams::mu() + k], -1.4426950408889634f / (2.0f * sg * sg), 1.0f / (sg * sg), 0.0f};
+      dn = prm[TklParams::dense() + k];
+      km = prm[TklParams::kmult() + k];
+    }
+    *(f32x4*)(kc + 4 * k) = kp;
+    dkm[k] = dn;
+    dkm[kKS + k] = km;
+  }
   for (int w = tid; w < Wp; w += kTT) {
     float s = w < W ? a.win[(int64_t)b * W + w] : 0.0f;
     if (s == 0.0f) s = -9900.0f;
@@ -490,284 +556,476 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     }
     __syncthreads();
   }
+  // ---- the window list (:276 order: peaks, -1, +1, -2, +2), every window's row table and every region's, resolved once --
+  if (wv == 0) {
+    const int j = lane;
+    bool valid = false;
+    int idx = 0;
+    if (j < 15) {
+      const int off = j < 3 ? 0 : (j < 6 ? -1 : (j < 9 ? 1 : (j < 12 ? -2 : 2)));
+      idx = top_s[j % 3] + off;
+      idx = idx < 0 ? 0 : (idx >= Wp ? Wp - 1 : idx);            // :277-278
+      valid = orig[idx] > -9900.0f;                              // :282 an empty window is the constant 0
+      wcs[j] = prm[TklParams::chunk_scoring() + j];
+      winf[j] = valid ? idx : -1;
+    }
+    // the list in REGION order (region r = the windows j = r, r + 3, ..., r + 12 around peak r): the five windows of a region
+    // overlap in 28 of their 30 positions, and d loss / d c is summed over them per POSITION before the two gradient
+    // products run once per region (below)
+    const int jr = j < 15 ? (j % 3) * 5 + j / 3 : 63;            // rank of window j in region order
+    const unsigned long long m = __ballot(valid);
+    if (valid) {
+      int before = 0;
+      for (int o = 0; o < 15; ++o) {
+        const int rank_o = (o % 3) * 5 + o / 3;
+        before += (((m >> o) & 1ull) && rank_o < jr) ? 1 : 0;
+      }
+      wlist[before] = j;
+    }
+    if (lane == 0) wlist[15] = __popcll(m);
+    if (lane < 3) {                                              // region r: first position, number of positions (<= 38)
+      int lo = 0x7fffffff, hi = -1;
+      for (int o = 0; o < 5; ++o) {
+        const int jj = lane + 3 * o;
+        int ix = top_s[lane] + (o == 0 ? 0 : (o == 1 ? -1 : (o == 2 ? 1 : (o == 3 ? -2 : 2))));
+        ix = ix < 0 ? 0 : (ix >= Wp ? Wp - 1 : ix);
+        if (orig[ix] > -9900.0f) { lo = ix < lo ? ix : lo; hi = ix > hi ? ix : hi; }
+        (void)jj;
+      }
+      rinf[lane] = hi >= 0 ? 2 * lo : 0;
+      rinf[4 + lane] = hi >= 0 ? 2 * (hi - lo) + kBwdT : 0;
+      // does region r touch positions of an earlier region?  (peaks are >= 15 windows = 30 positions apart and a region
+      // spans <= 38: rarely) — only then must its chunk rows be read before they are added to
+      const int p0 = hi >= 0 ? 2 * lo : 0, p1 = hi >= 0 ? 2 * hi + kBwdT : 0;
+      int ov = 0;
+      for (int o = 0; o < 2; ++o) {
+        const int q0 = __shfl(p0, o, 64), q1 = __shfl(p1, o, 64);
+        if (o < lane && q1 > q0 && p1 > p0 && q0 < p1 && p0 < q1) ov = 1;
+      }
+      rinf[8 + lane] = ov;
+    }
+  }
+  __syncthreads();
+  auto resolve = [&](int pos, bool in, int& flat, float& m) {      // document position -> packed chunk row and its mask
+    flat = -1;
+    m = 0.0f;
+    if (in && pos < C * 40) {
+      const int c = pos / 40;
+      const int info = a.slot2p[(int64_t)b * C + c];
+      if (info >= 0) {
+        flat = (info >> 2) * 50 + 5 + (pos - 40 * c);
+        m = a.chunk_mask[flat] != 0.0f ? 1.0f : 0.0f;
+      }
+    }
+  };
+  for (int e2 = tid; e2 < 15 * 32 + 3 * 64; e2 += kTT) {
+    int flat;
+    float m;
+    if (e2 < 15 * 32) {
+      const int j = e2 >> 5, t = e2 & 31;
+      const int ix = winf[j];
+      resolve(2 * ix + t, ix >= 0 && t < kBwdT, flat, m);
+      prowA[e2] = flat;
+      mtA[e2] = m;
+    } else {
+      const int r = (e2 - 15 * 32) >> 6, p2 = (e2 - 15 * 32) & 63;
+      resolve(rinf[r] + p2, p2 < rinf[4 + r], flat, m);
+      prowR[r * 64 + p2] = m != 0.0f ? flat : -1;
+    }
+  }
+  __syncthreads();
+  const int nv = wlist[15];
 
-  const int rg = tid >> 6, tg8 = (tid >> 3) & 7, ks = tid & 7;      // cosine tile: 8 row groups x 8 token groups x 8 K slices
-  const int TQ = (Q + 7) >> 3;
-  const int TG = QS >> 2;
-  f32x4 accq[2][4];
+  // A block of rows travels global -> registers -> LDS in two steps (see kernel_pool_bwd_tiled_kernel): fetch() is called
+  // one window ahead inside a region, commit() once the current window's arithmetic has read DB.  A thread's chunks are the
+  // same (row, column) in every block.
+  int frow[kLB], fcol[kLB];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int u = 0; u < kLB; ++u) {
+    const int idx = tid + u * kTT;
+    frow[u] = 32;
+    fcol[u] = 0;
+    if (idx < 32 * NC) {
+      frow[u] = idx / NC;
+      fcol[u] = 4 * (idx - frow[u] * NC);
+    }
+  }
+  f32x4 nxt[kLB];
+  auto fetch = [&](const int* table) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) accq[s][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  const int offs[5] = {0, -1, 1, -2, 2};
-  for (int j = 0; j < 15; ++j) {
-    int idx = top_s[j % 3] + offs[j / 3];                       // :276 order: peaks, -1, +1, -2, +2
-    idx = idx < 0 ? 0 : (idx >= Wp ? Wp - 1 : idx);            // :277-278
-    const float wfwd = orig[idx];
-    const float cs = prm[TklParams::chunk_scoring() + j];
-    if (wfwd <= -9900.0f) continue;                             // :282 an empty window is the constant 0 (uniform branch)
-    if (tid < 32) {                                             // the window's 30 positions -> chunk rows
-      const int pos = 2 * idx + tid;
-      int flat = -1;
-      float m = 0.0f;
-      if (tid < kBwdT && pos < C * 40) {
-        const int c = pos / 40;
-        const int info = a.slot2p[(int64_t)b * C + c];
-        if (info >= 0) {
-          flat = (info >> 2) * 50 + 5 + (pos - 40 * c);
-          m = a.chunk_mask[flat] != 0.0f ? 1.0f : 0.0f;
-        }
+    for (int u = 0; u < kLB; ++u) {
+      nxt[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      const int flat = frow[u] < 32 ? table[frow[u]] : -1;
+      if (flat >= 0) nxt[u] = *(const f32x4*)(a.chunks + (int64_t)flat * E + fcol[u]);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < kLB; ++u)
+      if (frow[u] < 32) *(f32x4*)(DB + frow[u] * ES + fcol[u]) = nxt[u];
+  };
+  auto row_norms = [&]() {                              // sixteen threads per row of DB
+    const int row = tid >> 4, sub = tid & 15;
+    float ss = 0.0f;
+    for (int c = sub; c < NC; c += 16) {
+      const f32x4 v = *(const f32x4*)(DB + row * ES + 4 * c);
+      ss += dot4(v, v);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    if (sub == 0) {
+      const float nn = sqrtf(ss);
+      nd[row] = nn;
+      rd[row] = 1.0f / (nn + 1e-13f);
+    }
+  };
+
+  const int NT = (E + 31) >> 5;                         // 32-column tiles of E; wavefront w owns tiles w and w + 8
+  const int KQ = (Q + 1) >> 1;                          // MFMA steps over the query tokens
+  f32x16 accq[2];
+  accq[0] = f32x16{0};
+  accq[1] = f32x16{0};
+  TKL_PH(0);
+  for (int n = 0; n < nv; ++n) {
+    const int j = wlist[n];
+    const int r = j % 3;
+    const bool first = n == 0 || wlist[n - 1] % 3 != r;            // (wave-uniform: LDS values)
+    const bool last = n + 1 == nv || wlist[n + 1] % 3 != r;
+    const int* prow = prowA + j * 32;
+    const float* mt = mtA + j * 32;
+    const float cs = wcs[j];
+    const int poff = 2 * winf[j] - rinf[r];                        // first position of the window inside its region
+    if (first) {
+      fetch(prow);                                                 // (not prefetched: the registers carried the previous region's rows)
+      for (int idx = tid; idx < 64 * QS; idx += kTT) Gsum[idx] = 0.0f;
+    }
+    commit();
+    __syncthreads();
+    if (!last) fetch(prowA + wlist[n + 1] * 32);
+    TKL_PH(1);
+    row_norms();
+    if (tid < kBwdQ) lmask[tid] = 0;
+    {  // cosine tile: this wavefront's K slice of the 32 x 32 tile; the eight partial tiles meet in LDS in a fixed order
+      f32x16 acc = {0};
+      const float* arow = DB + ln * ES;
+      const float* brow = QH + (ln < Q ? ln : Q - 1) * ES;
+      for (int p = wv; 2 * p < NC; p += 8) {
+        const int cc = 2 * p + lh;
+        const int cl = cc < NC ? cc : NC - 1;            // (odd NC: the last pair's upper half multiplies zeros)
+        f32x4 av = *(const f32x4*)(arow + 4 * cl);
+        const f32x4 bv = *(const f32x4*)(brow + 4 * cl);
+        if (cc >= NC) av = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q4], bv[q4], acc, 0, 0, 0);
       }
-      prow[tid] = flat;
-      mt[tid] = m;
+      float* ps = PS + (wv & 3) * 1024 + 4 * lh * 32 + ln;
+      if (wv >= 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] = acc[i];
+      }
+      __syncthreads();
+      if (wv < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] += acc[i];
+      }
     }
     __syncthreads();
-    for (int e2 = tid; e2 < 32 * NC; e2 += kTT) {               // rows -> LDS
-      const int row = e2 / NC, c = e2 - row * NC;
-      const int flat = prow[row];
-      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (flat >= 0) v = *(const f32x4*)(a.chunks + (int64_t)flat * E + 4 * c);
-      *(f32x4*)(DB + row * ES + 4 * c) = v;
-    }
-    __syncthreads();
-    {  // row norms: sixteen threads per row
-      const int row = tid >> 4, sub = tid & 15;
-      float ss = 0.0f;
-      for (int c = sub; c < NC; c += 16) {
-        const f32x4 v = *(const f32x4*)(DB + row * ES + 4 * c);
-        ss += dot4(v, v);
-      }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
-      if (sub == 0) {
-        const float n = sqrtf(ss);
-        nd[row] = n;
-        rd[row] = 1.0f / (n + 1e-13f);
+    TKL_PH(2);
+    for (int idx = tid; idx < 1024; idx += kTT) {
+      const int row = idx >> 5, i = idx & 31;
+      const float v = (((PS[idx] + PS[1024 + idx]) + PS[2048 + idx]) + PS[3072 + idx]) * rd[row];
+      if (i < Q) {
+        CT[row * QS + i] = v;
+        if (row < kBwdT) CTR[(poff + row) * QS + i] = v;           // (the same bits from every window that holds the position)
       }
     }
     __syncthreads();
-    {  // cosines: thread = (4 rows, TQ tokens, every 8th chunk of E)
-      float acc[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[r][t] = 0.0f;
-      for (int c = ks; c < NC; c += 8) {
-        f32x4 dv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dv[r] = *(const f32x4*)(DB + (4 * rg + r) * ES + 4 * c);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          if (t < TQ) {
-            int i = tg8 * TQ + t;
-            i = i < Q ? i : Q - 1;
-            const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r][t] += dot4(dv[r], qv);
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          acc[r][t] += __shfl_xor(acc[r][t], 1, 64);
-          acc[r][t] += __shfl_xor(acc[r][t], 2, 64);
-          acc[r][t] += __shfl_xor(acc[r][t], 4, 64);
-        }
-      const int row = 4 * rg + (ks & 3);
-      const float rdv = rd[row];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = tg8 * TQ + t;
-        if (ks < 4 && t < TQ && i < Q) {
-          const float v = (ks & 3) == 0 ? acc[0][t] : ((ks & 3) == 1 ? acc[1][t] : ((ks & 3) == 2 ? acc[2][t] : acc[3][t]));
-          CT[row * QS + i] = v * rdv;
-        }
-      }
-    }
-    __syncthreads();
-    for (int e2 = tid; e2 < Q * kK; e2 += kTT) {                // pooled kernels of the window
-      const int i = e2 / kK, k = e2 - i * kK;
-      const float mu = prm[TklParams::mu() + k], sg = prm[TklParams::sigma() + k];
-      const float c2 = -1.0f / (2.0f * sg * sg);
+    TKL_PH(3);
+    for (int idx = tid >> 1; idx < Q * kK; idx += kTT / 2) {     // pooled kernels of the window: (i, k) on two threads, fifteen positions each
+      const int i = idx / kK, k = idx - i * kK;
+      const float mu = kc[4 * k], c2 = kc[4 * k + 1];
+      const int t0 = 15 * (tid & 1);
       float s = 0.0f;
-      for (int t = 0; t < kBwdT; ++t) {
-        const float d = CT[t * QS + i] - mu;
-        s += mt[t] * __expf(d * d * c2);
+      int bits = 0;
+#pragma unroll
+      for (int tt = 0; tt < 15; ++tt) {
+        const float d = CT[(t0 + tt) * QS + i] - mu;
+        const float e = mt[t0 + tt] * __builtin_amdgcn_exp2f(d * d * c2);
+        s += e;
+        bits |= (e != 0.0f ? 1 : 0) << (t0 + tt);
       }
-      pk[i * kK + k] = s;
-    }
-    if (tid >= 448 && tid - 448 < Q) {                          // window lengths (:210), on the last wavefront
-      const int i = tid - 448;
-      int n = 0;
-      for (int t = 0; t < kBwdT; ++t) {
-        float any = 0.0f;
-        for (int k = 0; k < kK; ++k) {
-          const float sg = prm[TklParams::sigma() + k];
-          const float d = CT[t * QS + i] - prm[TklParams::mu() + k];
-          any += mt[t] * __expf(-d * d / (2.0f * sg * sg));
-        }
-        n += any != 0.0f ? 1 : 0;
+      s += __shfl_xor(s, 1, 64);
+      bits |= __shfl_xor(bits, 1, 64);
+      if (!(tid & 1)) {
+        pk[i * kKS + k] = s;
+        atomicOr(&lmask[i], bits);                                // window length (:210) = positions with any non-zero activation
       }
-      lens[i] = (float)n;
     }
     __syncthreads();
-    // ---- saturation forward + backward per query token (as above) -------------------------------------------------------
+    TKL_PH(4);
+    // ---- saturation forward + backward (as above): thread = (query token, kernel), sixteen lanes per token --------------------
+    // (On the first wavefront alone — one lane per token looping over the kernels — this chain of logs, exponentials and
+    // LDS read-modify-writes was 20 % of the kernel, the other seven wavefronts waiting at the barrier.)
     const float gw = g * cs;                                     // d loss / d w_j
-    if (tid < Q) {
-      const int i = tid;
-      const float len = lens[i];
-      const float f = a.q_mask[(int64_t)b * Q + i] * (len > 0.0f ? 1.0f : 0.0f);      // :248
-      float* rr = red + i * 40;      // [0..10] dense, [11..21] kernel_mult, [22..34] saturation block (13)
+    {
+      const int i = tid >> 4, k = tid & 15;
+      const bool tin = i < Q, kin = k < kK;
+      const int ic = tin ? i : 0;
+      const float len = (float)__popc(lmask[ic]);
+      const float f = tin ? qmk[ic] * (len > 0.0f ? 1.0f : 0.0f) : 0.0f;      // :248
+      float* rr = red + ic * 40;       // [0..10] dense, [11..21] kernel_mult, [22..34] saturation block (13)
+      const float p = pk[ic * kKS + (kin ? k : kKS - 1)];
+      const float dk = dkm[kin ? k : kKS - 1];                   // (the twelfth entries are zero)
+      const float dsat = gw * f * dk;
       float val = 0.0f;
       if (a.sat == MM_TKL_SAT_EMBEDDING) {
-        const float x0 = embv[i], x1 = len;
+        const float x0 = embv[ic], x1 = len;
         const float mean = (x0 + x1) * 0.5f;
         const float d0 = x0 - mean, d1 = x1 - mean;
         const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
         const float xh0 = d0 * rstd, xh1 = d1 * rstd;
-        const float n0 = xh0 * sp[9] + sp[11], n1 = xh1 * sp[10] + sp[12];
-        const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];
-        const float u = n0 * sp[3] + n1 * sp[4] + sp[5];
+        const float n0 = xh0 * spl[9] + spl[11], n1 = xh1 * spl[10] + spl[12];
+        const float s1 = n0 * spl[0] + n1 * spl[1] + spl[2];
+        const float u = n0 * spl[3] + n1 * spl[4] + spl[5];
         const float s2 = 1.0f / u;
-        const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];
-        float ds1 = 0.0f, ds2 = 0.0f, ds3 = 0.0f;
-        for (int k = 0; k < kK; ++k) {
-          const float p = pk[i * kK + k];
-          const float x = fmaxf(p, 1e-10f);
-          const float lx = __logf(x);
-          const float xp = __expf(s2 * lx);
-          const float sat = s1 * xp - s3;
-          const float dk = prm[TklParams::dense() + k];
-          val += dk * (sat * f);
-          const float dsat = gw * f * dk;
+        const float s3 = n0 * spl[6] + n1 * spl[7] + spl[8];
+        const float x = fmaxf(p, 1e-10f);
+        const float lx = __logf(x);
+        const float xp = __expf(s2 * lx);
+        const float sat = s1 * xp - s3;
+        const bool on = tin && kin;                               // (idle lanes must contribute exact zeros, not 0 x inf)
+        val = on ? dk * (sat * f) : 0.0f;
+        float ds1 = on ? dsat * xp : 0.0f, ds3 = on ? -dsat : 0.0f, ds2 = on ? dsat * s1 * xp * lx : 0.0f;
+        if (on) {
           rr[k] += gw * f * sat;                                  // d dense_k
-          ds1 += dsat * xp;
-          ds3 -= dsat;
-          ds2 += dsat * s1 * xp * lx;
-          dpk[i * kK + k] = p >= 1e-10f ? dsat * s1 * s2 * xp / x : 0.0f;
+          dpk[i * kKS + k] = p >= 1e-10f ? dsat * s1 * s2 * xp / x : 0.0f;
         }
-        const float du = -ds2 * s2 * s2;
-        const float dn0 = ds1 * sp[0] + du * sp[3] + ds3 * sp[6];
-        const float dn1 = ds1 * sp[1] + du * sp[4] + ds3 * sp[7];
-        rr[22 + 0] += ds1 * n0; rr[22 + 1] += ds1 * n1; rr[22 + 2] += ds1;
-        rr[22 + 3] += du * n0;  rr[22 + 4] += du * n1;  rr[22 + 5] += du;
-        rr[22 + 6] += ds3 * n0; rr[22 + 7] += ds3 * n1; rr[22 + 8] += ds3;
-        rr[22 + 9] += dn0 * xh0; rr[22 + 10] += dn1 * xh1;       // LayerNorm weight
-        rr[22 + 11] += dn0;      rr[22 + 12] += dn1;             // LayerNorm bias
-        const float dx0h = dn0 * sp[9], dx1h = dn1 * sp[10];
-        const float m1 = (dx0h + dx1h) * 0.5f, m2 = (dx0h * xh0 + dx1h * xh1) * 0.5f;
-        dev[i] += rstd * (dx0h - m1 - xh0 * m2);                 // d loss / d (emb . q_i); the length carries no gradient
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {                        // over the token's kernels (lanes 11..15 hold zeros)
+          ds1 += __shfl_xor(ds1, m, 64);
+          ds2 += __shfl_xor(ds2, m, 64);
+          ds3 += __shfl_xor(ds3, m, 64);
+          val += __shfl_xor(val, m, 64);
+        }
+        if (tin && k == 0) {
+          const float du = -ds2 * s2 * s2;
+          const float dn0 = ds1 * spl[0] + du * spl[3] + ds3 * spl[6];
+          const float dn1 = ds1 * spl[1] + du * spl[4] + ds3 * spl[7];
+          rr[22 + 0] += ds1 * n0; rr[22 + 1] += ds1 * n1; rr[22 + 2] += ds1;
+          rr[22 + 3] += du * n0;  rr[22 + 4] += du * n1;  rr[22 + 5] += du;
+          rr[22 + 6] += ds3 * n0; rr[22 + 7] += ds3 * n1; rr[22 + 8] += ds3;
+          rr[22 + 9] += dn0 * xh0; rr[22 + 10] += dn1 * xh1;       // LayerNorm weight
+          rr[22 + 11] += dn0;      rr[22 + 12] += dn1;             // LayerNorm bias
+          const float dx0h = dn0 * spl[9], dx1h = dn1 * spl[10];
+          const float m1 = (dx0h + dx1h) * 0.5f, m2 = (dx0h * xh0 + dx1h * xh1) * 0.5f;
+          dev[i] += rstd * (dx0h - m1 - xh0 * m2);                 // d loss / d (emb . q_i); the length carries no gradient
+        }
       } else {
-        for (int k = 0; k < kK; ++k) {
-          const float p = pk[i * kK + k];
-          const float km = prm[TklParams::kmult() + k];
-          const bool live = p * km >= 1e-10f;
-          const float sat = __logf(fmaxf(p * km, 1e-10f));
-          const float dk = prm[TklParams::dense() + k];
-          val += dk * (sat * f);
-          const float dsat = gw * f * dk;
+        const float km = dkm[kKS + (kin ? k : kKS - 1)];
+        const bool live = p * km >= 1e-10f;
+        const float sat = __logf(fmaxf(p * km, 1e-10f));
+        val = tin && kin ? dk * (sat * f) : 0.0f;
+        if (tin && kin) {
           rr[k] += gw * f * sat;
           rr[11 + k] += live ? dsat / km : 0.0f;
-          dpk[i * kK + k] = live ? dsat / p : 0.0f;
+          dpk[i * kKS + k] = live ? dsat / p : 0.0f;
         }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) val += __shfl_xor(val, m, 64);
       }
-      vals[i] = val;
+      if (k == 0) vals[i & 31] = tin ? val : 0.0f;
     }
     __syncthreads();
-    if (tid == 0) {                                             // d chunk_scoring_j = g * w_j (:249 sum in index order)
+    TKL_PH(5);
+    if (wv == 0) {                                              // d chunk_scoring_j = g * w_j (:249 sum in index order)
+      const float val = vals[lane & 31];
       float wj = 0.0f;
-      for (int i = 0; i < Q; ++i) wj += vals[i];
-      csg[j] += g * wj;
+      for (int i = 0; i < Q; ++i) wj += __shfl(val, i, 64);
+      if (lane == 0) csg[j] += g * wj;
     }
-    for (int e2 = tid; e2 < 32 * QS; e2 += kTT) {               // G = d loss / d c
-      const int t = e2 / QS, i = e2 - t * QS;
+    for (int idx = tid; idx < 1024; idx += kTT) {               // G = d loss / d c, added to the region's sum at the window's positions
+      const int t = idx >> 5, i = idx & 31;
+      const int ic = i < Q ? i : Q - 1;
+      const float c = CT[t * QS + ic];
+      const bool live = i < Q && mt[t] != 0.0f;                  // (mt[30], mt[31] are zero)
       float s = 0.0f;
-      if (i < Q && mt[t] != 0.0f) {
-        const float c = CT[t * QS + i];
-        for (int k = 0; k < kK; ++k) {
-          const float sg = prm[TklParams::sigma() + k];
-          const float d = c - prm[TklParams::mu() + k];
-          const float inv = 1.0f / (sg * sg);
-          s += dpk[i * kK + k] * __expf(-0.5f * d * d * inv) * (-d * inv);
+#pragma unroll
+      for (int k4 = 0; k4 < kKS; k4 += 4) {
+        const f32x4 a4 = *(const f32x4*)(dpk + ic * kKS + k4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const f32x4 kp = *(const f32x4*)(kc + 4 * (k4 + kk));      // the twelfth row is zeros, and so is dpk's twelfth entry
+          const float d = c - kp[0];
+          s -= a4[kk] * __builtin_amdgcn_exp2f(d * d * kp[1]) * d * kp[2];
         }
       }
-      GJ[t * QS + i] = s;
-      GI[i * 32 + t] = s;
+      if (live) Gsum[(poff + t) * QS + i] += s;
     }
     __syncthreads();
-    if (tid < Q) {
-      float s = 0.0f;
-      for (int t = 0; t < kBwdT; ++t) s += GI[tid * 32 + t] * CT[t * QS + tid];
-      sqs[tid] += s;
-    } else if (tid >= 64 && tid < 96) {
-      const int t = tid - 64;
-      float s = 0.0f;
-      for (int i = 0; i < Q; ++i) s += GJ[t * QS + i] * CT[t * QS + i];
-      td[t] = s;
-    }
-    __syncthreads();
-    // chunk-row gradients: item = (4 rows, one 16-byte chunk of E); overlapping windows accumulate into the same rows, one after
-    // the other inside this workgroup
-    for (int it = tid; it < 8 * NC; it += kTT) {
-      const int rgp = it / NC, c = it - rgp * NC;
-      f32x4 acc[4];
+    TKL_PH(6);
+    if (!last) continue;                                          // (wave-uniform)
+
+    // ---- the region's gradient products: its <= 38 positions as two blocks of 32 rows -------------------------------------
+    for (int hb = 0; hb < 2; ++hb) {
+      if (32 * hb >= rinf[4 + r]) break;
+      const int* ptab = prowR + r * 64 + 32 * hb;
+      const float* gs = Gsum + 32 * hb * QS;                     // [32][QS] d loss / d c of the block's positions
+      const float* ctr = CTR + 32 * hb * QS;
+      int fmin = 0x7fffffff;                                     // lowest chunk row of the block (wave-uniform after the reduction)
+      {
+        const int v = ptab[ln];
+        fmin = v >= 0 ? v : fmin;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      for (int i = 0; i < Q; ++i) {
-        const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
-        const f32x4 g4 = *(const f32x4*)(GI + i * 32 + 4 * rgp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += qv * g4[r];
+        for (int o = 16; o >= 1; o >>= 1) {
+          const int w2 = __shfl_xor(fmin, o, 64);
+          fmin = w2 < fmin ? w2 : fmin;
+        }
+        fmin = __builtin_amdgcn_readfirstlane(fmin == 0x7fffffff ? 0 : fmin);
       }
+      float* gblk = a.gchunks + (int64_t)fmin * E;
+      fetch(ptab);
+      for (int idx = tid; idx < 1024; idx += kTT) {              // the token-major copy the query-gradient product reads
+        const int t = idx >> 5, i = idx & 31;
+        if (i < QS) GI[i * 32 + t] = gs[t * QS + i];
+      }
+      commit();
+      __syncthreads();
+      TKL_PH(7);
+      row_norms();
+      __syncthreads();
+      {  // sixteen threads per position / per query token, two terms each
+        const int r16 = tid >> 4, sub = tid & 15;
+        const bool rin = 32 * hb + r16 < rinf[4 + r];            // (positions past the region hold stale cosines)
+        float s = 0.0f, u = 0.0f;
+        if (rin)
+          for (int i = sub; i < Q; i += 16) s += gs[r16 * QS + i] * ctr[r16 * QS + i];
+        if (r16 < Q)
+          for (int t = sub; t < 32; t += 16)
+            if (32 * hb + t < rinf[4 + r]) u += gs[t * QS + r16] * ctr[t * QS + r16];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * rgp + r;
-        const int flat = prow[row];
-        if (flat >= 0 && mt[row] != 0.0f) {
-          const f32x4 x = *(const f32x4*)(DB + row * ES + 4 * c);
-          const float self = nd[row] > 0.0f ? td[row] / nd[row] : 0.0f;
-          f32x4* dst = (f32x4*)(a.gchunks + (int64_t)flat * E + 4 * c);
-          *dst = *dst + (acc[r] - x * self) * rd[row];
+        for (int m = 1; m < 16; m <<= 1) {
+          s += __shfl_xor(s, m, 64);
+          u += __shfl_xor(u, m, 64);
+        }
+        if (sub == 0) {
+          const float nn = nd[r16];
+          td[r16] = nn > 0.0f ? s / nn : 0.0f;           // the row's own-direction term of the norm's gradient
+          if (r16 < Q) sqs[r16] += u;
         }
       }
-    }
-    // query gradient: item = (4 tokens, one chunk), accumulated over the windows
+      __syncthreads();
+      TKL_PH(8);
+      // (lane coordinates behind an opaque copy: everything derived from them below — some 80 LDS addresses — is then computed
+      // here, per block, instead of once before the window loop and kept in spilled registers)
+      int lq = ln, hq = lh;
+      asm volatile("" : "+v"(lq), "+v"(hq));
+      {  // chunk-row gradients: A[row][token] = G (K = tokens, two per step; zero past Q), shared by this wavefront's tiles.
+         // Regions may overlap each other by a few positions: rows are read, added to and written back; the regions follow
+         // each other inside this one workgroup.
+        float ga[16];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int it = tid + kTT * s;
-      if (it < TG * NC) {
-        const int tg = it / NC, c = it - tg * NC;
-        for (int t = 0; t < kBwdT; ++t) {
-          const f32x4 dv = *(const f32x4*)(DB + t * ES + 4 * c) * rd[t];
-          const f32x4 g4 = *(const f32x4*)(GJ + t * QS + 4 * tg);
+        for (int st = 0; st < 16; ++st) {
+          const int i = 2 * st + hq;
+          ga[st] = gs[lq * QS + (i < QS ? i : QS - 1)];
+          if (i >= Q) ga[st] = 0.0f;
+        }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) accq[s][u] += dv * g4[u];
+        for (int t = 0; t < 2; ++t) {
+          const int nt = wv + 8 * t;
+          if (nt >= NT) break;                             // wave-uniform
+          const int col = 32 * nt + lq;
+          const bool cin = col < E;
+          const float* qcol = QH + (cin ? col : 0);
+          const float* dcol = DB + (cin ? col : 0);
+          float bq[16];
+#pragma unroll
+          for (int st = 0; st < 16; ++st) {
+            const int i = 2 * st + hq;
+            bq[st] = qcol[(i < Q ? i : Q - 1) * ES];       // (multiplied by ga = 0 past Q)
+          }
+          f32x16 acc = {0};
+#pragma unroll
+          for (int g2 = 0; g2 < 8; ++g2) {
+            if (2 * g2 < KQ) {                             // wave-uniform
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[2 * g2], bq[2 * g2], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[2 * g2 + 1], bq[2 * g2 + 1], acc, 0, 0, 0);
+            }
+          }
+          // rows are addressed as 32-bit offsets from the block's lowest chunk row (one address register per store
+          // instead of a 64-bit pair and two wide multiplies: the block ran on spilled registers before)
+          float* gcol = gblk + (cin ? col : 0);
+          const bool rmw = rinf[8 + r] != 0;               // (wave-uniform) an earlier region wrote some of these rows
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {                 // eight rows at a time
+            float ov[8];
+            uint32_t of[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int row = mrow(8 * hf + i) + 4 * hq;
+              const int fl = ptab[row];                    // (-1: no such position, or a padding token)
+              ov[i] = (acc[8 * hf + i] - dcol[row * ES] * td[row]) * rd[row];
+              of[i] = (cin && fl >= 0) ? (uint32_t)(fl - fmin) * (uint32_t)E : 0xffffffffu;
+            }
+            if (rmw) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i)                  // eight reads in flight (lanes without a row read the block's first row and
+                ov[i] += gcol[of[i] != 0xffffffffu ? of[i] : 0u];      // drop it: no lane-conditional block around a load), then the stores
+            }
+            TKL_KEEP8(ov);
+            TKL_KEEP8(of);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (of[i] != 0xffffffffu) gcol[of[i]] = ov[i];
+          }
         }
       }
+      TKL_PH(9);
+      {  // query gradient: A[token][t] = G / (|d_t| + tiny) (K = the block's positions), B = the raw rows
+        float gi[16];
+        const int tk = lq < Q ? lq : Q - 1;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+          const int i = 2 * st + hq;
+          gi[st] = GI[tk * 32 + i] * rd[i];
+          if (lq >= Q) gi[st] = 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int nt = wv + 8 * t;
+          if (nt >= NT) break;
+          const int col = 32 * nt + lq;
+          const float* dcol = DB + (col < E ? col : 0);
+          float bd[16];
+#pragma unroll
+          for (int st = 0; st < 16; ++st) bd[st] = dcol[(2 * st + hq) * ES];
+#pragma unroll
+          for (int st = 0; st < 16; ++st) accq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gi[st], bd[st], accq[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();   // the next block / region reuses the LDS tiles and may touch the same chunk rows
+      TKL_PH(10);
     }
-    __syncthreads();   // the next window may touch the same chunk rows and reuses the LDS tiles
   }
 
   // ---- grad_q = rq (sum_w sum_t G dh - (sum G c) q / |q|) + dev emb_w; parameter rows of this document -----------------
   const bool emb_sat = a.sat == MM_TKL_SAT_EMBEDDING;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int it = tid + kTT * s;
-    if (it < TG * NC) {
-      const int tg = it / NC, c = it - tg * NC;
-      f32x4 ew = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (emb_sat) ew = *(const f32x4*)(prm + TklParams::emb() + 4 * c);
+  for (int t = 0; t < 2; ++t) {
+    const int nt = wv + 8 * t;
+    const int col = 32 * nt + ln;
+    if (nt < NT && col < E) {
+      const float ew = emb_sat ? prm[TklParams::emb() + col] : 0.0f;
+      float ov[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = 4 * tg + u;
-        if (i < Q) {
-          const f32x4 qv = *(const f32x4*)(QH + i * ES + 4 * c);
-          const float self = nq[i] > 0.0f ? sqs[i] : 0.0f;
-          *(f32x4*)(gq + (int64_t)i * E + 4 * c) = (accq[s][u] - qv * self) * rq[i] + ew * dev[i];
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int tok = mrow(i) + 4 * lh, tc = tok < Q ? tok : Q - 1;
+        const float self = nq[tc] > 0.0f ? sqs[tc] : 0.0f;            // QH holds q_i / |q_i| (to 1e-13)
+        ov[i] = (accq[t][i] - QH[tc * ES + col] * self) * rq[tc] + ew * dev[tc];
       }
+      TKL_KEEP16(ov);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (mrow(i) + 4 * lh < Q) gq[(uint32_t)((mrow(i) + 4 * lh) * E + col)] = ov[i];
     }
   }
   float* gp = a.gprm + (int64_t)b * a.NP;
@@ -788,6 +1046,12 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     gp[dst] = s;
   }
   if (tid < 15) gp[TklParams::chunk_scoring() + tid] = csg[tid];
+#if MM_TKL_BWD_PHASE_TIMES
+  TKL_PH(11);
+  __syncthreads();
+  if (tid == 0 && b == 0)
+    for (int k = 0; k < 12; ++k) gp[k] = ph[k];
+#endif
 }
 
 // slot2p for the backward (the forward's preparation kernels live in tkl.hip)
@@ -842,11 +1106,14 @@ extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* ch
   a.gprm = grad_params; a.C = C; a.Q = Q; a.E = E; a.W = W; a.NP = MM_TKL_NPARAMS(K, E); a.sat = saturation;
   {
     const size_t tl = tkl_bwd_tiled_lds_bytes(Wp, Q, E);
-    const int QS = (Q + 3) & ~3;
-    if (!(E & 3) && (QS >> 2) * (E >> 2) <= 2 * kTT && tl <= 150 * 1024 && !env().kp_bwd_untiled &&
+    if (!(E & 3) && E <= 512 && tl <= 150 * 1024 && !env().kp_bwd_untiled &&
         !(((uintptr_t)q_ctx | (uintptr_t)chunks | (uintptr_t)grad_q | (uintptr_t)grad_chunks | (uintptr_t)params) & 15)) {
-      if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)tkl_bwd_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-      hipLaunchKernelGGL(tkl_bwd_tiled_kernel, dim3((unsigned)B), dim3(kTT), tl, stream, a);
+      auto go = [&](auto kern) {
+        if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTT), tl, stream, a);
+      };
+      if (8 * E <= 5 * kTT) go(tkl_bwd_tiled_kernel<5>);      // a thread's share of a window's rows: five 16-byte chunks (E <= 320) or eight
+      else go(tkl_bwd_tiled_kernel<8>);
       return check_launch("tkl_bwd_tiled_kernel");
     }
   }

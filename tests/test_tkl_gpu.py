@@ -298,6 +298,8 @@ def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, 
         return s.detach(), q_ctx.grad, chunks.grad, {k: params[k].grad.clone() for k in names}
 
     s_n, gq_n, gc_n, gp_n = run(True)
+    s_2, gq_2, gc_2, gp_2 = run(True)                           # overlapping windows add into shared chunk rows in window order:
+    assert torch.equal(gc_n, gc_2) and torch.equal(gq_n, gq_2)  # the same bits from run to run
     s_t, gq_t, gc_t, gp_t = run(False)
     torch.testing.assert_close(s_n, s_t, rtol=1e-4, atol=1e-3)
     for got, want, name in [(gq_n, gq_t, "grad_q"), (gc_n, gc_t, "grad_chunks")] + [(gp_n[k], gp_t[k], k) for k in names]:
