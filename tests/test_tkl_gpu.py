@@ -249,7 +249,7 @@ def test_tkl_full_model_trains_end_to_end():
 
 
 @pytest.mark.parametrize("sat", ["embedding", "log"])
-@pytest.mark.parametrize("B,Q,D,E", [(4, 20, 2048, 300), (3, 7, 120, 64), (2, 32, 41, 128)])
+@pytest.mark.parametrize("B,Q,D,E", [(4, 20, 2048, 300), (3, 7, 120, 64), (2, 32, 41, 128), (2, 16, 300, 400)])
 def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, D, E):
     """mm_tkl_bwd vs autograd through `tests/tkl_window_reference.selected_window_scores` (the same 15-window computation in torch ops, itself pinned on
     the real class's gradients above): gradients w.r.t. the contextualised query, the contextualised chunks and every
@@ -305,6 +305,49 @@ def test_native_backward_equals_the_differentiable_torch_restatement(sat, B, Q, 
     for got, want, name in [(gq_n, gq_t, "grad_q"), (gc_n, gc_t, "grad_chunks")] + [(gp_n[k], gp_t[k], k) for k in names]:
         scale = max(1.0, float(want.abs().max()))
         torch.testing.assert_close(got, want, rtol=2e-3, atol=3e-4 * scale, msg=lambda m_, n=name: f"{n}: {m_}")
+
+
+@pytest.mark.parametrize("peaks", [[(10, 25, 40), (0, 15, 185)], [(100, 85, 70), (184, 169, 3)]])
+def test_backward_when_the_regions_overlap_or_sit_at_the_ends(peaks):
+    """mm_tkl_bwd sums d loss / d c per document position over the windows of a region and runs the gradient products per
+    region; a region that shares positions with an earlier one must read the rows it adds to.  The window scores handed to the
+    backward are planted so that the three peaks are exactly 15 windows apart (regions overlap by 8 positions) or sit at the
+    first / last window (neighbour indices clamp: the same window several times).  Against autograd through the torch
+    restatement given the same scores."""
+    from matchmaker_amd import ops
+    from matchmaker_amd.tkl import chunk_documents
+    dev = util.require_gpu()
+    torch.manual_seed(31)
+    B, Q, D, E, sat = 2, 12, 400, 64, "embedding"
+    m = make_model(E, sat, dev, bypass=True).train()
+    with torch.no_grad():
+        for lin in (m.saturation_linear, m.saturation_linear2, m.saturation_linear3):
+            lin.bias.fill_(2.0)
+            lin.weight.normal_(0, 0.3)
+        m.chunk_scoring.normal_(1.0, 0.3)
+    q = torch.randn(B, Q, E, device=dev)
+    d = torch.randn(B, D, E, device=dev)
+    qm = torch.ones(B, Q, device=dev)
+    dm = torch.ones(B, D, device=dev)
+    dm[1, 390:] = 0
+    go = torch.randn(B, device=dev)
+    chunks, cmask, slot, C = chunk_documents(d * dm.unsqueeze(-1), dm)
+    W = (C * 40 - 30) // 2 + 1
+    win = torch.rand(B, W, device=dev) * 0.1 + 0.01
+    for b in range(B):
+        for rank, w in enumerate(peaks[b]):
+            win[b, w] = 5.0 - rank
+    gq, gc, _ = ops.tkl_bwd(q, chunks, cmask, slot, qm, m.pack_params(), win, go, B, C, 11, sat)
+    gq2, gc2, _ = ops.tkl_bwd(q, chunks, cmask, slot, qm, m.pack_params(), win, go, B, C, 11, sat)
+    assert torch.equal(gq, gq2) and torch.equal(gc, gc2)
+    q_t = q.clone().requires_grad_(True)
+    c_t = chunks.clone().requires_grad_(True)
+    s = selected_window_scores(m, q_t, c_t, cmask, slot, qm, win, C)
+    (s * go).sum().backward()
+    for got, want, name in ((gq, q_t.grad, "grad_q"), (gc, c_t.grad, "grad_chunks")):
+        scale = max(1.0, float(want.abs().max()))
+        torch.testing.assert_close(got, want, rtol=2e-3, atol=3e-4 * scale, msg=lambda m_, n=name: f"{n}: {m_}")
+    assert float(gc.abs().sum()) > 0
 
 
 def ops_tkl(q_ctx, chunks, cmask, slot, qm, m, B, C, sat):
