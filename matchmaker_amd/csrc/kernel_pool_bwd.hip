@@ -17,10 +17,11 @@
 // replaces dmask_j by dmask_j s_j in pkq and G, and gets grad_s_j = dmask_j sum_ik A_ik e_ijk; the floor
 // 1e-10 inside the log is a parameter (1e-4: IDCM sampler, sigir21_idcm.py:185).
 //
-// One workgroup (256 threads) per pair, fp32 VALU throughout: training batches are tens of pairs, so
-// this is a correctness path — what matters is that loss.backward() stays on the device without a
-// [B,Q,D,K] tensor, for ANY document length (the [Q,D] tiles are swept DT positions at a time).
-// Pair-per-row layout (the one train.py feeds: neuralIR_encoder.py:86-87).
+// Two kernels.  kernel_pool_bwd_tiled_kernel (below; every shape the reference's configs train at) keeps the pair's tiles
+// in LDS and runs its three products on the matrix pipe in exact fp32.  kernel_pool_bwd_kernel (first) is the general
+// fallback — one 256-thread workgroup per pair, fp32 VALU, operands straight from global memory — for ANY document length
+// and width (the [Q,D] tiles are swept DT positions at a time): what matters there is that loss.backward() stays on the
+// device without a [B,Q,D,K] tensor.  Pair-per-row layout (the one train.py feeds: neuralIR_encoder.py:86-87).
 #include "mm_internal.h"
 
 namespace mm {

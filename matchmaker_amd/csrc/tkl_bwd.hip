@@ -19,7 +19,7 @@
 // Per-document parameter gradients are written as rows [B, MM_TKL_NPARAMS] (summed on the host: deterministic);
 // chunk-row gradients are accumulated window after window by one workgroup (the untiled kernel: read-modify-write; the
 // tiled one: no-return float atomics issued in window order — deterministic either way).
-// Correctness path: training batches are tens of documents.
+// tkl_bwd_tiled_kernel (below) is the product path; tkl_bwd_kernel (first) the general fallback for shapes its tiles do not fit.
 #include "mm_internal.h"
 
 namespace mm {
