@@ -265,21 +265,23 @@ __global__ void __launch_bounds__(256) kernel_pool_bwd_kernel(const KpBwdArgs a,
 //     document block), accumulated in registers across the blocks.
 // (The first version of this kernel ran the three products as register-blocked VALU FMAs out of the same LDS tiles:
 // 1.12 ms for 2,048 pairs, 17 % VALU utilisation — every FMA needed its operands from LDS.)
+// Two forms: 1,024 threads (sixteen wavefronts, <= 128 registers: one column tile per wavefront, twice the wavefronts to
+// hide the phases' latencies; 0.79 ms for 2,048 pairs) when its 8 partial-tile slots fit the LDS, else 512 threads (0.85 ms).
 // The document is read from HBM/L2 twice and its gradient written once.  Q <= 32, E <= 384 (16-byte rows), K <= 16, LDS
 // permitting; everything else takes the kernel above.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTK = 16;
-constexpr int kTT = 512;   // threads of the tiled kernel: eight wavefronts, two per SIMD, around ONE set of LDS tiles per CU
+constexpr int kTT = 512;   // threads of the tiled kernel's smaller form (eight wavefronts, two per SIMD, around ONE set of LDS tiles per CU); the default form has 1,024
 
 // Row stride of the [row][E] tiles in floats: an ODD number of 16-byte units, so that the sixteen lanes of a ds_read_b128
 // phase that read one column chunk of sixteen consecutive rows (the A / B operands of the cosine MFMAs) cover all 64 banks.
 // (E + 4 alone is even for E = 300: 304 floats = 48 banks apart, rows r and r + 4 on the same banks, 8-way conflicts.)
 __host__ __device__ inline int kp_bwd_row_stride(int E) { return ((E >> 2) & 1) ? E + 8 : E + 4; }
 
-__host__ __device__ inline size_t kp_bwd_tiled_lds_bytes(int Q, int E, int Dpad) {
+__host__ __device__ inline size_t kp_bwd_tiled_lds_bytes(int Q, int E, int Dpad, int nthr = 512) {
   const int ES = kp_bwd_row_stride(E), QS = (Q + 3) & ~3;
   return ((size_t)Q * ES + 32 * (size_t)ES + (size_t)Dpad * QS + 3 * 32 * (size_t)QS + 2 * (size_t)Q * kTK + 4 * (size_t)Dpad +
-          5 * 32 + 4 * kTK + 4 * 1024) * 4;
+          5 * 32 + 4 * kTK + (nthr / 128) * 1024) * 4;
 }
 
 __device__ __forceinline__ constexpr int mrow(int i) { return (i & 3) + 8 * (i >> 2); }   // C/D layout of the 32x32 MFMA: acc[i] of lane l = row mrow(i) + 4 (l >> 5), column l & 31
@@ -304,8 +306,12 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a
 #define KP_PH(k) do { } while (0)
 #endif
 
-template <bool GATE, int kLB>   // kLB: 16-byte chunks of a document block per thread = ceil(32 (E / 4) / kTT)
-__global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdArgs a, const int Dpad) {
+template <bool GATE, int kLB, int NTHR>   // kLB: 16-byte chunks of a document block per thread = ceil(32 (E / 4) / NTHR)
+__global__ void __launch_bounds__(NTHR) kernel_pool_bwd_tiled_kernel(const KpBwdArgs a, const int Dpad) {
+  constexpr int NW = NTHR / 64;          // wavefronts: 8 (two per SIMD, 256 registers each) or 16 (four per SIMD, 128 each)
+  constexpr int NS = NW / 2;             // slots of partial cosine tiles (wavefronts w and w + NS share one)
+  constexpr int TPW = 16 / NW;           // 32-column tiles of E per wavefront (E <= 512)
+  constexpr int PP = NTHR / 256;         // threads per (token, kernel) in the pooling phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int64_t pair = blockIdx.x;
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
 #endif
 
   // ---- query tile, constants ---------------------------------------------------------------------------------
-  for (int idx = tid; idx < Q * NC; idx += kTT) {
+  for (int idx = tid; idx < Q * NC; idx += NTHR) {
     const int i = idx / NC, c = idx - i * NC;
     *(f32x4*)(QH + i * ES + 4 * c) = *(const f32x4*)(qb + (int64_t)i * E + 4 * c);
   }
@@ -356,10 +362,10 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
     }
     *(f32x4*)(kc + 4 * tid) = kp;
   }
-  for (int idx = tid; idx < Q * kTK; idx += kTT) PK[idx] = 0.0f;
+  for (int idx = tid; idx < Q * kTK; idx += NTHR) PK[idx] = 0.0f;
   if (tid < 32) sq[tid] = 0.0f;
   __syncthreads();
-  {  // norms: sixteen threads per query token; the tile is stored normalised
+  if (tid < 512) {  // norms: sixteen threads per query token; the tile is stored normalised
     const int i = tid >> 4, sub = tid & 15;
     float ss = 0.0f;
     if (i < Q)
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
   int frow[kLB], fcol[kLB];
 #pragma unroll
   for (int u = 0; u < kLB; ++u) {
-    const int idx = tid + u * kTT;
+    const int idx = tid + u * NTHR;
     frow[u] = 32;
     fcol[u] = 0;
     if (idx < 32 * NC) {
@@ -427,7 +433,7 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
     commit();
     __syncthreads();
     KP_PH(1);
-    {  // row norms and masks: sixteen threads per row
+    if (tid < 512) {  // row norms and masks: sixteen threads per row (whole wavefronts)
       const int row = tid >> 4, sub = tid & 15;
       float ss = 0.0f;
       for (int c = sub; c < NC; c += 16) {
@@ -458,7 +464,7 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
       f32x16 acc = {0};
       const float* arow = DB + ln * ES;
       const float* brow = QH + (ln < Q ? ln : Q - 1) * ES;
-      for (int p = wv; 2 * p < NC; p += 8) {
+      for (int p = wv; 2 * p < NC; p += NW) {
         const int cc = 2 * p + lh;
         const int cl = cc < NC ? cc : NC - 1;            // (odd NC: the last pair's upper half multiplies zeros)
         f32x4 av = *(const f32x4*)(arow + 4 * cl);
@@ -467,45 +473,48 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
       }
-      float* ps = PS + (wv & 3) * 1024 + 4 * lh * 32 + ln;
-      if (wv >= 4) {
+      float* ps = PS + (wv % NS) * 1024 + 4 * lh * 32 + ln;
+      if (wv >= NS) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] = acc[i];
       }
       __syncthreads();
-      if (wv < 4) {
+      if (wv < NS) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] += acc[i];
       }
     }
     __syncthreads();
     KP_PH(3);
-    for (int idx = tid; idx < 1024; idx += kTT) {
+    for (int idx = tid; idx < 1024; idx += NTHR) {
       const int row = idx >> 5, i = idx & 31;
-      const float v = ((PS[idx] + PS[1024 + idx]) + PS[2048 + idx]) + PS[3072 + idx];
+      float v = PS[idx];
+#pragma unroll
+      for (int w = 1; w < NS; ++w) v += PS[w * 1024 + idx];
       if (i < Q) CT[(j0 + row) * QS + i] = v * RD[j0 + row];
     }
     __syncthreads();
     KP_PH(4);
-    for (int idx = tid >> 1; idx < Q * K; idx += kTT / 2) {   // (i, k): two threads, sixteen positions each; owned across the blocks
+    for (int idx = tid / PP; idx < Q * K; idx += NTHR / PP) {   // (i, k): PP threads, 32 / PP positions each; owned across the blocks
       const int i = idx / K, k = idx - i * K;
       const float mu = kc[4 * k], c2 = kc[4 * k + 1];
-      const int jb = j0 + 16 * (tid & 1);
+      const int jb = j0 + (32 / PP) * (tid % PP);
       float pk = 0.0f;
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
+      for (int jj = 0; jj < 32 / PP; ++jj) {
         const float t = CT[(jb + jj) * QS + i] - mu;
         pk += DMF[jb + jj] * __builtin_amdgcn_exp2f(t * t * c2);
       }
-      pk += __shfl_xor(pk, 1, 64);
-      if (!(tid & 1)) PK[i * kTK + k] += pk;
+#pragma unroll
+      for (int m = 1; m < PP; m <<= 1) pk += __shfl_xor(pk, m, 64);
+      if (!(tid % PP)) PK[i * kTK + k] += pk;
     }
     __syncthreads();
     KP_PH(5);
   }
 
   // ---- A_ik and the parameter gradients of this pair -----------------------------------------------------------
-  for (int idx = tid; idx < Q * K; idx += kTT) {
+  for (int idx = tid; idx < Q * K; idx += NTHR) {
     const int i = idx / K, k = idx - i * K;
     const float pk = PK[i * kTK + k];
     const float al = a.alpha[k];
@@ -532,14 +541,14 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
   // conditional LDS read in front of an MFMA becomes a branch, a wait and an exposed latency per step.
   const int NT = (E + 31) >> 5;                         // 32-column tiles of E; wavefront w owns tiles w and w + 8
   const int KQ = (Q + 1) >> 1;                          // MFMA steps over the query tokens
-  f32x16 accq[2];
-  accq[0] = f32x16{0};
-  accq[1] = f32x16{0};
+  f32x16 accq[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) accq[t] = f32x16{0};
   for (int j0 = 0; j0 < D; j0 += 32) {
     const int nj = D - j0 < 32 ? D - j0 : 32;
     commit();
     if (j0 + 32 < D) fetch(j0 + 32);
-    for (int idx = tid; idx < 1024; idx += kTT) {
+    for (int idx = tid; idx < 1024; idx += NTHR) {
       const int jj = idx >> 5, i = idx & 31;
       // every lane runs the arithmetic on a clamped token (reads ahead of the exp chain, no lane-conditional block)
       const int ic = i < Q ? i : Q - 1;
@@ -566,7 +575,7 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
     }
     __syncthreads();
     KP_PH(7);
-    {  // sixteen threads per row / per query token, two terms each
+    if (tid < 512) {  // sixteen threads per row / per query token, two terms each (whole wavefronts)
       const int r16 = tid >> 4, sub = tid & 15;
       float s = 0.0f, u = 0.0f, sgs = 0.0f;
       for (int i = sub; i < Q; i += 16) {                // sum_i G c of every position of the block
@@ -590,26 +599,30 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
     }
     __syncthreads();
     KP_PH(8);
+    // (lane coordinates behind an opaque copy: the ~80 per-lane LDS addresses derived from them below are then computed
+    // here, per block, instead of once before the loop and kept in registers the 1,024-thread form does not have)
+    int lq = ln, hq = lh;
+    asm volatile("" : "+v"(lq), "+v"(hq));
     {  // grad_d of the block: A[row][token] = G (K = tokens, two per step; zero past Q), shared by this wavefront's tiles
       float ga[16];
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
-        const int i = 2 * st + lh;
-        ga[st] = GJ[ln * QS + (i < QS ? i : QS - 1)];
+        const int i = 2 * st + hq;
+        ga[st] = GJ[lq * QS + (i < QS ? i : QS - 1)];
         if (i >= Q) ga[st] = 0.0f;
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int nt = wv + 8 * t;
+      for (int t = 0; t < TPW; ++t) {
+        const int nt = wv + NW * t;
         if (nt >= NT) break;                             // wave-uniform
-        const int col = 32 * nt + ln;
+        const int col = 32 * nt + lq;
         const bool cin = col < E;
         const float* qcol = QH + (cin ? col : 0);
         const float* dcol = DB + (cin ? col : 0);
         float bq[16];
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
-          const int i = 2 * st + lh;
+          const int i = 2 * st + hq;
           bq[st] = qcol[(i < Q ? i : Q - 1) * ES];       // (multiplied by ga = 0 past Q)
         }
         f32x16 acc = {0};
@@ -620,11 +633,11 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[2 * g2 + 1], bq[2 * g2 + 1], acc, 0, 0, 0);
           }
         }
-        const uint32_t o0 = (uint32_t)((j0 + 4 * lh) * E + col);
+        const uint32_t o0 = (uint32_t)((j0 + 4 * hq) * E + col);
         float ov[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int row = mrow(i) + 4 * lh;
+          const int row = mrow(i) + 4 * hq;
           ov[i] = (acc[i] - dcol[row * ES] * td[row]) * RD[j0 + row];
         }
         if (nj == 32 && 32 * nt + 32 <= E) {             // wave-uniform: a full tile of a full block stores without lane conditions
@@ -634,29 +647,29 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
           KP_KEEP16(ov);
 #pragma unroll
           for (int i = 0; i < 16; ++i)
-            if (cin && mrow(i) + 4 * lh < nj) gd[o0 + (uint32_t)(mrow(i) * E)] = ov[i];
+            if (cin && mrow(i) + 4 * hq < nj) gd[o0 + (uint32_t)(mrow(i) * E)] = ov[i];
         }
       }
     }
     KP_PH(9);
     {  // grad_q: A[token][row] = G / (|d_row| + tiny) (K = the block's rows), B = the raw document block
       float gi[16];
-      const int tk = ln < Q ? ln : Q - 1;
+      const int tk = lq < Q ? lq : Q - 1;
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
-        const int i = 2 * st + lh;
+        const int i = 2 * st + hq;
         gi[st] = GI[tk * 32 + i] * RD[j0 + i];
-        if (ln >= Q) gi[st] = 0.0f;
+        if (lq >= Q) gi[st] = 0.0f;
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int nt = wv + 8 * t;
+      for (int t = 0; t < TPW; ++t) {
+        const int nt = wv + NW * t;
         if (nt >= NT) break;
-        const int col = 32 * nt + ln;
+        const int col = 32 * nt + lq;
         const float* dcol = DB + (col < E ? col : 0);
         float bd[16];
 #pragma unroll
-        for (int st = 0; st < 16; ++st) bd[st] = dcol[(2 * st + lh) * ES];
+        for (int st = 0; st < 16; ++st) bd[st] = dcol[(2 * st + hq) * ES];
 #pragma unroll
         for (int st = 0; st < 16; ++st) accq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gi[st], bd[st], accq[t], 0, 0, 0);
       }
@@ -665,8 +678,8 @@ __global__ void __launch_bounds__(kTT) kernel_pool_bwd_tiled_kernel(const KpBwdA
     KP_PH(10);
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int nt = wv + 8 * t;
+  for (int t = 0; t < TPW; ++t) {
+    const int nt = wv + NW * t;
     const int col = 32 * nt + ln;
     if (nt < NT && col < E) {
       float ov[16];
@@ -716,7 +729,8 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
   // the tiled kernel whenever its tiles fit (every shape the reference's configs train at); the per-element kernel otherwise
   {
     const int Dpad = (D + 31) & ~31;
-    const size_t tl = kp_bwd_tiled_lds_bytes(Q, E, Dpad);
+    const int nthr = (env().kp_bwd_threads == 1024 && kp_bwd_tiled_lds_bytes(Q, E, Dpad, 1024) <= 150 * 1024) ? 1024 : 512;
+    const size_t tl = kp_bwd_tiled_lds_bytes(Q, E, Dpad, nthr);
     if (Q <= 32 && !(E & 3) && E <= 512 && K <= kTK && tl <= 150 * 1024 &&
         !(((uintptr_t)q | (uintptr_t)d | (uintptr_t)grad_q | (uintptr_t)grad_d) & 15) && !env().kp_bwd_untiled) {
       KpBwdArgs a{};
@@ -729,11 +743,18 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
       if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
       auto go = [&](auto kern) {
         if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3(kTT), tl, stream, a, Dpad);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3((unsigned)nthr), tl, stream, a, Dpad);
       };
-      const bool small = 8 * E <= 5 * kTT;              // a thread's share of a 32-row block: five chunks (E <= 320) or eight
-      if (d_gate) small ? go(kernel_pool_bwd_tiled_kernel<true, 5>) : go(kernel_pool_bwd_tiled_kernel<true, 8>);
-      else small ? go(kernel_pool_bwd_tiled_kernel<false, 5>) : go(kernel_pool_bwd_tiled_kernel<false, 8>);
+      // a thread's share of a 32-row block in 16-byte chunks: 512 threads: five (E <= 320) or eight; 1,024: three (E <= 384) or four
+      if (nthr == 1024) {
+        const bool small = E <= 384;
+        if (d_gate) small ? go(kernel_pool_bwd_tiled_kernel<true, 3, 1024>) : go(kernel_pool_bwd_tiled_kernel<true, 4, 1024>);
+        else small ? go(kernel_pool_bwd_tiled_kernel<false, 3, 1024>) : go(kernel_pool_bwd_tiled_kernel<false, 4, 1024>);
+      } else {
+        const bool small = E <= 320;
+        if (d_gate) small ? go(kernel_pool_bwd_tiled_kernel<true, 5, 512>) : go(kernel_pool_bwd_tiled_kernel<true, 8, 512>);
+        else small ? go(kernel_pool_bwd_tiled_kernel<false, 5, 512>) : go(kernel_pool_bwd_tiled_kernel<false, 8, 512>);
+      }
       return check_launch("kernel_pool_bwd_tiled_kernel");
     }
   }

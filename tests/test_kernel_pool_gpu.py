@@ -109,7 +109,7 @@ def test_kernel_pool_config1_scale_properties():
 
 @pytest.mark.parametrize("B,Q,D,E", [(4, 20, 200, 300), (3, 30, 47, 64), (2, 5, 3, 8), (3, 33, 70, 128),
                                      (2, 30, 2000, 64), (2, 20, 1000, 50),     # long documents: the [Q, D] tiles are swept in pieces
-                                     (3, 24, 100, 384), (2, 32, 60, 512)])      # wide rows: eight 16-byte chunks per thread and block, two column tiles per wavefront
+                                     (3, 24, 100, 384), (2, 32, 60, 512), (2, 8, 40, 448)])      # wide rows: eight 16-byte chunks per thread and block, two column tiles per wavefront
 def test_kernel_pool_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
     """mm_kernel_pool_bwd vs autograd through the torch port of ecai20_tk.py:105-124 (CPU, float64 and
     float32), incl. the two trainable pooling parameters, and through the drop-in's autograd function."""

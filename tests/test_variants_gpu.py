@@ -103,7 +103,7 @@ def test_gated_kernel_pool_vs_oracle(B, Q, D, E):
     np.testing.assert_allclose(ones.cpu().numpy(), plain.cpu().numpy(), atol=3e-4 if D > 1000 else 1e-5, rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,Q,D,E", [(4, 20, 200, 300), (3, 30, 47, 64), (3, 12, 64, 128), (2, 25, 1500, 100), (3, 20, 90, 384)])
+@pytest.mark.parametrize("B,Q,D,E", [(4, 20, 200, 300), (3, 30, 47, 64), (3, 12, 64, 128), (2, 25, 1500, 100), (3, 20, 90, 384), (2, 8, 40, 448)])
 def test_gated_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
     from matchmaker_amd import ops
     dev = util.require_gpu()
