@@ -640,9 +640,11 @@ __global__ void __launch_bounds__(NTHR) kernel_pool_bwd_tiled_kernel(const KpBwd
           const int row = mrow(i) + 4 * hq;
           ov[i] = (acc[i] - dcol[row * ES] * td[row]) * RD[j0 + row];
         }
-        if (nj == 32 && 32 * nt + 32 <= E) {             // wave-uniform: a full tile of a full block stores without lane conditions
+        if (nj == 32) {                                  // wave-uniform: a full block stores under ONE lane mask (the tile's columns < E)
+          if (cin) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) gd[o0 + (uint32_t)(mrow(i) * E)] = ov[i];   // 128-byte row segments per store
+            for (int i = 0; i < 16; ++i) gd[o0 + (uint32_t)(mrow(i) * E)] = ov[i];   // 128-byte row segments per store
+          }
         } else {
           KP_KEEP16(ov);
 #pragma unroll
