@@ -17,8 +17,9 @@
 // layers, the 2-element LayerNorm, sat_emb_reduce1 / kernel_mult).  Exact zeros are constants as in the reference
 // (:257, :282: a window whose score is 0 is rewritten to -9900 and contributes nothing).
 // Per-document parameter gradients are written as rows [B, MM_TKL_NPARAMS] (summed on the host: deterministic);
-// chunk-row gradients are accumulated window after window by one workgroup (the untiled kernel: read-modify-write; the
-// tiled one: no-return float atomics issued in window order — deterministic either way).
+// chunk-row gradients are accumulated by the one workgroup that owns the document — window after window (untiled kernel) or
+// region after region (tiled kernel: plain stores for a region that touches no earlier region's rows, else read-add-write) —
+// without atomics: deterministic.
 // tkl_bwd_tiled_kernel (below) is the product path; tkl_bwd_kernel (first) the general fallback for shapes its tiles do not fit.
 #include "mm_internal.h"
 
