@@ -380,15 +380,14 @@ __global__ void __launch_bounds__(kBwdThreads) tkl_bwd_kernel(const TklBwdArgs a
 // (The first tiled version — VALU FMA products, loads at the point of use, global parameter reads inside the loops — took
 // 4.9 ms for 2,048 documents.)  Q <= 32, E <= 512 (16-byte rows); other shapes take the kernel above.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTT = 512;
 constexpr int kKS = 12;        // row stride of the [token][kernel] tables (16-byte rows, the twelfth entry is zero)
 
 __host__ __device__ inline int tkl_bwd_row_stride(int E) { return ((E >> 2) & 1) ? E + 8 : E + 4; }   // odd number of 16-byte units
 
-__host__ __device__ inline size_t tkl_bwd_tiled_lds_bytes(int Wp, int Q, int E) {
+__host__ __device__ inline size_t tkl_bwd_tiled_lds_bytes(int Wp, int Q, int E, int nthr = 512) {
   const int ES = tkl_bwd_row_stride(E), QS = (Q + 3) & ~3;
   return ((size_t)Q * ES + 32 * (size_t)ES + 2 * 32 * (size_t)QS + 2 * kBwdQ * kKS + kBwdQ * 40 + 8 * kBwdQ + 4 * 32 + 16 + 4 * kKS +
-          2 * kKS + 16 + 4 * 1024 + 2 * 15 * 32 + 3 * 64 + 44 + 2 * 64 * (size_t)QS + 2 * (size_t)Wp) * 4 + 64;
+          2 * kKS + 16 + (nthr / 128) * 1024 + 2 * 15 * 32 + 3 * 64 + 44 + 2 * 64 * (size_t)QS + 2 * (size_t)Wp) * 4 + 64;
 }
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -409,8 +408,12 @@ __device__ __forceinline__ constexpr int mrow(int i) { return (i & 3) + 8 * (i >
   asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), \
                "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
 
-template <int kLB>   // 16-byte chunks of a window's rows per thread = ceil(32 (E / 4) / kTT)
-__global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) {
+template <int kLB, int NTHR>   // kLB: 16-byte chunks of a window's rows per thread = ceil(32 (E / 4) / NTHR)
+__global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a) {
+  constexpr int NW = NTHR / 64;          // wavefronts: 16 (four per SIMD, <= 128 registers) or 8
+  constexpr int NS = NW / 2;             // slots of partial cosine tiles (wavefronts w and w + NS share one)
+  constexpr int TPW = 16 / NW;           // 32-column tiles of E per wavefront (E <= 512)
+  constexpr int PP = NTHR / 256;         // threads per (token, kernel) in the pooling phase: 2 x 15 positions, or 4 x 8
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,8 +446,8 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   float* kc = csg + 16;                        // [kKS][4]: mu, -log2(e) / (2 sigma^2), 1 / sigma^2, -
   float* dkm = kc + 4 * kKS;                   // [2][kKS]: dense, kernel_mult
   float* spl = dkm + 2 * kKS;                  // [16] the saturation block's 13 parameters
-  float* PS = spl + 16;                        // [4][32][32] partial cosine tiles (wavefronts w and w + 4 share a slot)
-  int* prowA = (int*)(PS + 4 * 1024);          // [15][32] flat chunk row (p * 50 + row) of every position of every window, or -1
+  float* PS = spl + 16;                        // [NS][32][32] partial cosine tiles (wavefronts w and w + NS share a slot)
+  int* prowA = (int*)(PS + NS * 1024);          // [15][32] flat chunk row (p * 50 + row) of every position of every window, or -1
   float* mtA = (float*)(prowA + 15 * 32);      // [15][32] mask x presence
   int* prowR = (int*)(mtA + 15 * 32);          // [3][64] flat chunk row of every position of every region, -1 = none / a padding token
   int* wlist = prowR + 3 * 64;                 // [15] the windows that carry gradient, in region order; [15] = their number
@@ -454,8 +457,8 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   float* CTR = Gsum + 64 * QS;                 // [64][QS] cosines of the region's positions
   float* orig = CTR + 64 * QS;                 // [Wp]
   float* work = orig + Wp;                     // [Wp]
-  __shared__ float rv[kTT / 64];
-  __shared__ int ri[kTT / 64];
+  __shared__ float rv[NW];
+  __shared__ int ri[NW];
   __shared__ int top_s[3];
 
   const float* qb = a.q_ctx + (int64_t)b * Q * E;
@@ -467,12 +470,12 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
 #endif
 
   // ---- query tile: raw rows -> norms, emb . q_i -> normalised in place; constants -----------------------------------
-  for (int idx = tid; idx < Q * NC; idx += kTT) {
+  for (int idx = tid; idx < Q * NC; idx += NTHR) {
     const int i = idx / NC, c = idx - i * NC;
     *(f32x4*)(QH + i * ES + 4 * c) = *(const f32x4*)(qb + (int64_t)i * E + 4 * c);
   }
-  for (int idx = tid; idx < kBwdQ * 40; idx += kTT) red[idx] = 0.0f;
-  for (int idx = tid; idx < 2 * kBwdQ * kKS; idx += kTT) pk[idx] = 0.0f;      // pk and dpk (their padding stays zero)
+  for (int idx = tid; idx < kBwdQ * 40; idx += NTHR) red[idx] = 0.0f;
+  for (int idx = tid; idx < 2 * kBwdQ * kKS; idx += NTHR) pk[idx] = 0.0f;      // pk and dpk (their padding stays zero)
   if (tid < 16) {
     csg[tid] = 0.0f;
     spl[tid] = tid < 13 ? prm[TklParams::sat() + tid] : 0.0f;
@@ -496,14 +499,14 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     dkm[k] = dn;
     dkm[kKS + k] = km;
   }
-  for (int w = tid; w < Wp; w += kTT) {
+  for (int w = tid; w < Wp; w += NTHR) {
     float s = w < W ? a.win[(int64_t)b * W + w] : 0.0f;
     if (s == 0.0f) s = -9900.0f;
     orig[w] = s;
     work[w] = s;
   }
   __syncthreads();
-  {
+  if (tid < 512) {                                      // (whole wavefronts)
     const int i = tid >> 4, sub = tid & 15;
     float ss = 0.0f, se = 0.0f;
     if (i < Q)
@@ -531,7 +534,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   for (int c = 0; c < 3; ++c) {
     float bv = -__builtin_huge_valf();
     int bi = 0x7fffffff;
-    for (int w = tid; w < Wp; w += kTT) {
+    for (int w = tid; w < Wp; w += NTHR) {
       const float v = work[w];
       if (v > bv) { bv = v; bi = w; }
     }
@@ -544,14 +547,14 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     if (lane == 0) { rv[wv] = bv; ri[wv] = bi; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kTT / 64; ++k) {
+    for (int k = 0; k < NW; ++k) {
       const float ov = rv[k];
       const int oi = ri[k];
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
     if (tid == 0) top_s[c] = bi;
     __syncthreads();
-    for (int w = tid; w < Wp; w += kTT) {
+    for (int w = tid; w < Wp; w += NTHR) {
       const int dlt = w > bi ? w - bi : bi - w;
       if (dlt < 15) work[w] = -10001.0f - (float)c;
     }
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
       }
     }
   };
-  for (int e2 = tid; e2 < 15 * 32 + 3 * 64; e2 += kTT) {
+  for (int e2 = tid; e2 < 15 * 32 + 3 * 64; e2 += NTHR) {
     int flat;
     float m;
     if (e2 < 15 * 32) {
@@ -643,7 +646,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   int frow[kLB], fcol[kLB];
 #pragma unroll
   for (int u = 0; u < kLB; ++u) {
-    const int idx = tid + u * kTT;
+    const int idx = tid + u * NTHR;
     frow[u] = 32;
     fcol[u] = 0;
     if (idx < 32 * NC) {
@@ -665,7 +668,8 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     for (int u = 0; u < kLB; ++u)
       if (frow[u] < 32) *(f32x4*)(DB + frow[u] * ES + fcol[u]) = nxt[u];
   };
-  auto row_norms = [&]() {                              // sixteen threads per row of DB
+  auto row_norms = [&]() {                              // sixteen threads per row of DB (the first eight wavefronts)
+    if (tid >= 512) return;
     const int row = tid >> 4, sub = tid & 15;
     float ss = 0.0f;
     for (int c = sub; c < NC; c += 16) {
@@ -683,9 +687,9 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
 
   const int NT = (E + 31) >> 5;                         // 32-column tiles of E; wavefront w owns tiles w and w + 8
   const int KQ = (Q + 1) >> 1;                          // MFMA steps over the query tokens
-  f32x16 accq[2];
-  accq[0] = f32x16{0};
-  accq[1] = f32x16{0};
+  f32x16 accq[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) accq[t] = f32x16{0};
   TKL_PH(0);
   for (int n = 0; n < nv; ++n) {
     const int j = wlist[n];
@@ -698,7 +702,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     const int poff = 2 * winf[j] - rinf[r];                        // first position of the window inside its region
     if (first) {
       fetch(prow);                                                 // (not prefetched: the registers carried the previous region's rows)
-      for (int idx = tid; idx < 64 * QS; idx += kTT) Gsum[idx] = 0.0f;
+      for (int idx = tid; idx < 64 * QS; idx += NTHR) Gsum[idx] = 0.0f;
     }
     commit();
     __syncthreads();
@@ -706,12 +710,14 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     TKL_PH(1);
     row_norms();
     if (tid < kBwdQ) lmask[tid] = 0;
+    int lw = ln, hw = lh;                                // (opaque copies: the addresses below are recomputed per window, not kept)
+    asm volatile("" : "+v"(lw), "+v"(hw));
     {  // cosine tile: this wavefront's K slice of the 32 x 32 tile; the eight partial tiles meet in LDS in a fixed order
       f32x16 acc = {0};
-      const float* arow = DB + ln * ES;
-      const float* brow = QH + (ln < Q ? ln : Q - 1) * ES;
-      for (int p = wv; 2 * p < NC; p += 8) {
-        const int cc = 2 * p + lh;
+      const float* arow = DB + lw * ES;
+      const float* brow = QH + (lw < Q ? lw : Q - 1) * ES;
+      for (int p = wv; 2 * p < NC; p += NW) {
+        const int cc = 2 * p + hw;
         const int cl = cc < NC ? cc : NC - 1;            // (odd NC: the last pair's upper half multiplies zeros)
         f32x4 av = *(const f32x4*)(arow + 4 * cl);
         const f32x4 bv = *(const f32x4*)(brow + 4 * cl);
@@ -719,22 +725,25 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q4], bv[q4], acc, 0, 0, 0);
       }
-      float* ps = PS + (wv & 3) * 1024 + 4 * lh * 32 + ln;
-      if (wv >= 4) {
+      float* ps = PS + (wv % NS) * 1024 + 4 * hw * 32 + lw;
+      if (wv >= NS) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] = acc[i];
       }
       __syncthreads();
-      if (wv < 4) {
+      if (wv < NS) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ps[mrow(i) * 32] += acc[i];
       }
     }
     __syncthreads();
     TKL_PH(2);
-    for (int idx = tid; idx < 1024; idx += kTT) {
+    for (int idx = tid; idx < 1024; idx += NTHR) {
       const int row = idx >> 5, i = idx & 31;
-      const float v = (((PS[idx] + PS[1024 + idx]) + PS[2048 + idx]) + PS[3072 + idx]) * rd[row];
+      float v = PS[idx];
+#pragma unroll
+      for (int w2 = 1; w2 < NS; ++w2) v += PS[w2 * 1024 + idx];
+      v *= rd[row];
       if (i < Q) {
         CT[row * QS + i] = v;
         if (row < kBwdT) CTR[(poff + row) * QS + i] = v;           // (the same bits from every window that holds the position)
@@ -742,22 +751,25 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     }
     __syncthreads();
     TKL_PH(3);
-    for (int idx = tid >> 1; idx < Q * kK; idx += kTT / 2) {     // pooled kernels of the window: (i, k) on two threads, fifteen positions each
+    for (int idx = tid / PP; idx < Q * kK; idx += NTHR / PP) {   // pooled kernels of the window: (i, k) on PP threads, 32 / PP positions each
       const int i = idx / kK, k = idx - i * kK;
       const float mu = kc[4 * k], c2 = kc[4 * k + 1];
-      const int t0 = 15 * (tid & 1);
+      const int t0 = (32 / PP) * (tid % PP);                     // (positions 30, 31: zero mask)
       float s = 0.0f;
       int bits = 0;
 #pragma unroll
-      for (int tt = 0; tt < 15; ++tt) {
+      for (int tt = 0; tt < 32 / PP; ++tt) {
         const float d = CT[(t0 + tt) * QS + i] - mu;
         const float e = mt[t0 + tt] * __builtin_amdgcn_exp2f(d * d * c2);
         s += e;
         bits |= (e != 0.0f ? 1 : 0) << (t0 + tt);
       }
-      s += __shfl_xor(s, 1, 64);
-      bits |= __shfl_xor(bits, 1, 64);
-      if (!(tid & 1)) {
+#pragma unroll
+      for (int m = 1; m < PP; m <<= 1) {
+        s += __shfl_xor(s, m, 64);
+        bits |= __shfl_xor(bits, m, 64);
+      }
+      if (!(tid % PP)) {
         pk[i * kKS + k] = s;
         atomicOr(&lmask[i], bits);                                // window length (:210) = positions with any non-zero activation
       }
@@ -768,7 +780,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
     // (On the first wavefront alone — one lane per token looping over the kernels — this chain of logs, exponentials and
     // LDS read-modify-writes was 20 % of the kernel, the other seven wavefronts waiting at the barrier.)
     const float gw = g * cs;                                     // d loss / d w_j
-    {
+    if (tid < 512) {                                      // (whole wavefronts)
       const int i = tid >> 4, k = tid & 15;
       const bool tin = i < Q, kin = k < kK;
       const int ic = tin ? i : 0;
@@ -844,7 +856,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
       for (int i = 0; i < Q; ++i) wj += __shfl(val, i, 64);
       if (lane == 0) csg[j] += g * wj;
     }
-    for (int idx = tid; idx < 1024; idx += kTT) {               // G = d loss / d c, added to the region's sum at the window's positions
+    for (int idx = tid; idx < 1024; idx += NTHR) {               // G = d loss / d c, added to the region's sum at the window's positions
       const int t = idx >> 5, i = idx & 31;
       const int ic = i < Q ? i : Q - 1;
       const float c = CT[t * QS + ic];
@@ -885,7 +897,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
       }
       float* gblk = a.gchunks + (int64_t)fmin * E;
       fetch(ptab);
-      for (int idx = tid; idx < 1024; idx += kTT) {              // the token-major copy the query-gradient product reads
+      for (int idx = tid; idx < 1024; idx += NTHR) {              // the token-major copy the query-gradient product reads
         const int t = idx >> 5, i = idx & 31;
         if (i < QS) GI[i * 32 + t] = gs[t * QS + i];
       }
@@ -894,7 +906,7 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
       TKL_PH(7);
       row_norms();
       __syncthreads();
-      {  // sixteen threads per position / per query token, two terms each
+      if (tid < 512) {  // sixteen threads per position / per query token, two terms each (whole wavefronts)
         const int r16 = tid >> 4, sub = tid & 15;
         const bool rin = 32 * hb + r16 < rinf[4 + r];            // (positions past the region hold stale cosines)
         float s = 0.0f, u = 0.0f;
@@ -931,8 +943,8 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
           if (i >= Q) ga[st] = 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int nt = wv + 8 * t;
+        for (int t = 0; t < TPW; ++t) {
+          const int nt = wv + NW * t;
           if (nt >= NT) break;                             // wave-uniform
           const int col = 32 * nt + lq;
           const bool cin = col < E;
@@ -991,8 +1003,8 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
           if (lq >= Q) gi[st] = 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int nt = wv + 8 * t;
+        for (int t = 0; t < TPW; ++t) {
+          const int nt = wv + NW * t;
           if (nt >= NT) break;
           const int col = 32 * nt + lq;
           const float* dcol = DB + (col < E ? col : 0);
@@ -1011,8 +1023,8 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   // ---- grad_q = rq (sum_w sum_t G dh - (sum G c) q / |q|) + dev emb_w; parameter rows of this document -----------------
   const bool emb_sat = a.sat == MM_TKL_SAT_EMBEDDING;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int nt = wv + 8 * t;
+  for (int t = 0; t < TPW; ++t) {
+    const int nt = wv + NW * t;
     const int col = 32 * nt + ln;
     if (nt < NT && col < E) {
       const float ew = emb_sat ? prm[TklParams::emb() + col] : 0.0f;
@@ -1031,15 +1043,15 @@ __global__ void __launch_bounds__(kTT) tkl_bwd_tiled_kernel(const TklBwdArgs a) 
   }
   float* gp = a.gprm + (int64_t)b * a.NP;
   if (emb_sat) {
-    for (int e = tid; e < E; e += kTT) {
+    for (int e = tid; e < E; e += NTHR) {
       float s = 0.0f;
       for (int i = 0; i < Q; ++i) s += dev[i] * QH[i * ES + e] * (nq[i] + 1e-13f);     // q_i = qh_i (|q_i| + tiny)
       gp[TklParams::emb() + e] = s;
     }
   } else {
-    for (int e = tid; e < E; e += kTT) gp[TklParams::emb() + e] = 0.0f;
+    for (int e = tid; e < E; e += NTHR) gp[TklParams::emb() + e] = 0.0f;
   }
-  for (int k = tid; k < 2 * kK; k += kTT) gp[k] = 0.0f;                           // mu, sigma are not trained
+  for (int k = tid; k < 2 * kK; k += NTHR) gp[k] = 0.0f;                           // mu, sigma are not trained
   if (tid < 35) {                                                              // sum over the query tokens in index order
     float s = 0.0f;
     for (int i = 0; i < Q; ++i) s += red[i * 40 + tid];
@@ -1106,15 +1118,18 @@ extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* ch
   a.q_mask = q_mask; a.prm = params; a.win = win_scores; a.go = grad_out; a.gq = grad_q; a.gchunks = grad_chunks;
   a.gprm = grad_params; a.C = C; a.Q = Q; a.E = E; a.W = W; a.NP = MM_TKL_NPARAMS(K, E); a.sat = saturation;
   {
-    const size_t tl = tkl_bwd_tiled_lds_bytes(Wp, Q, E);
+    // 512 threads.  (The kernel is written for NTHR = 512 | 1024 like kernel_pool_bwd_tiled_kernel; here the sixteen-wavefront
+    // form loses — 2,155 vs 2,059 us for 2,048 documents, 29 spilled registers at the 128-register budget — and is not instantiated.)
+    const int nthr = 512;
+    const size_t tl = tkl_bwd_tiled_lds_bytes(Wp, Q, E, nthr);
     if (!(E & 3) && E <= 512 && tl <= 150 * 1024 && !env().kp_bwd_untiled &&
         !(((uintptr_t)q_ctx | (uintptr_t)chunks | (uintptr_t)grad_q | (uintptr_t)grad_chunks | (uintptr_t)params) & 15)) {
       auto go = [&](auto kern) {
         if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTT), tl, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3((unsigned)nthr), tl, stream, a);
       };
-      if (8 * E <= 5 * kTT) go(tkl_bwd_tiled_kernel<5>);      // a thread's share of a window's rows: five 16-byte chunks (E <= 320) or eight
-      else go(tkl_bwd_tiled_kernel<8>);
+      // a thread's share of a block of rows in 16-byte chunks: five (E <= 320) or eight
+      E <= 320 ? go(tkl_bwd_tiled_kernel<5, 512>) : go(tkl_bwd_tiled_kernel<8, 512>);
       return check_launch("tkl_bwd_tiled_kernel");
     }
   }
