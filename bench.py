@@ -1441,12 +1441,16 @@ def main():
                         extra["dropin_forward"] = {"error": repr(e)}
                     del q, d
                     torch.cuda.empty_cache()
+                    wall = {}                   # host seconds per leg (what the default run's few minutes are spent on)
                     for name, fn in LEGS:
+                        t_leg = time.time()
                         try:
                             extra[name] = fn(3 if name == "dot_topk" else 10, cpu_b)
                         except Exception as e:
                             extra[name] = {"error": repr(e)}
                         torch.cuda.empty_cache()
+                        wall[name] = round(time.time() - t_leg, 1)
+                    extra["wall_s"] = wall
                     out["extra"] = extra
         print(json.dumps(out), flush=True)
     if use_dist:
