@@ -493,6 +493,49 @@ def test_store_burst_accounting_never_overcounts():
             assert exact >= 0.9 * total, (per, nbuf, ns, exact, total)   # (elsewhere an older burst is left uncounted on purpose)
 
 
+def test_tkl_backward_window_list_in_region_order():
+    """Model of tkl_bwd_tiled_kernel's window bookkeeping (csrc/tkl_bwd.hip): the 15 windows of sigir20_tkl.py:275-277
+    (j = peaks, -1, +1, -2, +2 around the three peaks, clamped to the document) are processed in REGION order — rank
+    (j % 3) * 5 + j // 3 among the non-empty ones — d loss / d c is summed per position over a region's windows, and a
+    region reads the chunk rows it adds to only when it shares a position with an EARLIER region.  Checked here: every
+    non-empty window appears exactly once, regions are contiguous runs of the list, a window's positions lie inside its
+    region's range (<= 38 positions = two blocks of 32), and the overlap flag is exactly 'intersects an earlier region'."""
+    rng = np.random.default_rng(9)
+    offs = [0, -1, 1, -2, 2]
+    for trial in range(400):
+        Wp = int(rng.integers(3, 200))
+        # three peaks as the region search finds them: >= 15 windows apart while the document is long enough, anywhere else
+        work = rng.random(Wp)
+        top = []
+        for c in range(3):
+            b = int(np.argmax(work))
+            top.append(b)
+            work[np.abs(np.arange(Wp) - b) < 15] = -1.0 - c
+        empty = rng.random(Wp) < 0.15                          # windows whose forward score is exactly 0 (:282)
+        idx = [min(max(top[j % 3] + offs[j // 3], 0), Wp - 1) for j in range(15)]
+        valid = [not empty[i] for i in idx]
+        # device: compact list by rank, region ranges, overlap flags
+        rank = [(j % 3) * 5 + j // 3 for j in range(15)]
+        wlist = [j for _, j in sorted((rank[j], j) for j in range(15) if valid[j])]
+        lo = [min([idx[r + 3 * o] for o in range(5) if valid[r + 3 * o]], default=None) for r in range(3)]
+        hi = [max([idx[r + 3 * o] for o in range(5) if valid[r + 3 * o]], default=None) for r in range(3)]
+        p0 = [2 * lo[r] if lo[r] is not None else 0 for r in range(3)]
+        p1 = [2 * hi[r] + 30 if hi[r] is not None else 0 for r in range(3)]
+        ov = [int(any(p1[o] > p0[o] and p1[r] > p0[r] and p0[o] < p1[r] and p0[r] < p1[o] for o in range(r))) for r in range(3)]
+        # properties
+        assert sorted(wlist) == [j for j in range(15) if valid[j]]
+        regions = [j % 3 for j in wlist]
+        assert regions == sorted(regions)                          # contiguous runs, region 0 first
+        for j in wlist:
+            r = j % 3
+            assert p1[r] - p0[r] <= 38 and p0[r] <= 2 * idx[j] and 2 * idx[j] + 30 <= p1[r]
+        touched = set()
+        for r in range(3):
+            mine = set(range(p0[r], p1[r]))
+            assert ov[r] == int(bool(mine & touched)), (trial, r, p0, p1)
+            touched |= mine
+
+
 def test_flat_index_precision_follows_token_dtype():
     """base_index.py:14: use_fp16 = config["token_dtype"] == "float16"; an fp32 index is refused, not silently rounded."""
     from matchmaker_amd.retrieval import FlatIPIndexer
