@@ -1084,6 +1084,115 @@ LEGS = (("eval_batch", extra_eval_batch), ("maxsim_fp32", extra_maxsim_fp32), ("
         ("ragged_aggregate", extra_ragged_aggregate), ("variants", extra_variants), ("dot_topk", extra_dot_topk))
 
 
+# ---- the record the driver reads -------------------------------------------------------------------------------------
+# The driver keeps the last ~9 KB of stdout and parses the LAST line.  Round 4's single line had grown to 21.7 KB, so the
+# head of it (value, ms_per_step, roofline) was cut off and BENCH_r04.parsed came back null.  The last stdout line is
+# therefore a compact record (< 4 KB; tests/test_bench_launch_cpu.py bounds it); the full record with every leg's prose
+# goes to gpurun_out/bench_full.json and to an EARLIER stdout line ("FULL_RECORD {...}").
+_SLIM_NUM = ("ms", "frac", "us_per_call_completed", "us_per_call_device", "step_us", "forward_us", "kernel_us", "host_us",
+             "backward_op_over_forward", "frac_needed_bytes")
+
+
+def _r4(x):
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.4g}")
+    return x
+
+
+def _slim_leg(leg, depth=0):
+    """one `extra` leg -> {ms, frac} (+ the same for the sub-measurements it nests), numbers to 4 significant digits"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:80]}
+    out = {}
+    for k in _SLIM_NUM:
+        if isinstance(leg.get(k), (int, float)):
+            out[k] = _r4(leg[k])
+    roof = leg.get("roofline")
+    if isinstance(roof, dict) and isinstance(roof.get("frac"), (int, float)):
+        out["frac"] = _r4(roof["frac"])
+        if roof.get("bound") == "mfma":
+            out["bound"] = "mfma"
+    if depth < 3:
+        for k, v in leg.items():
+            if k in ("roofline", "cpu_baseline", "vendor_gemm", "hbm_calibration", "eager_gpu_baseline", "graph_replay") \
+                    or not isinstance(v, dict):
+                continue
+            sub = _slim_leg(v, depth + 1)
+            if sub:
+                out[k] = sub
+    return out
+
+
+def compact_record(out, limit=4000):
+    """the LAST stdout line: every key of the bench contract + roofline + cpu_baseline, `extra` reduced to {leg: {ms, frac}}"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "world_size", "dry", "all_gather_verified")
+    c = {k: out[k] for k in keep if k in out}
+    cfg = dict(out.get("config") or {})
+    if isinstance(cfg.get("workload"), str) and len(cfg["workload"]) > 260:
+        cfg["workload"] = cfg["workload"][:257] + "..."
+    c["config"] = cfg
+    coll = out.get("collective")
+    if coll:
+        c["collective"] = {k: (v[:100] if isinstance(v, str) else v) for k, v in coll.items() if k != "final_sort"}
+        if isinstance(coll.get("final_sort"), dict):
+            c["collective"]["final_sort"] = {k: v for k, v in coll["final_sort"].items() if k != "what"}
+    else:
+        c["collective"] = None
+    sc = out.get("self_check")
+    if sc:
+        c["self_check"] = {k: (_r4(v) if not isinstance(v, str) else v[:120]) for k, v in sc.items()}
+    roof = out.get("roofline")
+    if roof:
+        r = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes",
+                                  "frac_of_calibrated", "calibrated_stream_GBps") if k in roof}
+        mu = roof.get("mfma_util") or {}
+        r["mfma_util"] = {k: _r4(mu[k]) for k in ("tflops", "frac_of_dense_bf16_peak", "pmc_busy_frac") if k in mu}
+        if "traffic_source" in roof:
+            r["traffic_source"] = roof["traffic_source"].split(" ")[0]
+        c["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: (v[:120] if isinstance(v, str) else v) for k, v in cb.items()
+                             if k in ("value", "unit", "cores", "kind", "cpu_model", "single_thread_value", "sample", "error")}
+    extra = out.get("extra")
+    if isinstance(extra, dict):
+        slim = {}
+        for name, leg in extra.items():
+            if name in ("wall_s", "hbm_calibration"):
+                continue
+            sl = _slim_leg(leg)
+            if sl:
+                slim[name] = sl
+        c["extra"] = slim
+        c["full_record"] = "gpurun_out/bench_full.json (and the FULL_RECORD stdout line before this one)"
+        # hard bound: drop the deepest sub-measurements first, then whole legs from the end
+        while len(json.dumps(c)) > limit and any(isinstance(v, dict) and any(isinstance(x, dict) for x in v.values())
+                                                  for v in slim.values()):
+            name = max(slim, key=lambda n: len(json.dumps(slim[n])))
+            slim[name] = {k: v for k, v in slim[name].items() if not isinstance(v, dict)} or {"see": "full_record"}
+        while len(json.dumps(c)) > limit and slim:
+            slim.pop(next(reversed(slim)))
+    return c
+
+
+def emit(out):
+    """full record -> gpurun_out/bench_full.json + an earlier stdout line; compact record = the last stdout line"""
+    full = json.dumps(out)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    print("FULL_RECORD " + full, flush=True)
+    print(json.dumps(compact_record(out)), flush=True)
+
+
 def init_dist(args, dev, world, rank, backend):
     import torch.distributed as dist
     # the GPU boxes export NCCL_DEBUG=VERSION and RCCL prints to STDOUT (its banner would follow the JSON line, once
@@ -1452,7 +1561,7 @@ def main():
                         wall[name] = round(time.time() - t_leg, 1)
                     extra["wall_s"] = wall
                     out["extra"] = extra
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

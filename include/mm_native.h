@@ -25,8 +25,8 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2 /* 2: `flags` on the MaxSim forwards (the reference's 16-bit dtype flow); mm_tkl_fwd's ascending chunk_slot
-                            contract and workspace layout */
+#define MM_ABI_VERSION 3 /* 2: `flags` on the MaxSim forwards (the reference's 16-bit dtype flow); mm_tkl_fwd's ascending chunk_slot
+                            contract and workspace layout.  3: + mm_tkl_fwd_peaks (the region search's three peak indices) */
 
 /* element types of the embedding tensors */
 #define MM_F32 0
@@ -292,6 +292,17 @@ int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* chunk_mask,
                float* win_scores, float* out,
                int64_t B, int64_t P, int C, int Q, int E, int K, int saturation,
                void* workspace, size_t workspace_bytes, void* stream);
+
+/* mm_tkl_fwd + the region search's own result (ABI 3): top_idx [B, 3] int32 out (may be NULL) receives, per document, the
+ * three arg-max window indices in round order — the reference's `top_non_overlapping_idx` (sigir20_tkl.py:266-271, returned
+ * under output_secondary_output :290).  With win_scores they give `top_k_non_overlapping` (:276-282) by a gather of 15
+ * values per document (matchmaker_amd/tkl.py does that), and they are what a rank-parity check needs to tell "the device
+ * picked another region of equal score" from "the device scored a region wrongly" (tie policy). */
+int mm_tkl_fwd_peaks(const void* q_ctx, const void* chunks, const float* chunk_mask,
+                     const int32_t* chunk_slot, const float* q_mask, const float* params,
+                     float* win_scores, float* out, int32_t* top_idx,
+                     int64_t B, int64_t P, int C, int Q, int E, int K, int saturation,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of mm_tkl_fwd (training: train.py:503-524 through sigir20_tkl.py:180-286).  The document score is a weighted
  * sum of at most 15 window scores whose indices are piecewise constant, so the exact gradient involves only those windows:

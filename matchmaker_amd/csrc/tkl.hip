@@ -25,7 +25,7 @@ constexpr int kTokGroup = 10;  // query tokens per window workgroup (see tkl_win
 constexpr int kRThreads = 256;  // region kernel (1,024 threads, one window each, measured slower: 11.3 vs 9.8-10.5 us)
 
 __device__ __forceinline__ void region_topk(float* orig, float* work, float* rv, int* ri, int Wp, const float* __restrict__ prm,
-                                            float* __restrict__ out, int tid);      // (defined below the window kernel)
+                                            float* __restrict__ out, int32_t* __restrict__ peaks, int tid);   // (defined below the window kernel)
 
 
 // Preparation in ONE launch (round 1: memset + emb + two mask packs + slot map = five, ~25 us of a 0.3 ms call) —
@@ -230,10 +230,10 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
                                                          const float* __restrict__ emb_g,
                                                          const float* __restrict__ q_mask,
                                                          const int32_t* __restrict__ q_len,
-                                                         const float* __restrict__ prm, float* __restrict__ win,
+                                                         const float* __restrict__ prm, float* win,
                                                          int C, int Q, int W, int lds_bytes, const int32_t* __restrict__ ntile,
-                                                         int n_planes, float* __restrict__ win_final, float* __restrict__ out,
-                                                         int32_t* __restrict__ done_cnt) {
+                                                         int n_planes, float* win_final, float* __restrict__ out,
+                                                         int32_t* __restrict__ done_cnt, int32_t* __restrict__ peaks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float rv[kRThreads / 64];
   __shared__ int ri[kRThreads / 64];
@@ -242,12 +242,19 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   const int w0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
   // ---- last-workgroup epilogue (round 4: the region top-k of :254-286 no longer has its own launch) ------------------------
-  // Every workgroup that scores a live tile of document b publishes its 64 partial window scores with write-through stores
-  // (agent scope: sc1), drains them (vmcnt(0)), and arrives on done_cnt[b]; the workgroup whose arrival completes the document
-  // sums the planes (sc1 loads: the producers stored sc1, so no stale copy can sit in an L2) and runs the region search in
-  // the LDS its tile just left.  expected = live tiles x live token groups of the document — dead tiles (past the last kept
-  // chunk, tkl_prep_kernel) and groups without a real token neither write nor arrive.  out == nullptr: the standalone
-  // tkl_region_kernel follows (A/B runs) and this kernel only publishes.
+  // The "last block" reduction pattern, written to the HIP memory model (round 5; round 4 relied on gfx950's sc1 write-through
+  // behaviour alone).  Every workgroup that scores a live tile of document b
+  //   1. publishes its 64 partial window scores (agent-scope atomic stores: sc1 write-through),
+  //   2. every thread issues an agent-scope RELEASE fence (buffer_wbl2 sc1 + s_waitcnt: its stores are visible device-wide),
+  //   3. barrier, then thread 0 arrives on done_cnt[b] with an ACQ_REL agent-scope fetch_add.
+  // The workgroup whose arrival completes the document (old + 1 == expected) issues an agent-scope ACQUIRE fence in every
+  // thread (buffer_inv sc1: no stale line of another XCD's scores in this XCD's L2), sums the planes and runs the region
+  // search in the LDS its tile just left.  release-fence -> acq_rel RMW chain on one counter -> acquire-fence orders every
+  // publisher's stores before the finalizer's loads, whichever XCDs they ran on.  expected = live tiles x live token groups
+  // of the document — dead tiles (past the last kept chunk, tkl_prep_kernel) and groups without a real token neither write
+  // nor arrive.  out == nullptr: the standalone tkl_region_kernel follows (MM_TKL_REGION_KERNEL=1) and this kernel only
+  // publishes.  win / win_final are NOT __restrict__: with one token group (Q <= 10) they are the same buffer (each thread
+  // reads and writes only its own windows there).
   const float* const part = win;
   const int64_t plane_stride = (int64_t)gridDim.y * W;
   const int nt_live = ntile[b] < (int)gridDim.x ? ntile[b] : (int)gridDim.x;
@@ -277,23 +284,28 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
       work[w] = s;
     }
     __syncthreads();
-    region_topk(orig, work, rv, ri, Wp, prm, out + b, tid);
+    region_topk(orig, work, rv, ri, Wp, prm, out + b, peaks ? peaks + 3 * (int64_t)b : nullptr, tid);
   };
   auto arrive = [&]() {
     if (!out) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this thread's published scores have reached memory
-    __syncthreads();                                                   // ... and so have every thread's; the tile's LDS is free
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // this thread's published scores are visible device-wide
+    __syncthreads();                                                   // ... and so are every thread's; the tile's LDS is free
     if (tid == 0) {
-      const int old = __hip_atomic_fetch_add(done_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int old = __hip_atomic_fetch_add(done_cnt + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       last_flag = old + 1 == expected;
     }
     __syncthreads();
-    if (last_flag) finalize();
+    if (last_flag) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // the other workgroups' scores, not a stale cached line
+      finalize();
+    }
   };
   if (out && expected == 0) {            // no live tile or no real query token: every window is empty, the score is 0 (:257, :282)
     if (blockIdx.x == 0 && blockIdx.z == 0) {
       for (int w = tid; w < W; w += kWThreads) win_final[(int64_t)b * W + w] = 0.0f;
       if (tid == 0) out[b] = 0.0f;
+      // every window is -9900: the arg-max rounds pick 0, then the first index outside +-15 of it, and so on (:268-273)
+      if (peaks && tid < 3) { const int Wp = W < 3 ? 3 : W; peaks[3 * (int64_t)b + tid] = 15 * tid < Wp ? 15 * tid : 0; }
     }
     return;
   }
@@ -511,8 +523,9 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
 // Region top-k over the window scores of ONE document (:254-286) by the 256 threads of a workgroup: orig / work [Wp] in LDS
 // hold the scores with 0 -> -9900 (:257) on entry.  Three arg-max rounds (ties -> lowest index, like torch.argmax), +-15
 // suppression (:268-273), the peaks' +-1 / +-2 neighbours (:276-282), chunk_scoring dot (:286) -> *out.
+// peaks (nullable): the three arg-max indices in round order = the reference's top_non_overlapping_idx row (:266-271, :290).
 __device__ __forceinline__ void region_topk(float* orig, float* work, float* rv, int* ri, int Wp, const float* __restrict__ prm,
-                                            float* __restrict__ out, int tid) {
+                                            float* __restrict__ out, int32_t* __restrict__ peaks, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
   int top[3];
   for (int c = 0; c < 3; ++c) {                                        // :268-273
@@ -559,16 +572,17 @@ __device__ __forceinline__ void region_topk(float* orig, float* work, float* rv,
     }
     const float s = wave_sum(term);
     if (lane == 0) *out = s;
+    if (peaks && lane < 3) peaks[lane] = lane == 0 ? top[0] : (lane == 1 ? top[1] : top[2]);
   }
 }
 
 // One 256-thread workgroup per document: the standalone form (MM_TKL_REGION_KERNEL=1, A/B runs; since round 4 the LAST window
 // workgroup of a document does this itself, see tkl_window_kernel).  (One wavefront per document spent 16 us on sixteen
 // dependent 4-byte loads per lane; four wavefronts load the ~1,000 scores of a 2,048-token document in four rounds.)
-__global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* __restrict__ part, int n_planes, int64_t plane,
-                                                         const int32_t* __restrict__ q_len, float* __restrict__ win,
+__global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* part, int n_planes, int64_t plane,
+                                                         const int32_t* __restrict__ q_len, float* win,
                                                          const float* __restrict__ prm, float* __restrict__ out, int W,
-                                                         const int32_t* __restrict__ ntile) {
+                                                         const int32_t* __restrict__ ntile, int32_t* __restrict__ peaks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float rv[kRThreads / 64];
   __shared__ int ri[kRThreads / 64];
@@ -597,7 +611,7 @@ __global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* __re
     work[w] = s;
   }
   __syncthreads();
-  region_topk(orig, work, rv, ri, Wp, prm, out + b, tid);
+  region_topk(orig, work, rv, ri, Wp, prm, out + b, peaks ? peaks + 3 * (int64_t)b : nullptr, tid);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -627,6 +641,14 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
                           const float* q_mask, const float* params, float* win_scores, float* out, int64_t B,
                           int64_t P, int C, int Q, int E, int K, int saturation, void* workspace,
                           size_t workspace_bytes, void* stream_) {
+  return mm_tkl_fwd_peaks(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, params, win_scores, out, nullptr, B, P, C, Q, E, K,
+                          saturation, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int mm_tkl_fwd_peaks(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
+                                const float* q_mask, const float* params, float* win_scores, float* out, int32_t* top_idx,
+                                int64_t B, int64_t P, int C, int Q, int E, int K, int saturation, void* workspace,
+                                size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!q_ctx || !q_mask || !params || !out) return set_error(MM_EINVAL, "tkl: null pointer");
   if (P > 0 && (!chunks || !chunk_mask || !chunk_slot)) return set_error(MM_EINVAL, "tkl: null chunk pointer");
@@ -712,7 +734,7 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
       if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, grid2, dim3(kWThreads), lds2, stream, (const float*)ps, (const int32_t*)slot2p, (const float*)emb, q_mask,
                          (const int32_t*)qmk.len, params, wdst, C, Q, W, (int)lds2, (const int32_t*)ntile, n_planes, win,
-                         fold_regions ? out : (float*)nullptr, done_cnt);
+                         fold_regions ? out : (float*)nullptr, done_cnt, top_idx);
     };
     if (saturation == MM_TKL_SAT_EMBEDDING) {
       if (use_cos) launch(tkl_window_kernel<MM_TKL_SAT_EMBEDDING, true>);
@@ -727,6 +749,6 @@ extern "C" int mm_tkl_fwd(const void* q_ctx, const void* chunks, const float* ch
   const int Wp = W < 3 ? 3 : W;
   hipLaunchKernelGGL(tkl_region_kernel, dim3((unsigned)B), dim3(kRThreads), (size_t)Wp * 8, stream,
                      (const float*)(n_planes > 1 ? planes : win), n_planes, (int64_t)B * W, (const int32_t*)qmk.len, win, params, out, W,
-                     (const int32_t*)ntile);
+                     (const int32_t*)ntile, top_idx);
   return check_launch("tkl_region_kernel");
 }

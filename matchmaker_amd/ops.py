@@ -520,8 +520,11 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
 
 def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor, chunk_slot: torch.Tensor,
               q_mask: torch.Tensor, params: torch.Tensor, B: int, C: int, K: int, saturation: str = "embedding",
-              return_windows: bool = False, check_order: bool = True):
+              return_windows: bool = False, check_order: bool = True, return_peaks: bool = False):
     """TKL windowed kernel pooling + region top-k (sigir20_tkl.py:180-286).  See mm_native.h.
+
+    return_peaks: also return the region search's three arg-max window indices per document, int64 [B, 3] in round order =
+    the reference's `top_non_overlapping_idx` (:266-271).  Returns score | (score, win) | (score, win, peaks).
 
     chunk_slot must be strictly ASCENDING (what boolean-mask packing / torch.nonzero produce, sigir20_tkl.py:159-162): the
     kernels rely on a document's chunks being adjacent and on its last kept chunk coming last.  check_order=True verifies
@@ -551,14 +554,18 @@ def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tenso
     L = _lib.lib()
     out = torch.empty(B, dtype=torch.float32, device=dev)
     win = torch.empty((B, W), dtype=torch.float32, device=dev)
+    peaks = torch.empty((B, 3), dtype=torch.int32, device=dev) if return_peaks else None
     if B:
         with torch.cuda.device(dev):
             wsb = L.mm_tkl_workspace_bytes(B, P, C, Q, K)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-            rc = L.mm_tkl_fwd(q_ctx.data_ptr(), chunks.data_ptr(), chunk_mask.data_ptr(), chunk_slot.data_ptr(),
-                              q_mask.data_ptr(), params.data_ptr(), win.data_ptr(), out.data_ptr(), B, P, C, Q, E,
-                              K, sat, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
-        _lib.check(rc, "mm_tkl_fwd")
+            rc = L.mm_tkl_fwd_peaks(q_ctx.data_ptr(), chunks.data_ptr(), chunk_mask.data_ptr(), chunk_slot.data_ptr(),
+                                    q_mask.data_ptr(), params.data_ptr(), win.data_ptr(), out.data_ptr(),
+                                    peaks.data_ptr() if peaks is not None else None, B, P, C, Q, E,
+                                    K, sat, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+        _lib.check(rc, "mm_tkl_fwd_peaks")
+    if return_peaks:
+        return out, win, peaks.long()
     return (out, win) if return_windows else out
 
 

@@ -54,6 +54,28 @@ def chunk_documents(document_embeddings: torch.Tensor, document_mask: torch.Tens
     return chunks, chunk_mask[chunk_slot], chunk_slot.to(torch.int32), C
 
 
+def region_peaks(win: torch.Tensor) -> torch.Tensor:
+    """sigir20_tkl.py:254-273 on window scores [B, W]: 0 -> -9900, three arg-max rounds with |r - best| < 15 suppression.
+    int64 [B, 3].  The kernels do this search themselves (mm_tkl_fwd_peaks returns its result); this torch form serves the
+    autograd path's secondary output and the tests that pin the kernel's indices (same fp32 values, same first-index ties)."""
+    score = win
+    if score.shape[1] < TOP_K:
+        score = nn.functional.pad(score, (0, TOP_K - score.shape[1]))
+    work = torch.where(score == 0, torch.full_like(score, -9900.0), score)
+    r = torch.arange(work.shape[1], device=work.device)
+    peaks = torch.zeros((work.shape[0], TOP_K), dtype=torch.long, device=work.device)
+    for c in range(TOP_K):
+        best = torch.argmax(work, dim=1)
+        peaks[:, c] = best
+        work = torch.where((r - best.unsqueeze(-1)).abs() < WINDOW / 2, torch.full_like(work, -10001.0 - c), work)
+    return peaks
+
+
+def region_neighbors(peaks: torch.Tensor, W: int) -> torch.Tensor:
+    """:276-278 — the 15 window indices of a document: peaks, -1, +1, -2, +2, clamped to [0, W - 1]."""
+    return torch.cat([peaks, peaks - 1, peaks + 1, peaks - 2, peaks + 2], dim=1).clamp_(0, max(W, TOP_K) - 1)
+
+
 class _TKLScoreFn(torch.autograd.Function):
     """mm_tkl_fwd / mm_tkl_bwd behind autograd.  `scoring` are the parameter tensors in pack order (see
     TKL_sigir20._pack): their gradients come back as slices of the packed gradient vector."""
@@ -207,16 +229,43 @@ class TKL_sigir20(nn.Module):
             scoring, sizes = self._pack_layout()
             score, win = _TKLScoreFn.apply(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
                                            (B, C, K, saturation, self.pack_params(), sizes), *scoring)
+            peaks = region_peaks(win.detach()) if output_secondary_output else None
         else:
             with torch.no_grad():
-                score, win = ops.tkl_score(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
-                                           self.pack_params(), B, C, K, saturation, return_windows=True, check_order=False)
+                score, win, peaks = ops.tkl_score(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
+                                                  self.pack_params(), B, C, K, saturation, return_windows=True, check_order=False,
+                                                  return_peaks=True)
         if output_secondary_output:
-            query_mean_vector = query_ctx.sum(dim=1) / query_pad_oov_mask.sum(dim=1).unsqueeze(-1)
-            return score, {"score": score, "orig_score": win, "orig_doc_len": document_pad_oov_mask.sum(dim=-1),
-                           "total_chunks": B * C, "packed_chunks": int(chunks.shape[0]),
-                           "query_mean_vector": query_mean_vector}
+            return score, self._secondary(score, win, peaks, query_ctx, query_pad_oov_mask, document_pad_oov_mask, B, C,
+                                          int(chunks.shape[0]))
         return score
+
+    @torch.no_grad()
+    def _secondary(self, score, win, peaks, query_ctx, query_mask, document_mask, B, C, P):
+        """sigir20_tkl.py:288-292 — the same keys.  top_non_overlapping_idx is the region search's own result (the kernel
+        writes it); top_k_non_overlapping is a gather of 15 of the kernel's window scores per document (empty windows are 0
+        there, as after :282); sat_influence_from_top_k is the saturation layer's input (:225-228) at those 15 windows:
+        LayerNorm2([sat_emb_reduce1(q), lengths]).  `lengths` (:210) counts the window positions whose kernel activations are
+        not all zero — the unmasked document positions (an unmasked position always has a kernel within 0.1 of its cosine)."""
+        W = win.shape[1]
+        neighbors = region_neighbors(peaks, W)                                                  # :276-278
+        sec = {"score": score, "orig_score": win, "top_non_overlapping_idx": peaks,
+               "orig_doc_len": document_mask.sum(dim=-1), "top_k_non_overlapping": win.gather(1, neighbors),
+               "total_chunks": B * C, "packed_chunks": P,
+               "query_mean_vector": query_ctx.sum(dim=1) / query_mask.sum(dim=1).unsqueeze(-1)}
+        if self.use_embedding_sat:    # (the reference's log branch never defines sat_influencer: NameError at :290)
+            D = document_mask.shape[1]
+            right = EXT_CHUNK - ((D - OVERLAP) % CHUNK) if D > OVERLAP else EXT_CHUNK - OVERLAP - D
+            pos = nn.functional.pad(document_mask.float(), (0, right - OVERLAP))[:, :C * CHUNK]   # centre tokens of all chunks
+            pos = nn.functional.pad(pos, (0, max(0, WINDOW - pos.shape[1])))                      # :206-207
+            cs = nn.functional.pad(pos.cumsum(1), (1, 0))
+            lengths = cs.gather(1, 2 * neighbors + WINDOW) - cs.gather(1, 2 * neighbors)          # [B, 15]  (:209-210)
+            emb = self.sat_emb_reduce1(query_ctx.float()).squeeze(-1)                             # [B, Q]   (:224)
+            Q = emb.shape[1]
+            infl = torch.stack([emb.unsqueeze(1).expand(-1, neighbors.shape[1], -1),
+                                lengths.unsqueeze(-1).expand(-1, -1, Q)], dim=-1)                 # [B, 15, Q, 2] (:225-227)
+            sec["sat_influence_from_top_k"] = self.sat_normer(infl)                               # :228, :290
+        return sec
 
     # ------------------------------------------------------------------ training
     def _pack_layout(self):

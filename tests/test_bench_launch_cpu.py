@@ -38,3 +38,59 @@ def test_single_rank_dry_and_the_cpu_guard():
     # a CPU device without --dry is refused: there is no CPU scoring path to measure
     r, _ = _run("--device", "cpu")
     assert r.returncode != 0 and "only valid with --dry" in (r.stderr + r.stdout)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_last_stdout_line_is_a_compact_record_the_driver_can_keep():
+    """Round 4's ONE line was 21.7 KB; the driver keeps ~9 KB of stdout, so value / ms_per_step / roofline were cut off and
+    BENCH_r04.parsed was null.  The last line must stay small whatever the legs add, and still carry the contract's keys."""
+    b = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))
+    assert len(json.dumps(full)) > 20000                      # the record that broke the driver's parse
+    line = json.dumps(b.compact_record(full))
+    assert len(line) < 4200, len(line)
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "self_check"):
+        assert k in j, k
+    assert j["value"] == full["value"] and j["ms_per_step"] == full["ms_per_step"]
+    assert j["roofline"]["frac"] == full["roofline"]["frac"] and j["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert j["roofline"]["frac_of_calibrated"] == full["roofline"]["frac_of_calibrated"]
+    assert j["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and j["cpu_baseline"]["cores"] == 128
+    assert len(j["cpu_baseline"]["sample"]) <= 120
+    assert j["config"]["workload"].startswith("BASELINE.json configs[1]")
+    # every leg survives as numbers only
+    for leg in ("tk", "tkl", "dot_topk", "variants", "train_step", "ragged_aggregate", "eval_batch"):
+        assert leg in j["extra"], leg
+    assert abs(j["extra"]["tk"]["frac"] - full["extra"]["tk"]["roofline"]["frac"]) < 1e-3
+    assert not any(isinstance(v, str) and len(v) > 130 for v in _leaves(j["extra"]))
+    # a pathological record (legs that balloon) is still bounded
+    fat = json.loads(json.dumps(full))
+    for i in range(40):
+        fat["extra"][f"leg{i}"] = {"ms": 1.0, "roofline": {"frac": 0.5}, "sub": {f"s{k}": {"ms": 2.0, "frac": 0.1} for k in range(30)}}
+    assert len(json.dumps(b.compact_record(fat))) <= 4000
+
+
+def _leaves(o):
+    if isinstance(o, dict):
+        for v in o.values():
+            yield from _leaves(v)
+    else:
+        yield o
+
+
+def test_full_record_goes_to_an_earlier_line_and_to_a_file(tmp_path):
+    r, lines = _run("--dry", "--device", "cpu", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.strip().splitlines()
+    assert out[-1].startswith("{") and len(out[-1]) < 4200            # the LAST line is the compact record
+    assert any(l.startswith("FULL_RECORD {") for l in out[:-1])
+    full = json.loads(next(l for l in out if l.startswith("FULL_RECORD "))[len("FULL_RECORD "):])
+    assert full["n_gpus"] == json.loads(out[-1])["n_gpus"] == 1

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mm_abi_version() == 2 == _lib.ABI_VERSION
+    assert L.mm_abi_version() == 3 == _lib.ABI_VERSION
     # size queries are pure host arithmetic: callable without a GPU
     assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_NONE, _lib.MASK_LEN_I32) == 0
     assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_I64, _lib.MASK_I64) > 0

@@ -1,7 +1,7 @@
 """Phase clocks of the tiled TK backward kernel (kernel_pool_bwd_tiled_kernel built with -DMM_KP_BWD_PHASE_TIMES=1):
 
     tools/build_variant.sh phases kernel_pool_bwd -DMM_KP_BWD_PHASE_TIMES=1
-    MM_NATIVE_LIB=matchmaker_amd/csrc/libmm_native_phases.so python tools/bench_kp_bwd_phases.py [pairs]
+    MM_NATIVE_LIB=variants/libmm_native_phases.so python tools/bench_kp_bwd_phases.py [pairs]
 
 prints thread 0 / pair 0's s_memtime ticks per phase (100 MHz constant clock on gfx950) and the share of each."""
 import os

@@ -1,7 +1,7 @@
 """Phase clocks of the tiled TKL backward kernel (tkl_bwd_tiled_kernel built with -DMM_TKL_BWD_PHASE_TIMES=1):
 
     tools/build_variant.sh phases tkl_bwd -DMM_TKL_BWD_PHASE_TIMES=1
-    MM_NATIVE_LIB=matchmaker_amd/csrc/libmm_native_phases.so python tools/bench_tkl_bwd_phases.py [documents]
+    MM_NATIVE_LIB=variants/libmm_native_phases.so python tools/bench_tkl_bwd_phases.py [documents]
 
 prints thread 0 / document 0's s_memtime ticks per phase (summed over its <= 15 windows), and — with any library — the
 duration of the whole mm_tkl_bwd call and of its grad_chunks memset alone."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B library variant: tools/build_variant.sh <name> <translation unit> <-D flags...>
-#   -> matchmaker_amd/csrc/libmm_native_<name>.so = the current objects with <translation unit> recompiled under the flags.
+#   -> variants/libmm_native_<name>.so (git-ignored, outside the package: A/B libraries do not ship in matchmaker_amd/) = the current objects with <translation unit> recompiled under the flags.
 # Select it for one process with MM_NATIVE_LIB=<path> (matchmaker_amd/_lib.py).  Build the default library first.
 set -e
 cd "$(dirname "$0")/../matchmaker_amd/csrc"
@@ -10,5 +10,6 @@ objs=""
 for o in common maxsim maxsim_pair kernel_pool kernel_pool128 kernel_pool_bwd tkl tkl_bwd dot_topk; do
   if [ "$o" = "$tu" ]; then objs="$objs build/${tu}_${name}.o"; else objs="$objs build/$o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libmm_native_${name}.so $objs
-echo "$(pwd)/libmm_native_${name}.so"
+mkdir -p ../../variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libmm_native_${name}.so $objs
+echo "$(cd ../../variants && pwd)/libmm_native_${name}.so"
