@@ -29,7 +29,7 @@ constexpr int kShadowValu = 5;
 // product lo.lo is below 2^-16 of the result and was kept through round 3 on a 1e-6-scale criterion on exact duplicates;
 // against the contract (scores within 1e-3, decided ranks) it changes nothing that can be measured — max |score - fp64|
 // 5.2745e-6 without it, 5.2733e-6 with it on the 16 x 1000 rank lists, 15,984 vs 15,986 of 16,000 positions equal to the
-// stable sort of the fp32 reference (tests/test_rank_order_gpu.py, profiles/r04_rank_parity/) — and it costs 4.5 % of the
+// stable sort of the fp32 reference (tests/test_zz_rank_order_gpu.py, profiles/r04_rank_parity/) — and it costs 4.5 % of the
 // call on a kernel that runs into the board's power limit.  -DMM_KP_LOLO=1 (tools/build_variant.sh) builds
 // the four-product kernel for A/B runs.
 #ifndef MM_KP_LOLO

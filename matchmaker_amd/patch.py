@@ -20,9 +20,9 @@ _TABLE = [
     ("matchmaker.models.published.cikm20_tk_sparse", "CIKM20_TK_Sparse", "matchmaker_amd.tk_sparse", "CIKM20_TK_Sparse"),
     ("matchmaker.models.knrm", "KNRM", "matchmaker_amd.knrm", "KNRM"),
     ("matchmaker.models.conv_knrm", "Conv_KNRM", "matchmaker_amd.conv_knrm", "Conv_KNRM"),
-    # IDCM: only its passage sampler (sigir21_idcm.py:167-186) lies on the scoring path — a thin subclass of the
-    # reference's OWN class whose forward is matchmaker_amd.idcm.forward_native ("subclass:" = built from the class found)
-    ("matchmaker.models.published.sigir21_idcm", "IDCM", "matchmaker_amd.idcm", "subclass:native_subclass"),
+    # IDCM is NOT rebound: only its passage sampler (sigir21_idcm.py:182-186) lies on the scoring path, the block is inline
+    # in IDCM.forward (no module boundary to hook) and restating that forward here would be a copy of an out-of-scope method.
+    # INTEGRATION.md shows the three-line edit a maintainer makes there to call matchmaker_amd.idcm.sampler_scores.
 ]
 
 
@@ -38,13 +38,7 @@ def patch_matchmaker(strict: bool = False):
             if strict:
                 raise
             continue
-        if our_attr.startswith("subclass:"):
-            current = getattr(ref, ref_attr)
-            if getattr(current, "__module__", "").startswith("matchmaker_amd"):
-                continue                                  # already patched: do not stack subclasses
-            ours = getattr(importlib.import_module(our_mod), our_attr[len("subclass:"):])(current)
-        else:
-            ours = getattr(importlib.import_module(our_mod), our_attr)
+        ours = getattr(importlib.import_module(our_mod), our_attr)
         setattr(ref, ref_attr, ours)
         done.append(ref_mod + "." + ref_attr)
         all_mod = sys.modules.get("matchmaker.models.all")      # `from ... import *` copies made earlier

@@ -268,7 +268,9 @@ def gen_tkl():
         if sat == "embedding":
             score, sec = R.tkl_forward(m, q, d, qm, dm, secondary=True)    # sigir20_tkl.py:128-294
             extra = dict(orig_score=sec["orig_score"].numpy(),            # window scores, -9900 -> 0 (:284)
-                         top_idx=sec["top_non_overlapping_idx"].numpy())
+                         top_idx=sec["top_non_overlapping_idx"].numpy(),
+                         top_k_non_overlapping=sec["top_k_non_overlapping"].numpy(),           # :281-282
+                         sat_influence_from_top_k=sec["sat_influence_from_top_k"].numpy())     # :290
         else:
             # secondary output raises UnboundLocalError for "log" in the reference (:290)
             score = R.tkl_forward(m, q, d, qm, dm)

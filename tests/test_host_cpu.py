@@ -48,7 +48,8 @@ def test_header_is_plain_c_and_a_c_client_links_the_library(tmp_path):
 #include <string.h>
 #include "mm_native.h"
 int main(void) {
-  if (mm_abi_version() != MM_ABI_VERSION || MM_ABI_VERSION != 2) return 1;
+  if (mm_abi_version() != MM_ABI_VERSION || MM_ABI_VERSION != 3) return 1;
+  if (mm_tkl_fwd_peaks(NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 4, 100, 52, 20, 300, 11, MM_TKL_SAT_EMBEDDING, NULL, 0, NULL) != MM_EINVAL) return 6;
   if (mm_maxsim_workspace_bytes(10, 1, 32, 180, MM_MASK_I64, MM_MASK_I64) == 0) return 2;
   if (mm_tkl_workspace_bytes(4, 100, 52, 20, 11) == 0) return 3;
   /* a null pointer is refused before anything touches the device */
@@ -585,3 +586,75 @@ def test_stream_handle_is_read_once_and_the_public_path_is_the_fallback(monkeypa
     c = ops._workspace(dev, 100, 6)
     assert a is b and c is not a and made == [1 << 16, 1 << 16]
     assert ops._workspace(dev, 0, 5) is None
+
+
+@pytest.mark.parametrize("fname", [f for f in __import__("tests.util", fromlist=["x"]).golden_files("tkl_") if "embedding" in f])
+def test_tkl_secondary_outputs_host_part_matches_the_real_class(fname):
+    """sigir20_tkl.py:288-292 returns top_non_overlapping_idx / top_k_non_overlapping / sat_influence_from_top_k.  The kernels
+    supply the window scores and the three peaks; everything else is host arithmetic (matchmaker_amd/tkl.py `_secondary`,
+    `region_peaks`, `region_neighbors`) — checked here against the REAL class's outputs (tests/golden/gen_golden.py gen_tkl),
+    feeding it the real class's own window scores in place of the kernels'."""
+    from tests import util
+    from matchmaker_amd.tkl import TKL_sigir20, region_peaks, region_neighbors, chunk_documents
+    g = util.load(fname)
+    state = {k[len("param."):]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("param.")}
+    E = g["q"].shape[-1]
+    m = TKL_sigir20(E, [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9], [0.1] * 11, 8 if E % 10 else 10, 1, 32, 2000,
+                    True, True, "embedding")
+    missing, unexpected = m.load_state_dict(state, strict=False)
+    assert not unexpected
+    q, d = torch.from_numpy(g["q"]).float(), torch.from_numpy(g["d"]).float()
+    qm, dm = torch.from_numpy(g["q_mask"]), torch.from_numpy(g["d_mask"])
+    win = torch.from_numpy(g["orig_score"]).float()
+    B = q.shape[0]
+    _, _, _, C = chunk_documents(d, dm)
+    W = (max(C * 40, 30) - 30) // 2 + 1
+    assert win.shape[1] == max(W, 3)
+    peaks = region_peaks(win)
+    assert torch.equal(peaks, torch.from_numpy(g["top_idx"]))                         # :266-271, integer work: exact
+    nb = region_neighbors(peaks, win.shape[1])
+    assert int(nb.min()) >= 0 and int(nb.max()) <= win.shape[1] - 1
+    q_ctx = q * qm.unsqueeze(-1)                                                     # the golden bypasses the contextualiser
+    sec = m._secondary(torch.from_numpy(g["score"]), win, peaks, q_ctx, qm, dm, B, C, 0)
+    assert torch.equal(sec["top_non_overlapping_idx"], torch.from_numpy(g["top_idx"]))
+    np.testing.assert_array_equal(sec["top_k_non_overlapping"].numpy(), g["top_k_non_overlapping"])   # a gather: exact
+    np.testing.assert_allclose(sec["sat_influence_from_top_k"].numpy(), g["sat_influence_from_top_k"], atol=2e-5, rtol=1e-5)
+    assert sec["sat_influence_from_top_k"].shape == (B, 15, q.shape[1], 2)
+    np.testing.assert_array_equal(sec["orig_doc_len"].numpy(), g["d_mask"].sum(-1))
+
+
+def test_tkl_region_tie_policy_classifier():
+    """tests/util.tkl_region_classify is what the GPU rank test trusts to tell "another region of equal score" from "a wrong
+    region": pinned here on hand-made window rows and against the real class's own peaks (tkl goldens)."""
+    from tests import util
+    from matchmaker_amd.tkl import region_peaks
+    for f in util.golden_files("tkl_"):
+        g = util.load(f)
+        if "top_idx" in g:
+            for b in range(g["orig_score"].shape[0]):
+                assert util.tkl_region_search(g["orig_score"][b]) == g["top_idx"][b].tolist()
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.1, 1.0, 200)
+    w[[20, 90, 150]] = [5.0, 4.0, 3.0]
+    assert util.tkl_region_search(w) == [20, 90, 150]
+    assert util.tkl_region_search(w) == region_peaks(torch.from_numpy(w)[None])[0].tolist()
+    assert util.tkl_region_classify(w, [20, 90, 150], 1e-5) == ("same", 0.0)
+    w2 = w.copy()
+    w2[60] = 4.0 - 3e-6                                   # a second candidate 3e-6 below the round-2 peak
+    assert util.tkl_region_search(w2) == [20, 90, 60]
+    cls, gap = util.tkl_region_classify(w2, [20, 60, 90], 1e-5)      # the device took 60 first, then 90: both within the noise
+    assert cls == "tied" and abs(gap - 3e-6) < 1e-9
+    cls, gap = util.tkl_region_classify(w2, [20, 60, 150], 1e-5)     # ... but skipping 90 (1.0 above 150) is wrong
+    assert cls == "wrong" and abs(gap - 1.0) < 1e-6
+    assert util.tkl_region_classify(w2, [20, 60, 90], 1e-6)[0] == "wrong"      # ... and so is a 3e-6 gap at 1e-6 of noise
+    assert util.tkl_region_classify(w2, [20, 25, 90], 1e-5)[0] == "wrong"      # a suppressed window
+    assert util.tkl_region_classify(w, [90, 20, 150], 1e-5)[0] == "wrong"      # same set, wrong order: weights differ (:286)
+    # exact ties go to the lowest index on both sides; all-empty rows pick 0, 15, 30 (:257, :268-273)
+    assert util.tkl_region_search(np.zeros(100)) == [0, 15, 30]
+    assert util.tkl_region_search(np.zeros(20)) == [0, 15, 0]
+    assert util.tkl_region_search(np.zeros(6)) == [0, 0, 0]
+    z = torch.zeros(1, 20)
+    assert region_peaks(z)[0].tolist() == [0, 15, 0]
+    cs = np.arange(1, 16, dtype=np.float64)
+    assert abs(util.tkl_score_at(w, [20, 90, 150], cs) -
+               sum(cs[i] * w[j] for i, j in enumerate([20, 90, 150, 19, 89, 149, 21, 91, 151, 18, 88, 148, 22, 92, 152]))) < 1e-12

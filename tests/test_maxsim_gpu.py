@@ -150,7 +150,7 @@ def test_config2_full_size_properties_and_rank_order():
         ref64 = O.maxsim_paired(np.repeat(qn[i:i + 1], C, 0), dn, qm, dm, dtype=np.float64)
         got = out[i * C:(i + 1) * C].cpu().numpy()
         np.testing.assert_allclose(got, ref32, atol=util.TOL_BF16)
-        # rank order under the measured-noise tie policy (tests/util.rank_parity; every query: test_rank_order_gpu.py)
+        # rank order under the measured-noise tie policy (tests/util.rank_parity; every query: test_zz_rank_order_gpu.py)
         util.rank_parity(got, ref32, ref64, (1, 10, 100, 1000), label=f"query {i}")
 
 

@@ -16,8 +16,10 @@ MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
 SIGMA = [0.1] * 11
 
 
-def make_model(E, sat, dev, heads=None, state=None, bypass=True):
+def make_model(E, sat, dev, heads=None, state=None, bypass=True, seed=1234):
     from matchmaker_amd.tkl import TKL_sigir20
+    torch.manual_seed(seed)      # the constructor draws dense / saturation / sat_emb_reduce1 from the GLOBAL generator: the weights
+                                 # must not depend on which tests ran before (round 4's red TKL rank test)
 
     class Bypass(TKL_sigir20):   # mirrors oracle/ref_harness.TKLBypass: keeps the mask multiply of :306
         def forward_representation(self, emb, mask, positional_features=None):
@@ -49,6 +51,21 @@ def test_tkl_matches_reference_golden(fname):
         win = sec["orig_score"].cpu().numpy()
         ref = g["orig_score"]
         np.testing.assert_allclose(win, ref[:, :win.shape[1]], atol=util.TOL_FP32, rtol=1e-5)
+        # the reference's other secondary outputs (:288-292), from the kernel's own peaks (mm_tkl_fwd_peaks)
+        assert sec["top_non_overlapping_idx"].dtype == torch.long
+        np.testing.assert_array_equal(sec["top_non_overlapping_idx"].cpu().numpy(), g["top_idx"])
+        np.testing.assert_allclose(sec["top_k_non_overlapping"].cpu().numpy(), g["top_k_non_overlapping"], atol=util.TOL_FP32, rtol=1e-5)
+        np.testing.assert_allclose(sec["sat_influence_from_top_k"].cpu().numpy(), g["sat_influence_from_top_k"], atol=1e-4, rtol=1e-4)
+        assert set(sec) >= {"score", "orig_score", "top_non_overlapping_idx", "orig_doc_len", "top_k_non_overlapping",
+                            "sat_influence_from_top_k", "total_chunks", "packed_chunks"}
+        # ... and through the autograd path (training with secondary output): the torch region search on the same windows
+        m.train()
+        score_t, sec_t = m.forward(t(g["q"]).requires_grad_(True), t(g["d"]), t(g["q_mask"]), t(g["d_mask"]), output_secondary_output=True)
+        m.eval()
+        assert score_t.requires_grad and torch.equal(sec_t["top_non_overlapping_idx"], sec["top_non_overlapping_idx"])
+        assert torch.equal(sec_t["top_k_non_overlapping"], sec["top_k_non_overlapping"])
+    else:
+        assert "sat_influence_from_top_k" not in sec      # the reference's log branch raises at :290; the drop-in omits the key
 
 
 @pytest.mark.parametrize("B,Q,D,E,sat", [(3, 20, 500, 300, "embedding"), (2, 30, 2048, 300, "log"),
@@ -79,8 +96,9 @@ def test_tkl_random_vs_oracle(B, Q, D, E, sat):
     params = O.tkl_params_from_state({k: v.cpu() for k, v in m.state_dict().items()})
     ref, ref_win = O.tkl_forward_bypass(q.numpy(), d.numpy(), qm.numpy(), dm.numpy(), params, sat, dtype=np.float64,
                                         return_windows=True)
-    np.testing.assert_allclose(sec["orig_score"].cpu().numpy(), ref_win, atol=util.TOL_FP32, rtol=1e-5)
-    np.testing.assert_allclose(score.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+    # windows: every one within 1e-3; documents: under the region tie policy (tests/util.tkl_check_documents)
+    util.tkl_check_documents(score.cpu().numpy(), sec["orig_score"].cpu().numpy(), sec["top_non_overlapping_idx"].cpu().numpy(),
+                             ref, ref_win, m.chunk_scoring.detach().cpu().numpy().reshape(-1), label=f"random B{B} D{D} {sat}")
 
 
 def test_tkl_config3_scale_properties():
@@ -105,16 +123,18 @@ def test_tkl_config3_scale_properties():
     def score(qx, dx, qmx, dmx):
         q_ctx = qx * qmx.unsqueeze(-1)
         chunks, cmask, slot, C = chunk_documents(dx * dmx.unsqueeze(-1), dmx)
-        s, w = ops.tkl_score(q_ctx, chunks, cmask, slot, qmx, params, B, C, 11, "embedding", return_windows=True)
-        return s, w, (q_ctx, chunks, cmask, slot, C)
+        s, w, pk = ops.tkl_score(q_ctx, chunks, cmask, slot, qmx, params, B, C, 11, "embedding", return_windows=True, return_peaks=True)
+        return s, w, pk, (q_ctx, chunks, cmask, slot, C)
 
-    s1, w1, (q_ctx, chunks, cmask, slot, C) = score(q, d, qm, dm)
-    s2, w2, _ = score(q, d, qm, dm)
-    assert torch.equal(s1, s2) and torch.equal(w1, w2)
+    s1, w1, p1, (q_ctx, chunks, cmask, slot, C) = score(q, d, qm, dm)
+    s2, w2, p2, _ = score(q, d, qm, dm)
+    assert torch.equal(s1, s2) and torch.equal(w1, w2) and torch.equal(p1, p2)
     perm = torch.randperm(B, device=dev)
-    sp, wp, _ = score(q[perm], d[perm], qm[perm], dm[perm])
+    sp, wp, pp, _ = score(q[perm], d[perm], qm[perm], dm[perm])
     assert torch.equal(wp, w1[perm]), "window scores depend on how the packed chunks are grouped"
-    assert torch.equal(sp, s1[perm])
+    assert torch.equal(sp, s1[perm]) and torch.equal(pp, p1[perm])
+    from matchmaker_amd.tkl import region_peaks
+    assert torch.equal(p1, region_peaks(w1)), "the kernel's peaks are the torch region search on its own window scores"
     with torch.no_grad():
         assert torch.equal(m.forward(q, d, qm, dm), s1)          # the drop-in's forward = the operator
     # every document / window vs the fp64 evaluation of sigir20_tkl.py:180-286 (torch port on CPU tensors)
@@ -131,9 +151,10 @@ def test_tkl_config3_scale_properties():
             s_, w_ = TP.tkl_scoring(q_ctx[b0:b1].cpu().double(), centre[keep], cm[keep], packed[b0 * C:b1 * C], b1 - b0,
                                     qm[b0:b1].cpu().double(), prm, "embedding")
         sc.append(s_.numpy()); wn.append(w_.numpy())
-    W = w1.shape[1]
-    np.testing.assert_allclose(w1.cpu().numpy(), np.concatenate(wn)[:, :W], atol=util.TOL_FP32, rtol=1e-5)
-    np.testing.assert_allclose(s1.cpu().numpy(), np.concatenate(sc), atol=util.TOL_FP32, rtol=1e-5)
+    # every window within 1e-3; every document under the region tie policy (a 48-document batch has a ~5 % chance of holding a
+    # region-tied document: asserting 1e-3 on every score, as rounds 1-4 did, is a coin with a 1-in-20 red side)
+    util.tkl_check_documents(s1.cpu().numpy(), w1.cpu().numpy(), p1.cpu().numpy(), np.concatenate(sc), np.concatenate(wn),
+                             m.chunk_scoring.detach().cpu().numpy().reshape(-1), label="config 3")
 
 
 
@@ -384,3 +405,106 @@ print("ACCEPTED")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "REFUSED" in r.stdout or r.returncode != 0, (r.stdout[-300:], r.stderr[-300:])
     assert "ACCEPTED" not in r.stdout
+
+
+# ---- the folded region epilogue (csrc/tkl.hip: the last window workgroup of a document runs the region search) -------------
+# Cross-workgroup, cross-XCD hand-off through HBM: publish (agent-scope stores) -> release fence -> acq_rel arrival counter
+# -> acquire fence -> sum the planes.  A missing fence or a stale cached line would show as a score / window / peak that
+# differs from the standalone tkl_region_kernel (MM_TKL_REGION_KERNEL=1: a kernel boundary instead of the hand-off), that
+# changes between repeated calls, or that carries a value left in the workspace by the previous call.
+
+def _epilogue_cases(dev):
+    """(label, B, Q, D, E, sat, seed): config 3 at 1,024 documents; Q <= 10 (ONE token group: the window output buffer is
+    also the plane the finalizer reads — win == win_final inside the kernel); Q = 30 (three groups); short documents."""
+    return [("config3_1024", 1024, 20, 2048, 300, "embedding", 11), ("one_group_q7", 96, 7, 2048, 300, "embedding", 12),
+            ("one_group_q10_log", 64, 10, 700, 64, "log", 13), ("three_groups_q30", 64, 30, 2048, 300, "embedding", 14),
+            ("short_docs", 200, 20, 90, 128, "embedding", 15)]
+
+
+def _epilogue_inputs(dev, B, Q, D, E, sat, seed):
+    from matchmaker_amd.tkl import chunk_documents
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    m = make_model(E, sat, dev, seed=seed)
+    q = torch.randn(B, Q, E, generator=gen, device=dev)
+    d = torch.randn(B, D, E, generator=gen, device=dev)
+    q_len = torch.randint(1, Q + 1, (B,), generator=gen, device=dev)
+    d_len = torch.randint(min(50, D), D + 1, (B,), generator=gen, device=dev)
+    qm = (torch.arange(Q, device=dev)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < d_len[:, None]).float()
+    q_ctx = q * qm.unsqueeze(-1)
+    chunks, cmask, slot, C = chunk_documents(d * dm.unsqueeze(-1), dm)
+    return q_ctx, chunks, cmask, slot, qm, m.pack_params(), B, C, sat
+
+
+def _epilogue_run_all(path=None):
+    """scores / windows / peaks of every case; `path`: save them (the child process under MM_TKL_REGION_KERNEL=1)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    out = {}
+    for label, B, Q, D, E, sat, seed in _epilogue_cases(dev):
+        q_ctx, chunks, cmask, slot, qm, params, B, C, sat = _epilogue_inputs(dev, B, Q, D, E, sat, seed)
+        s, w, p = ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, sat, return_windows=True, return_peaks=True)
+        out[label + ".score"], out[label + ".win"], out[label + ".peaks"] = s.cpu().numpy(), w.cpu().numpy(), p.cpu().numpy()
+        del q_ctx, chunks
+        torch.cuda.empty_cache()
+    if path:
+        np.savez(path, **out)
+    return out
+
+
+def test_folded_region_epilogue_is_bit_equal_to_the_standalone_region_kernel(tmp_path):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "standalone.npz")
+    r = subprocess.run([sys.executable, "-c", f"from tests.test_tkl_gpu import _epilogue_run_all; _epilogue_run_all({path!r})"], cwd=root,
+                       env=dict(os.environ, MM_TKL_REGION_KERNEL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert not os.environ.get("MM_TKL_REGION_KERNEL"), "this process must run the folded (default) path"
+    alone = np.load(path)
+    folded = _epilogue_run_all()
+    assert set(alone.files) == set(folded)
+    for k in sorted(folded):
+        assert folded[k].shape == alone[k].shape and folded[k].tobytes() == alone[k].tobytes(), f"{k}: folded epilogue != standalone region kernel"
+    assert folded["config3_1024.score"].shape == (1024,) and np.isfinite(folded["config3_1024.score"]).all()
+    assert (folded["config3_1024.peaks"][:, 0] != folded["config3_1024.peaks"][:, 1]).all()
+
+
+def test_folded_region_epilogue_is_stable_under_repetition_concurrency_and_a_poisoned_workspace():
+    """200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI with a caller-owned workspace that is filled with NaN
+    bit patterns (0xFF) before every call — a plane, counter or slot-map entry read before this call wrote it shows up as a
+    NaN or a changed bit — while a second stream keeps the headline MaxSim kernel running on all CUs (the window workgroups'
+    placement over the XCDs and their arrival order change from call to call)."""
+    from matchmaker_amd import ops, _lib, synth
+    dev = util.require_gpu()
+    L = _lib.lib()
+    q_ctx, chunks, cmask, slot, qm, params, B, C, sat = _epilogue_inputs(dev, 256, 20, 2048, 300, "embedding", 21)
+    P, Q, E = chunks.shape[0], q_ctx.shape[1], q_ctx.shape[2]
+    W = (max(C * 40, 30) - 30) // 2 + 1
+    s0, w0, p0 = ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, sat, return_windows=True, return_peaks=True)
+    wsb = L.mm_tkl_workspace_bytes(B, P, C, Q, 11)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    cmask_f, slot_i = cmask.float().contiguous(), slot.to(torch.int32).contiguous()
+    # the disturber: BASELINE configs[1]'s launch (64 queries x 1000 candidates) back to back on a side stream
+    mq, md, mql, mdl = synth.colbert_batch(64, 1000, 32, 180, 128, torch.bfloat16, dev, seed=7)
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    bad = []
+    for it in range(200):
+        out = torch.full((B,), float("nan"), device=dev)
+        win = torch.full((B, W), float("nan"), device=dev)
+        peaks = torch.full((B, 3), -7, dtype=torch.int32, device=dev)
+        ws.fill_(0xFF)
+        if it % 2 == 0:                                  # half of the calls race a MaxSim launch, half run alone
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    ops.maxsim(mq, md, mql, mdl, pairs_per_query=1000)
+        rc = L.mm_tkl_fwd_peaks(q_ctx.data_ptr(), chunks.data_ptr(), cmask_f.data_ptr(), slot_i.data_ptr(), qm.data_ptr(),
+                                params.data_ptr(), win.data_ptr(), out.data_ptr(), peaks.data_ptr(), B, P, C, Q, E, 11, 0,
+                                ws.data_ptr(), wsb, main.cuda_stream)
+        _lib.check(rc, "mm_tkl_fwd_peaks")
+        if not (torch.equal(out, s0) and torch.equal(win, w0) and torch.equal(peaks.long(), p0)):
+            bad.append((it, int((out != s0).sum()), int((win != w0).sum()), int((peaks.long() != p0).sum())))
+    torch.cuda.synchronize()
+    assert not bad, f"calls that differ from the first one (call, scores, windows, peaks): {bad[:10]}"
+    assert torch.isfinite(s0).all() and torch.isfinite(w0).all()

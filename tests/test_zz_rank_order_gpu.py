@@ -251,7 +251,7 @@ def run_tk_rank(name, nq=16, C=1000):
 def _child(fn_name, label, env_extra):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", f"from tests.test_rank_order_gpu import {fn_name}; {fn_name}({label!r})"], cwd=root,
+    r = subprocess.run([sys.executable, "-c", f"from tests.test_zz_rank_order_gpu import {fn_name}; {fn_name}({label!r})"], cwd=root,
                        env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stderr[-3000:]
@@ -265,19 +265,17 @@ def test_rank_order_tk_exact_f32_mfma():
     _child("run_tk_rank", "tk_exact_f32_mfma", {"MM_KP_F32MFMA": "1"})
 
 
-def run_tkl_rank(name, nq=4, C=64):
-    """nq queries x C long documents (config-3 shapes: D = 2048, lengths U{50..2048}, E = 300, Q = 20) through
-    ops.tkl_score on pre-contextualised chunks.  The document score sums 15 window scores picked by three arg-max
-    rounds (sigir20_tkl.py:262-286): when two windows of a document tie within the arithmetic noise the reference's own
-    fp32 and fp64 evaluations pick different regions, so documents whose fp32 / fp64 oracles disagree by more than the
-    window-level noise allows are reported as `unstable` and left out of the ranking lists (expected: none or a few)."""
+def _tkl_case(seed, nq, C, dev):
+    """ONE draw: parameters seeded (`torch.manual_seed` — round 4 built the model from the unseeded global RNG, so its weights
+    depended on which tests had run before), nq queries x C long documents (config-3 shapes: D = 2048, lengths U{50..2048},
+    E = 300, Q = 20) through ops.tkl_score on pre-contextualised chunks, and the fp32 / fp64 oracles of the same inputs."""
     from matchmaker_amd import ops
     from matchmaker_amd.tkl import TKL_sigir20, chunk_documents
     from oracle import torch_port as TP
-    dev = util.require_gpu()
     B, Q, D, E = nq * C, 20, 2048, 300
-    g = torch.Generator().manual_seed(3030)
+    torch.manual_seed(9000 + seed)
     m = TKL_sigir20(E, MU, [0.1] * 11, 10, 1, 32, 2000, True, True, "embedding").eval()
+    g = torch.Generator().manual_seed(3030 + seed)
     with torch.no_grad():
         m.chunk_scoring.copy_(torch.rand(m.chunk_scoring.shape, generator=g) + 0.5)
     qq = torch.randn(nq, Q, E, generator=g)
@@ -296,9 +294,8 @@ def run_tkl_rank(name, nq=4, C=64):
     q_ctx = q * qm.unsqueeze(-1)
     chunks, cmask, slot, Cc = chunk_documents(d * dm.unsqueeze(-1), dm)
     params = m.pack_params()
-    score, win = ops.tkl_score(q_ctx.to(dev), chunks.to(dev), cmask.to(dev), slot.to(dev), qm.to(dev), params.to(dev), B, Cc, 11,
-                               "embedding", return_windows=True)
-    score, win = score.cpu().numpy(), win.cpu().numpy()
+    score, win, peaks = ops.tkl_score(q_ctx.to(dev), chunks.to(dev), cmask.to(dev), slot.to(dev), qm.to(dev), params.to(dev), B, Cc, 11,
+                                      "embedding", return_windows=True, return_peaks=True)
     sd = {k: v for k, v in m.state_dict().items()}
     prm = {k: torch.as_tensor(np.asarray(v)).reshape(-1) for k, v in O.tkl_params_from_state(sd).items()}
     packed = torch.zeros(B * Cc, dtype=torch.bool)
@@ -315,35 +312,62 @@ def run_tkl_rank(name, nq=4, C=64):
                                         qm[b0:b1].to(dt), {k: v.to(dt) for k, v in prm.items()}, "embedding")
             sc.append(s_.numpy()); wn.append(w_.numpy())
         ref[dt] = (np.concatenate(sc), np.concatenate(wn))
-    (s32, w32), (s64, w64) = ref[torch.float32], ref[torch.float64]
-    W = win.shape[1]
-    np.testing.assert_allclose(win, w64[:, :W], atol=util.TOL_FP32, rtol=1e-5)      # every window of every document
-    np.testing.assert_allclose(score, s64, atol=util.TOL_FP32, rtol=1e-5)           # every document
-    assert ((win == 0) == (w64[:, :W] == 0)).all(), "empty windows must be exactly 0 on both sides (:248, :257)"
-    aw = float(np.abs(win - w64[:, :W]).max())
-    bw = float(np.abs(w32[:, :W] - w64[:, :W]).max())
-    # a document is stable when 15 windows x the window noise bounds both evaluations' document score error
-    lim = 15 * 1.5 * 2.0 * max(aw, bw)
-    stable = (np.abs(s32 - s64) <= lim) & (np.abs(score - s64) <= lim)
-    rows = []
-    for i in range(nq):
-        idx = np.arange(i * C, (i + 1) * C)[stable[i * C:(i + 1) * C]]
-        a = float(np.abs(score[idx] - s64[idx]).max())
-        b = float(np.abs(s32[idx] - s64[idx]).max())
-        rows.append(util.rank_parity(score[idx], s32[idx], s64[idx], (1, 10, len(idx)), noise=2.0 * max(a, b), label=f"{name} query {i}"))
+    return {"score": score.cpu().numpy(), "win": win.cpu().numpy(), "peaks": peaks.cpu().numpy(), "ref32": ref[torch.float32],
+            "ref64": ref[torch.float64], "chunk_scoring": m.chunk_scoring.detach().numpy().reshape(-1)}
+
+
+def run_tkl_rank(name, seeds=8, nq=4, C=64):
+    """TKL's document score sums 15 window scores picked by three arg-max rounds (sigir20_tkl.py:262-286): it is DISCONTINUOUS
+    in the window scores.  Tie policy (tests/util.tkl_region_classify) — classify FIRST, assert after:
+      * every WINDOW of every document is within 1e-3 of the fp64 oracle (continuous arithmetic: no policy needed), empty
+        windows are exactly 0 on both sides; a = the measured max window error of the device;
+      * the kernel's three peaks equal the region search re-run in numpy on the kernel's OWN window scores (integer work:
+        exact), and its score equals the 15-term sum of its own windows at those peaks;
+      * a document is `same` when the device's peaks are the fp64 oracle's: its score must be within 1e-3 of the oracle's;
+      * otherwise it is `region-tied` iff, replaying the rounds on the fp64 windows along the device's choices, every choice
+        lies within 4 a of the best window still available (two evaluations with window error <= a can only disagree when the
+        gap is <= 2 a); a device choice further below the best window is WRONG and fails the test; a tied document's score
+        must be within 1e-3 of the fp64 evaluation of the regions the device chose;
+      * tied documents <= 0.5 % over all draws (measured and simulated: ~0.1 % at a = 1e-5);
+      * rank order per query over the non-tied documents under tests/util.rank_parity.
+    `seeds` parameter draws x (nq x C) documents instead of one draw (round 4: one draw x 1,024, red on the driver's box)."""
+    dev = util.require_gpu()
+    rows, n_docs, n_tied, worst_gap, aw_max, bw_max = [], 0, 0, 0.0, 0.0, 0.0
+    for seed in range(seeds):
+        c = _tkl_case(seed, nq, C, dev)
+        score, win, peaks = c["score"], c["win"], c["peaks"]
+        (s32, w32), (s64, w64) = c["ref32"], c["ref64"]
+        B, W = win.shape
+        tied, aw, gap = util.tkl_check_documents(score, win, peaks, s64, w64, c["chunk_scoring"], label=f"{name} draw {seed}")
+        worst_gap = max(worst_gap, gap)
+        bw = float(np.abs(w32[:, :W] - w64[:, :W]).max())
+        assert aw <= 16 * bw + 1e-6, f"{name} draw {seed}: device window error {aw:.3e} vs the fp32 oracle's {bw:.3e}"
+        n_dev_tied = int(tied.sum())
+        # the fp32 oracle is the reference's own arithmetic: its ties are left out of the ranking lists as well
+        for b in range(B):
+            if not tied[b] and util.tkl_region_search(w32[b, :W]) != util.tkl_region_search(w64[b, :W]):
+                tied[b] = True
+        n_docs += B
+        n_tied += n_dev_tied
+        aw_max, bw_max = max(aw_max, aw), max(bw_max, bw)
+        for i in range(nq):
+            idx = np.arange(i * C, (i + 1) * C)[~tied[i * C:(i + 1) * C]]
+            a = float(np.abs(score[idx] - s64[idx]).max())
+            b_ = float(np.abs(s32[idx] - s64[idx]).max())
+            rows.append(util.rank_parity(score[idx], s32[idx], s64[idx], (1, 10, len(idx)), noise=2.0 * max(a, b_),
+                                         label=f"{name} draw {seed} query {i}"))
     frac = util.rank_report(name, rows)
-    print(f"[rank parity] {name}: window error device {aw:.3e} / fp32 oracle {bw:.3e}; unstable documents {int((~stable).sum())} of {B}")
-    assert (~stable).sum() <= B // 20, f"{name}: {int((~stable).sum())} of {B} documents differ beyond the window noise"
-    assert aw <= 16 * bw + 1e-6
-    # 256 positions: one borderline document is 0.4 %.  The fp32 ORACLE's own error (torch on the host's cores: its summation
-    # order follows the thread count) moves between boxes — 3.9e-5 on one, 8.7e-5 on another for these lists — and with it the
-    # tie bound and the set of documents that count as stable: 0.977-1.0 observed with identical device scores
+    print(f"[rank parity] {name}: {seeds} draws x {nq * C} documents; window error device {aw_max:.3e} / fp32 oracle {bw_max:.3e}; "
+          f"region-tied documents {n_tied} of {n_docs} (largest gap {worst_gap:.3e})")
+    assert n_tied <= max(1, n_docs // 200), f"{name}: {n_tied} of {n_docs} documents are region-tied (> 0.5 %)"
+    # 64-document lists: one borderline pair is 1.6 % of a list.  The tie bound follows the larger of the two errors, and the
+    # fp32 ORACLE's (torch on the host's cores: its summation order follows the thread count) moves between boxes
     assert frac >= 0.95, f"{name}: only {frac:.4f} of the rank positions are decided"
     return rows
 
 
 def test_rank_order_tkl_split_bf16():
-    run_tkl_rank("tkl_split_bf16", nq=16)      # 16 queries x 64 long documents (50 s, most of it the fp32 / fp64 oracles on the host)
+    run_tkl_rank("tkl_split_bf16")      # 8 parameter draws x 4 queries x 64 long documents (most of the time: the oracles on the host)
 
 
 def test_rank_order_tkl_exact_f32_mfma():

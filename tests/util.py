@@ -147,3 +147,96 @@ def rank_report(name, rows):
         with open(os.path.join(out, f"rank_parity_{name}.json"), "w") as f:
             json.dump(summary, f)
     return summary["decided_frac"]
+
+
+# ---- TKL region arg-max: tie policy -----------------------------------------------------------------------
+# sigir20_tkl.py:262-286 picks three windows by arg-max with +-15 suppression and sums 15 window scores around them: the
+# document score is DISCONTINUOUS in the window scores.  When two candidate peaks lie closer together than the rounding
+# noise of the window arithmetic, two correct evaluations (the reference's own fp32 and fp64 runs among them) pick different
+# regions and their document scores differ by far more than the window noise.  So "within 1e-3 of the reference" is only
+# defined for documents whose region choice is decided; the others are *region-tied* and get their own, equally strict checks.
+
+def tkl_region_search(win_row):
+    """:254-273 on ONE document's window scores (numpy, any float dtype): 0 -> -9900, three arg-max rounds (first maximal
+    index, like torch.argmax), |r - best| < 15 suppression to -10001 - c.  Returns the three peaks in round order."""
+    w = np.asarray(win_row).copy()
+    if w.shape[0] < 3:
+        w = np.concatenate([w, np.zeros(3 - w.shape[0], w.dtype)])
+    w[w == 0] = -9900
+    r = np.arange(w.shape[0])
+    peaks = []
+    for c in range(3):
+        b = int(np.argmax(w))
+        peaks.append(b)
+        w[np.abs(r - b) < 15] = -10001 - c
+    return peaks
+
+
+def tkl_score_at(win_row, peaks, chunk_scoring):
+    """:276-286 — the document score the window scores `win_row` give for the regions `peaks` (fp64)."""
+    w = np.asarray(win_row, dtype=np.float64)
+    if w.shape[0] < 3:
+        w = np.concatenate([w, np.zeros(3 - w.shape[0])])
+    p = np.asarray(peaks, dtype=np.int64)
+    idx = np.clip(np.concatenate([p, p - 1, p + 1, p - 2, p + 2]), 0, w.shape[0] - 1)
+    return float((w[idx] * np.asarray(chunk_scoring, dtype=np.float64).reshape(-1)).sum())
+
+
+def tkl_region_classify(w64_row, dev_peaks, gap_tol):
+    """Replays the three arg-max rounds on the fp64 oracle's window scores FOLLOWING the device's choices.  Returns
+    ("same" | "tied" | "wrong", gap): "same" = the device's peaks are the fp64 oracle's; otherwise gap = the largest amount by
+    which, in some round, the device's choice lies below the best window still available in fp64 — "tied" when gap <=
+    gap_tol (the choice is within the window arithmetic's noise of the best one), "wrong" when not (or when the device chose
+    a suppressed window)."""
+    ref = tkl_region_search(w64_row)
+    dev = [int(x) for x in dev_peaks]
+    if dev == ref:
+        return "same", 0.0
+    w = np.asarray(w64_row, dtype=np.float64).copy()
+    if w.shape[0] < 3:
+        w = np.concatenate([w, np.zeros(3 - w.shape[0])])
+    w[w == 0] = -9900
+    r = np.arange(w.shape[0])
+    gap = 0.0
+    for c in range(3):
+        gap = max(gap, float(w.max() - w[dev[c]]))
+        w[np.abs(r - dev[c]) < 15] = -10001 - c
+    return ("tied" if gap <= gap_tol else "wrong"), gap
+
+
+def tkl_check_documents(score, win, peaks, s64, w64, chunk_scoring, label="tkl", verbose=True):
+    """The tie policy applied to one batch (see run_tkl_rank in tests/test_zz_rank_order_gpu.py and DESIGN.md §4).  score [B],
+    win [B, W], peaks [B, 3] from the device; s64 [B], w64 [B, >= W] from the fp64 oracle.  Asserts: every window within 1e-3,
+    empty windows exactly 0 on both sides, the kernel's peaks = the search on its own windows, its score = the 15-term sum of
+    its own windows, `same` documents within 1e-3 of the oracle, no `wrong` region, `tied` documents within 1e-3 of the fp64
+    windows evaluated at the device's regions.  Returns (tied mask [B], device window error, largest tied gap)."""
+    score, win, peaks = np.asarray(score), np.asarray(win), np.asarray(peaks)
+    B, W = win.shape
+    w64 = np.asarray(w64)[:, :W]
+    np.testing.assert_allclose(win, w64, atol=TOL_FP32, rtol=1e-5, err_msg=f"{label}: window scores")
+    assert ((win == 0) == (w64 == 0)).all(), f"{label}: empty windows must be exactly 0 on both sides (:248, :257)"
+    aw = float(np.abs(win - w64).max()) if win.size else 0.0
+    gap_tol = 4.0 * max(aw, 1e-7)
+    tied = np.zeros(B, dtype=bool)
+    worst = 0.0
+    for b in range(B):
+        own = tkl_region_search(win[b])
+        assert own == [int(x) for x in peaks[b]], f"{label} doc {b}: kernel peaks {peaks[b]} != search on its own windows {own}"
+        at_own = tkl_score_at(win[b], own, chunk_scoring)
+        assert abs(score[b] - at_own) <= 2e-5 + 2e-6 * abs(at_own), f"{label} doc {b}: score {score[b]} is not the 15-term sum of its windows {at_own}"
+        cls, gap = tkl_region_classify(w64[b], peaks[b], gap_tol)
+        assert cls != "wrong", (f"{label} doc {b}: the device chose a region {gap:.3e} below the best available window "
+                                f"(window noise {aw:.3e}, tie bound {gap_tol:.3e})")
+        if cls == "same":
+            assert abs(score[b] - s64[b]) <= TOL_FP32 + 1e-5 * abs(s64[b]), \
+                f"{label} doc {b}: same regions as the oracle, score {score[b]} vs {s64[b]}"
+        else:
+            tied[b] = True
+            worst = max(worst, gap)
+            at_dev = tkl_score_at(w64[b], peaks[b], chunk_scoring)
+            assert abs(score[b] - at_dev) <= TOL_FP32 + 1e-5 * abs(at_dev), \
+                f"{label} doc {b}: region-tied, score {score[b]} vs fp64 windows at the device's regions {at_dev}"
+            if verbose:
+                print(f"[tkl tie] {label} doc {b}: peaks {peaks[b].tolist()} vs oracle {tkl_region_search(w64[b])}, "
+                      f"gap {gap:.3e} <= {gap_tol:.3e}; score {score[b]:.6f} oracle {s64[b]:.6f}")
+    return tied, aw, worst
