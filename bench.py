@@ -813,6 +813,12 @@ def extra_train_step(steps, cpu_budget):
                # call is large enough to hide the host (the `step` of a 64- or 2,048-pair ColBERT batch is host-bound)
                "backward_op_us": None if b_ms is None else 1e3 * b_ms,
                "backward_op_over_forward": None if b_ms is None else b_ms / f_ms,
+               # device time of the step's kernels (forward + backward operator, each timed back to back) and what is left of
+               # the step: Python + autograd engine + launch gaps.  (The framework's share alone, ops stubbed out on a CPU:
+               # ~54 us per step — Function.apply 10, engine + graph teardown 26 + ... — so a 64-pair step cannot go below
+               # that without leaving torch.autograd.Function.)
+               "kernel_us": None if b_ms is None else 1e3 * (f_ms + b_ms),
+               "host_us": None if b_ms is None else max(0.0, 1e3 * (s_ms - f_ms - b_ms)),
                "algorithmic_bytes": by,
                "roofline": {"bound": "hbm", "achieved": by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -1170,7 +1176,16 @@ def compact_record(out, limit=4000):
                 slim[name] = sl
         c["extra"] = slim
         c["full_record"] = "gpurun_out/bench_full.json (and the FULL_RECORD stdout line before this one)"
-        # hard bound: drop the deepest sub-measurements first, then whole legs from the end
+        # hard bound: drop the least important numbers first, then the deepest sub-measurements, then whole legs from the end
+        def strip(o, key):
+            if isinstance(o, dict):
+                o.pop(key, None)
+                for v in o.values():
+                    strip(v, key)
+        for key in ("us_per_call_device", "frac_needed_bytes", "forward_us", "backward_op_over_forward", "kernel_us"):
+            if len(json.dumps(c)) <= limit:
+                break
+            strip(slim, key)
         while len(json.dumps(c)) > limit and any(isinstance(v, dict) and any(isinstance(x, dict) for x in v.values())
                                                   for v in slim.values()):
             name = max(slim, key=lambda n: len(json.dumps(slim[n])))

@@ -39,6 +39,7 @@ const EnvCfg& env() {
     c.dot_no_spread = env_int("MM_DOT_NO_SPREAD", 0);
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
     c.tkl_region_kernel = env_int("MM_TKL_REGION_KERNEL", 0);
+    c.kp128_occ = env_int("MM_KP128_OCC", 0);
     c.kp_bwd_untiled = env_int("MM_KP_BWD_UNTILED", 0);
     c.kp_bwd_threads = env_int("MM_KP_BWD_THREADS", 1024);
     return c;

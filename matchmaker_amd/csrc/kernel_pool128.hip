@@ -55,8 +55,8 @@ __device__ __forceinline__ void wait_slices8(int younger) {
 // LDS map of a workgroup of KS waves: [KS rings of NBUF slices][KS x rdbuf 128 B][exchange, KS == 2 only:
 // xacc 2 x 4 KiB | xss 2 x 128 B | xq 2 x 2 x 128 B | xtot 2 x 16 B][KS gate vectors]
 constexpr int kXchgBytes = 2 * 4096 + 2 * 128 + 4 * 128 + 32;
-__host__ __device__ constexpr int kp128_lds_fixed(int KS) {
-  return KS * (kS128Nbuf * kS128Bytes + 128) + (KS == 2 ? kXchgBytes : 0);
+__host__ __device__ constexpr int kp128_lds_fixed(int KS, int nbuf = kS128Nbuf) {
+  return KS * (nbuf * kS128Bytes + 128) + (KS == 2 ? kXchgBytes : 0);
 }
 
 // MaxSim epilogue (MX): running maximum per accumulator register with ColBERT's -1000 sentinel for masked rows
@@ -78,13 +78,19 @@ __device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint
 
 // MX: 0 = kernel pooling; 1 = fp32 MaxSim with the two-term split (4 MFMAs per K step); 2 = fp32 MaxSim with the
 // three-term split x = hi + lo + c (6 MFMAs: + c.hi and hi.c; operand error 2^-25, i.e. fp32-class scores)
-template <int NSL, int K, bool W, int KS, int MX = 0>
-__global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpArgs a_in) {
+// OCC = 2 (round 5): TWO wavefronts per SIMD, each with a ring of two slices (16.5 KiB of LDS: eight single-wave workgroups per
+// CU) and at most 256 registers.  For SHORT documents — IDCM's ck-small sampler: 64-token passages, at most two blocks per
+// pair — a lone wavefront per SIMD spends more cycles between the blocks (scalar length / mask lookups with their waits, the
+// log pooling's eleven wave reductions, the store) than in them, and nothing else is resident to fill the gaps; a second
+// wavefront does.  E <= 128 only (the query fragments of wider rows need the whole register file).
+template <int NSL, int K, bool W, int KS, int MX = 0, int OCC = 1>
+__global__ void __launch_bounds__(64 * KS, OCC) kernel_pool_split128_kernel(const KpArgs a_in) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
+  static_assert(OCC == 1 || (OCC == 2 && KS == 1 && NSL <= 2 && !MX && !W), "two wavefronts per SIMD: plain pooling at E <= 128");
   const KpArgs a = kp_block_args(a_in);
   static_assert(!MX || !W, "the fp32 MaxSim mode has no gate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NBUF = kS128Nbuf;
+  constexpr int NBUF = OCC == 2 ? 2 : kS128Nbuf;
   const int lane = threadIdx.x & 63;
   const int wv = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 31, h = lane >> 5;
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(64 * KS) kernel_pool_split128_kernel(const KpA
   float* xss = (float*)(xchg + 8192);              // [2 waves][32 rows]
   float* xq = (float*)(xchg + 8192 + 256);         // [2 toggles][2 waves][32 query tokens]
   float* xtot = (float*)(xchg + 8192 + 256 + 512); // [2 toggles][4]
-  float* wbuf = (float*)(smem + kp128_lds_fixed(KS)) + wv * 32 * nblk_tot;
+  float* wbuf = (float*)(smem + kp128_lds_fixed(KS, NBUF)) + wv * 32 * nblk_tot;
   int q_toggle = 0, p_toggle = 0;
 
   // LDS-DMA source offsets: slot s = 64n + lane -> row s >> 4, stored chunk s & 15 <- global chunk (s & 15) ^ (row & 15)
@@ -460,6 +466,23 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
   const bool gated = a.dw != nullptr;
   const int nsl = a.E / 64;
   const int ks = nsl > 6 ? 2 : 1;
+  // two wavefronts per SIMD (OCC = 2, see the kernel): short documents (<= 3 blocks: the per-pair work — length / mask lookups,
+  // the log pooling's eleven wave reductions, a query tile when the pair brings its own — is as long as the blocks), E <= 128,
+  // enough pairs to give every one of the 2,048 wavefront slots several.  MM_KP128_OCC = 1 / 2 forces either form (A/B runs).
+  const bool occ_ok = !gated && nsl <= 2 && a.n_md == 0;
+  const bool occ_auto = a.D <= 96 && a.n_pairs >= (int64_t)kCUs * 8 * 4;
+  const bool occ2 = occ_ok && (env().kp128_occ == 2 || (env().kp128_occ == 0 && occ_auto));
+  if (occ2) {
+    const int lds2 = kp128_lds_fixed(1, 2);
+    int64_t groups = (int64_t)kCUs * 8;
+    if (groups > a.n_pairs) groups = a.n_pairs;
+    a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
+    groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+    const dim3 grid((unsigned)groups);
+    if (nsl == 1) hipLaunchKernelGGL((kernel_pool_split128_kernel<1, 11, false, 1, 0, 2>), grid, dim3(64), lds2, stream, a);
+    else hipLaunchKernelGGL((kernel_pool_split128_kernel<2, 11, false, 1, 0, 2>), grid, dim3(64), lds2, stream, a);
+    return check_launch("kernel_pool_split128_kernel<two wavefronts per SIMD>");
+  }
   const int lds = kp128_lds_fixed(ks) + (gated ? ks * 128 * ((a.D + 31) >> 5) : 0);
   int64_t groups = (int64_t)kCUs * 4 / ks;  // one wave per SIMD either way
   if (groups > a.n_pairs) groups = a.n_pairs;

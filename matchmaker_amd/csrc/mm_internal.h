@@ -39,6 +39,7 @@ struct EnvCfg {
   int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
   int kp_bwd_threads = 1024; // MM_KP_BWD_THREADS: 1024 (when its LDS fits) | 512 threads per pair in kernel_pool_bwd_tiled_kernel (A/B runs)
   int kp_bwd_untiled = 0;   // MM_KP_BWD_UNTILED: pooling backward on the per-element kernel of rounds 1-3 (A/B runs)
+  int kp128_occ = 0;          // MM_KP128_OCC: 0 = choose by shape, 1 / 2 = wavefronts per SIMD of the 64n-wide pooling kernel (A/B runs)
   int tkl_region_kernel = 0;  // MM_TKL_REGION_KERNEL: TKL's region top-k as its own launch (rounds 1-3) instead of the last window workgroup (A/B runs)
   int tkl_pairsums = 0;     // MM_TKL_PAIRSUMS: TKL stage 1 emits pair sums (round-2 data path) instead of cosines (A/B runs)
 };

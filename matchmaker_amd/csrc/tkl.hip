@@ -22,6 +22,9 @@ constexpr int kWinPairs = 15; // 30 positions, stride 2
 constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows staged: kWT + 14)
 constexpr int kWThreads = 256;
 constexpr int kTokGroup = 10;  // query tokens per window workgroup (see tkl_window_kernel)
+#ifndef MM_TKL_EPILOGUE_ORDER
+#define MM_TKL_EPILOGUE_ORDER 1   // 0: round 4 (relaxed counter + s_waitcnt), 1: acq_rel counter by thread 0, 2: fences in every thread
+#endif
 constexpr int kRThreads = 256;  // region kernel (1,024 threads, one window each, measured slower: 11.3 vs 9.8-10.5 us)
 
 __device__ __forceinline__ void region_topk(float* orig, float* work, float* rv, int* ri, int Wp, const float* __restrict__ prm,
@@ -245,12 +248,14 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   // The "last block" reduction pattern, written to the HIP memory model (round 5; round 4 relied on gfx950's sc1 write-through
   // behaviour alone).  Every workgroup that scores a live tile of document b
   //   1. publishes its 64 partial window scores (agent-scope atomic stores: sc1 write-through),
-  //   2. every thread issues an agent-scope RELEASE fence (buffer_wbl2 sc1 + s_waitcnt: its stores are visible device-wide),
-  //   3. barrier, then thread 0 arrives on done_cnt[b] with an ACQ_REL agent-scope fetch_add.
-  // The workgroup whose arrival completes the document (old + 1 == expected) issues an agent-scope ACQUIRE fence in every
-  // thread (buffer_inv sc1: no stale line of another XCD's scores in this XCD's L2), sums the planes and runs the region
-  // search in the LDS its tile just left.  release-fence -> acq_rel RMW chain on one counter -> acquire-fence orders every
-  // publisher's stores before the finalizer's loads, whichever XCDs they ran on.  expected = live tiles x live token groups
+  //   2. meets at the workgroup barrier (workgroup-scope release / acquire between its threads),
+  //   3. thread 0 arrives on done_cnt[b] with an ACQ_REL agent-scope fetch_add: the release half (buffer_wbl2 sc1 + s_waitcnt)
+  //      covers the whole workgroup's scores through the barrier (happens-before is transitive across scopes).
+  // The workgroup whose arrival completes the document (old + 1 == expected) has, through thread 0's acquire half
+  // (buffer_inv sc1) and the second barrier, every other workgroup's scores ordered before its own loads (which are agent-scope
+  // atomic loads besides: no stale line of another XCD's L2), sums the planes and runs the region search in the LDS its tile
+  // just left.  (A release fence in EVERY thread, round 5's first form, cost +0.19 ms per 256-document call — a buffer_wbl2
+  // from every wavefront; MM_TKL_EPILOGUE_ORDER=2 keeps it for A/B.)  expected = live tiles x live token groups
   // of the document — dead tiles (past the last kept chunk, tkl_prep_kernel) and groups without a real token neither write
   // nor arrive.  out == nullptr: the standalone tkl_region_kernel follows (MM_TKL_REGION_KERNEL=1) and this kernel only
   // publishes.  win / win_final are NOT __restrict__: with one token group (Q <= 10) they are the same buffer (each thread
@@ -288,15 +293,27 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   };
   auto arrive = [&]() {
     if (!out) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // this thread's published scores are visible device-wide
-    __syncthreads();                                                   // ... and so are every thread's; the tile's LDS is free
+#if MM_TKL_EPILOGUE_ORDER == 2
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // (A/B: a release fence in EVERY thread: +0.19 ms at 256 documents)
+#elif MM_TKL_EPILOGUE_ORDER == 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (A/B: round 4's hardware-level ordering, not the memory model's)
+#endif
+    __syncthreads();   // workgroup-scope release / acquire: every thread's published scores happen-before thread 0's RMW below
     if (tid == 0) {
+#if MM_TKL_EPILOGUE_ORDER == 0
+      const int old = __hip_atomic_fetch_add(done_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+      // ACQ_REL at agent scope: release = the workgroup's scores (cumulative over the barrier) are visible device-wide before
+      // the count; acquire = the finalizer sees the scores of every workgroup that counted before it
       const int old = __hip_atomic_fetch_add(done_cnt + b, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       last_flag = old + 1 == expected;
     }
-    __syncthreads();
+    __syncthreads();   // ... and thread 0's acquire happens-before every thread's loads in finalize()
     if (last_flag) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // the other workgroups' scores, not a stale cached line
+#if MM_TKL_EPILOGUE_ORDER == 2
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
       finalize();
     }
   };

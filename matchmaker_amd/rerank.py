@@ -26,11 +26,18 @@ class _GraphedForward:
     """One captured `model.forward` per batch shape (HIP graph): eval.py issues thousands of identical 512-pair steps
     (defaults.yaml:115), each of which costs ~10 us of Python + launches per kernel when issued eagerly — more than the
     4 us of HBM time a dim-128 ColBERT batch needs.  The tokenizer tensors of a batch are copied straight into the graph's
-    static input buffers (the H2D copy eval.py:89 makes anyway) and the graph is replayed."""
+    static input buffers (the H2D copy eval.py:89 makes anyway) and the graph is replayed.
+    Measured (bench.py extra.eval_batch.graph_replay): SLOWER than the eager path for dim-128 ColBERT batches (14.1 vs 10.5 us
+    per call), so `graph=False` stays the default.  eval.py pads each batch to its longest sequence, so real runs see many
+    (B, Lq, Ld) shapes: the cache is an LRU of at most `max_graphs` captures (each holds its static inputs and a private
+    memory pool); shapes beyond it, and shapes whose capture fails, run eagerly."""
 
-    def __init__(self, model, use_fp16, output_secondary_output, device):
+    def __init__(self, model, use_fp16, output_secondary_output, device, max_graphs: int = 16):
+        from collections import OrderedDict
         self.model, self.use_fp16, self.sec, self.device = model, use_fp16, output_secondary_output, device
-        self.entries = {}
+        self.entries = OrderedDict()
+        self.max_graphs = max_graphs
+        self.eager_calls = 0
 
     def _run(self, static):
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.use_fp16):
@@ -41,19 +48,31 @@ class _GraphedForward:
     def __call__(self, batch_orig):
         parts = {k: batch_orig[k] for k in ("query_tokens", "doc_tokens")}
         key = tuple((k, n, tuple(t.shape), t.dtype) for k in parts for n, t in sorted(parts[k].items()))
-        entry = self.entries.get(key)
-        if entry is None:
+        entry = self.entries.get(key, False)
+        if entry is False:
             static = _to_device(parts, self.device)
             static = {k: {n: t.clone() for n, t in v.items()} for k, v in static.items()}
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                      # warm-up outside capture (lazy initialisation, workspaces)
-                self._run(static)
+                eager_out = self._run(static)
             torch.cuda.current_stream(self.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._run(static)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._run(static)
+            except Exception:                                  # not capturable (data-dependent shapes, a host sync): eager, every time
+                self.entries[key] = entry = None
+                self.eager_calls += 1
+                return eager_out
             entry = self.entries[key] = (g, static, out)
+            while len(self.entries) > self.max_graphs:         # least recently replayed shape goes (its pool is freed with it)
+                self.entries.popitem(last=False)
+        elif key in self.entries:
+            self.entries.move_to_end(key)
+        if entry is None:                                      # a shape whose capture failed before
+            self.eager_calls += 1
+            return self._run(_to_device(parts, self.device))
         g, static, out = entry
         for k, v in parts.items():
             for n, t in v.items():

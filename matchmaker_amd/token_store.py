@@ -25,6 +25,7 @@ from . import ops
 class TokenStore:
     def __init__(self, tokens: torch.Tensor, seq_ids: Sequence, begin: np.ndarray, end: np.ndarray):
         self._tokens = tokens                         # [T, E] on the scoring device (read-only: the ranges below were validated against it)
+        self._tokens_lowp = None                      # fp16 image of an fp32 store, built on the first use_fp16 aggregate()
         self.seq_ids = list(seq_ids)
         self._index = {s: i for i, s in enumerate(self.seq_ids)}
         self._begin = np.asarray(begin, dtype=np.int64)   # global row ranges per document
@@ -85,8 +86,10 @@ class TokenStore:
         reference loops over, :400-402).  use_fp16: the searcher head's autocast switch (indexing_heads.py:49-56,
         `model_config["use_fp16"]` at :407): the stored rows go through `.float()` and autocast's cast back — the same fp16
         values — and `bmm` / `max` return fp16, so every per-token maximum is rounded to fp16 before the fp32 sum;
-        False = fp32 similarities of the stored values.  Returns, per query, [(seq_id, score)] like
-        `validation_results[query_id]` (:410)."""
+        False = fp32 similarities of the stored values.  An fp32 store (`token_dtype: float32`) under use_fp16 is scored as
+        the reference's autocast scores it: `bmm` casts BOTH operands to fp16 first, so the store's fp16 image (built once, on
+        the first such call: +50 % of the store's memory) and the fp16 query are what the kernel reads — MM_SIM_ROUND alone
+        would be a no-op on fp32 rows.  Returns, per query, [(seq_id, score)] like `validation_results[query_id]` (:410)."""
         nq = query_vecs.shape[0]
         if len(candidates) != nq:
             raise ValueError(f"{nq} queries but {len(candidates)} candidate lists")
@@ -106,8 +109,13 @@ class TokenStore:
         for i, n in enumerate(counts):
             bb[i, :n], ee[i, :n] = b[off: off + n], e[off: off + n]
             off += n
-        q = query_vecs.to(self.tokens.dtype)
-        scores = ops.maxsim_ragged(q, self.tokens, bb.view(-1), ee.view(-1), None, pairs_per_query=C, check_ranges=False,
+        tokens = self.tokens
+        if use_fp16 and tokens.dtype == torch.float32:
+            if self._tokens_lowp is None:
+                self._tokens_lowp = tokens.to(torch.float16)
+            tokens = self._tokens_lowp
+        q = query_vecs.to(tokens.dtype)
+        scores = ops.maxsim_ragged(q, tokens, bb.view(-1), ee.view(-1), None, pairs_per_query=C, check_ranges=False,
                                    sim_round=bool(use_fp16)).view(nq, C)
         scores = scores.cpu()
         return [[(candidates[i][j], float(scores[i, j])) for j in range(counts[i])] for i in range(nq)]

@@ -118,11 +118,12 @@ def cosine_matrix(a, b, dtype=np.float32):
     return np.matmul(an, np.swapaxes(bn, -1, -2))
 
 
-def cosine_matrix_split_bf16(a, b, lolo=True):
-    """Emulation of the DEVICE arithmetic of the split-bf16 kernels (matchmaker_amd/csrc/
-    kernel_pool.hip): x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
-    dot = hi.hi + lo.hi + hi.lo (+ lo.lo: TKL's stage 1 keeps it, the TK pooling kernel dropped it in round 4 — lolo=False)
-    (products exact, fp32-class accumulation), norms from the
+def cosine_matrix_split_bf16(a, b, lolo=False):
+    """Emulation of the DEVICE arithmetic of the split-bf16 kernels: x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+    dot = hi.hi + lo.hi + hi.lo — the THREE products the shipped TK pooling kernel and TKL's stage 1 compute
+    (matchmaker_amd/csrc/kernel_pool.hip: MM_KP_LOLO and MM_TKL_LOLO both default to 0 since round 4).  lolo=True adds
+    lo.lo: the four-product form of the 64n-wide kernels (kernel_pool128.hip: Conv-KNRM, IDCM sampler, fp32 MaxSim) and of
+    the -DMM_KP_LOLO=1 / -DMM_TKL_LOLO=1 A/B builds.  (Products exact, fp32-class accumulation), norms from the
     fp32 values.  Not a reference restatement: it exists so the CPU suite can bound the device
     scheme's error against `cosine_matrix(..., float64)` without a GPU."""
     a = np.asarray(a, dtype=np.float32)

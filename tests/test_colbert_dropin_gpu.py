@@ -124,3 +124,39 @@ def test_full_forward_matches_the_real_colbert_class_end_to_end():
     np.testing.assert_allclose(agg.cpu().numpy(), g["forward_aggregation"], atol=5e-3, rtol=2e-5)
     np.testing.assert_allclose(score16.cpu().numpy(), g["forward"], atol=0.5, rtol=2e-3)     # fp16 autocast encoder
     assert np.array_equal(np.argsort(-score.cpu().numpy(), kind="stable"), np.argsort(-g["forward"], kind="stable"))
+
+
+def test_graphed_evaluation_equals_eager_and_its_cache_is_bounded():
+    """rerank.evaluate_batches(graph=True): one HIP-graph capture per batch shape, replayed — same scores as the eager loop,
+    incl. a short last batch (another shape) and the secondary-output convention; the capture cache is an LRU (eval.py pads
+    every batch to its longest sequence: real runs see many shapes)."""
+    from matchmaker_amd import rerank
+    dev = util.require_gpu()
+    m = _model(dev)
+    g = torch.Generator().manual_seed(4)
+
+    def batch(B, Q, D, tag):
+        ql, dl = torch.randint(3, Q + 1, (B,), generator=g), torch.randint(8, D + 1, (B,), generator=g)
+        mk = lambda L, n: {"input_ids": torch.randint(1, 500, (B, n), generator=g),
+                           "attention_mask": (torch.arange(n)[None] < L[:, None]).long()}
+        return {"query_tokens": mk(ql, Q), "doc_tokens": mk(dl, D), "query_id": [f"q{tag}_{i % 3}" for i in range(B)],
+                "doc_id": [f"d{tag}_{i}" for i in range(B)]}
+    batches = [batch(16, 32, 180, 0), batch(16, 32, 180, 1), batch(16, 30, 170, 2), batch(16, 32, 180, 3), batch(5, 32, 180, 4)]
+    for sec in (False, True):
+        eager = rerank.evaluate_batches(m, batches, use_fp16=True, output_secondary_output=sec)
+        graphed = rerank.evaluate_batches(m, batches, use_fp16=True, output_secondary_output=sec, graph=True)
+        assert eager.keys() == graphed.keys()
+        for k in eager:
+            assert [d for d, _ in eager[k]] == [d for d, _ in graphed[k]]
+            np.testing.assert_array_equal([s for _, s in eager[k]], [s for _, s in graphed[k]])
+    # LRU bound: three shapes through a cache of two -> two captures alive, every score still right
+    gf = rerank._GraphedForward(m, True, False, dev, max_graphs=2)
+    with torch.no_grad():
+        outs = [gf(b).clone() for b in batches]
+        again = gf(batches[0]).clone()
+    assert len(gf.entries) == 2 and gf.eager_calls == 0
+    assert torch.equal(again, outs[0]) and outs[4].shape == (5,)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        want = m.forward({k: v.to(dev) for k, v in batches[2]["query_tokens"].items()},
+                         {k: v.to(dev) for k, v in batches[2]["doc_tokens"].items()})
+    assert torch.equal(outs[2], want)

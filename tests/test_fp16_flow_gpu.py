@@ -232,3 +232,37 @@ def test_flags_are_noops_for_fp32_and_unknown_flags_are_refused():
     rc = _lib.lib().mm_maxsim_fwd(q.data_ptr(), d.data_ptr(), None, _lib.MASK_NONE, None, _lib.MASK_NONE, out.data_ptr(), 100, 50,
                                   32, 180, 128, _lib.MM_F32, 8, None, 0, None)
     assert rc == -1 and b"flags" in _lib.lib().mm_last_error()
+
+
+def test_an_fp32_token_store_under_use_fp16_is_scored_as_autocast_scores_it():
+    """TokenStore.aggregate(use_fp16=True) on a `token_dtype: float32` store: the reference's searcher head runs
+    forward_aggregation under autocast (indexing_heads.py:49-56), whose bmm casts BOTH operands to fp16 — fp16 values, fp16
+    maxima, fp32 sum.  (Round 4 only set MM_SIM_ROUND, which is a no-op on fp32 rows: fp32 scores, silently.)  Checked against
+    torch's own statements under autocast on the padded copy, and against the fp16 store of the same values."""
+    from matchmaker_amd.token_store import TokenStore
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(77)
+    n, Q, E, Dmax = 120, 32, 128, 70
+    lens = torch.randint(1, Dmax + 1, (n,), generator=g)
+    end = torch.cumsum(lens, 0).numpy()
+    begin = end - lens.numpy()
+    tok32 = torch.nn.functional.normalize(torch.randn(int(end[-1]), E, generator=g), dim=-1)
+    q32 = torch.nn.functional.normalize(torch.randn(2, Q, E, generator=g), dim=-1)
+    q32[1, 20:] = 0                                                      # an encoded query with padded (zeroed) positions
+    ids = list(range(n))
+    st32 = TokenStore(tok32.to(dev), ids, begin, end)
+    st16 = TokenStore(tok32.half().to(dev), ids, begin, end)
+    cands = [ids[:90], ids[30:]]
+    got = st32.aggregate(q32.to(dev), cands, use_fp16=True)
+    same = st16.aggregate(q32.to(dev), cands, use_fp16=True)
+    assert got == same                                                   # the fp16 image of the store IS what gets scored
+    plain = st32.aggregate(q32.to(dev), cands, use_fp16=False)
+    assert any(abs(a[1] - b[1]) > 0 for ra, rb in zip(got, plain) for a, b in zip(ra, rb))      # and it is not the fp32 scoring
+    # torch's own statements under autocast (colbert.py:100-112), candidate by candidate as dense_retrieval.py:400-409 loops
+    for qi, cl in enumerate(cands):
+        for j in (0, len(cl) // 2, len(cl) - 1):
+            d = tok32[begin[cl[j]]:end[cl[j]]].unsqueeze(0).to(dev)
+            with torch.autocast("cuda", dtype=torch.float16):
+                sc = torch.bmm(q32[qi:qi + 1].to(dev), d.transpose(2, 1)).max(-1).values.sum(-1)
+            assert got[qi][j][0] == cl[j]
+            assert abs(got[qi][j][1] - float(sc)) <= 2 * 2.0 ** -11 * Q, (got[qi][j], float(sc))

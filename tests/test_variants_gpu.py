@@ -302,3 +302,42 @@ def test_knrm_with_21_kernels():
                              np.asarray(m.sigma.cpu()).reshape(-1), m.dense.weight.detach().cpu().numpy().reshape(-1),
                              dtype=np.float64)
     np.testing.assert_allclose(s.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+@pytest.mark.parametrize("E,D", [(128, 64), (64, 96), (128, 33)])
+def test_short_document_form_with_two_wavefronts_per_simd_matches_the_oracle(E, D):
+    """kernel_pool_split128_kernel<.., OCC = 2> (csrc/kernel_pool128.hip): chosen for documents of <= 96 tokens at E <= 128
+    once the call holds >= 8,192 pairs (IDCM's ck-small sampler, sigir21_idcm.py:182-186, on 64-token passages).  9,000
+    pairs in the three query layouts — shared query tile (pairs_per_query), one tile per pair, ragged groups through
+    pair_query — with ragged lengths, an empty document and hole masks, every pair against the fp64 oracle; the three
+    layouts must also agree bit for bit (same arithmetic, different addressing)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    gen = torch.Generator().manual_seed(E * 100 + D)
+    nq, C, Q = 9, 1000, 30
+    B = nq * C
+    q = torch.relu(torch.randn(nq, Q, E, generator=gen))
+    d = torch.relu(torch.randn(B, D, E, generator=gen))
+    for b in range(0, B, 7):
+        d[b, b % D] = q[b // C, b % Q] * 1.3                      # planted exact matches
+    q_len = torch.randint(1, Q + 1, (nq,), generator=gen)
+    d_len = torch.randint(1, D + 1, (B,), generator=gen)
+    d_len[5] = 0
+    d_len[B - 1] = D
+    qm = (torch.arange(Q)[None] < q_len[:, None])
+    dm = (torch.arange(D)[None] < d_len[:, None])
+    dm[11, 2] = False                                             # a hole (not a prefix mask)
+    alpha = torch.rand(11, generator=gen) + 0.5
+    w = torch.rand(11, generator=gen) - 0.5
+    mu, sg = torch.tensor(MU), torch.tensor(SIGMA)
+    t = lambda x: x.to(dev)
+    with torch.no_grad():
+        shared = ops.kernel_pool(t(q), t(d), t(qm), t(dm), t(mu), t(sg), t(alpha), t(w), pairs_per_query=C, clamp_min=1e-4)
+        qrep, qmrep = q.repeat_interleave(C, 0), qm.repeat_interleave(C, 0)
+        paired = ops.kernel_pool(t(qrep), t(d), t(qmrep), t(dm), t(mu), t(sg), t(alpha), t(w), pairs_per_query=1, clamp_min=1e-4)
+        pq = (torch.arange(B) // C).to(torch.int32)
+        ragged = ops.kernel_pool(t(q), t(d), t(qm), t(dm), t(mu), t(sg), t(alpha), t(w), clamp_min=1e-4, pair_query=t(pq))
+    assert torch.equal(shared, paired) and torch.equal(shared, ragged)
+    ref = O.idcm_sampler_scores(qrep.numpy(), d.numpy(), qmrep.numpy(), dm.numpy(), MU, SIGMA, alpha.numpy(), w.numpy(), 0.0,
+                                dtype=np.float64)
+    np.testing.assert_allclose(shared.cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
