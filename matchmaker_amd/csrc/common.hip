@@ -38,8 +38,9 @@ const EnvCfg& env() {
     c.dot_prof = env_int("MM_DOT_PROF", 0);
     c.dot_no_spread = env_int("MM_DOT_NO_SPREAD", 0);
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
-    c.tkl_region_kernel = env_int("MM_TKL_REGION_KERNEL", 0);
+    c.tkl_fold_regions = env_int("MM_TKL_FOLD_REGIONS", 0);
     c.kp128_occ = env_int("MM_KP128_OCC", 0);
+    c.kp_multi_2d = env_int("MM_KP_MULTI_2D", 0);
     c.kp_bwd_untiled = env_int("MM_KP_BWD_UNTILED", 0);
     c.kp_bwd_threads = env_int("MM_KP_BWD_THREADS", 1024);
     return c;

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64 * KS, OCC) kernel_pool_split128_kernel(cons
   const int lane = threadIdx.x & 63;
   const int wv = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 31, h = lane >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p0 = (int64_t)a.block_x * a.pairs_per_wave;
   const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
   if (p0 >= p1) return;
   constexpr int E = 64 * NSL * KS;
@@ -469,16 +469,27 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
   // two wavefronts per SIMD (OCC = 2, see the kernel): short documents (<= 3 blocks: the per-pair work — length / mask lookups,
   // the log pooling's eleven wave reductions, a query tile when the pair brings its own — is as long as the blocks), E <= 128,
   // enough pairs to give every one of the 2,048 wavefront slots several.  MM_KP128_OCC = 1 / 2 forces either form (A/B runs).
-  const bool occ_ok = !gated && nsl <= 2 && a.n_md == 0;
-  const bool occ_auto = a.D <= 96 && a.n_pairs >= (int64_t)kCUs * 8 * 4;
+  const bool occ_ok = !gated && nsl <= 2;
+  // ... and Conv-KNRM's multi launch at E = 128 (n_md > 0): in the flat XCD-grouped order (KpArgs::m_flat) two of three readers
+  // of a block hit the L2, the launch turns from HBM-bound into epilogue-bound, and a second wavefront's MFMAs run under the
+  // first one's RBF evaluations
+  const bool occ_auto = (a.D <= 96 || a.n_md > 0) && a.n_pairs >= (int64_t)kCUs * 8 * 4;
   const bool occ2 = occ_ok && (env().kp128_occ == 2 || (env().kp128_occ == 0 && occ_auto));
+  const int per_cu = occ2 ? 8 : 4 / ks;
+  auto flat_grid = [&](int64_t groups) {      // multi launch: n_mblk workgroups per pair range, XCD-grouped (kp_block_args)
+    a.m_flat = a.n_md > 0 && !env().kp_multi_2d;
+    a.m_ranges = (int)groups;
+    if (!a.m_flat) return dim3((unsigned)groups, (unsigned)(a.n_md > 0 ? a.n_mblk : 1));
+    const int64_t flat = (groups * a.n_md + 7) / 8 * 8;               // (range, document tensor) slots, whole groups of 8
+    return dim3((unsigned)(flat * (a.n_mblk / a.n_md)), 1u);
+  };
   if (occ2) {
     const int lds2 = kp128_lds_fixed(1, 2);
-    int64_t groups = (int64_t)kCUs * 8;
+    int64_t groups = (int64_t)kCUs * per_cu;
     if (groups > a.n_pairs) groups = a.n_pairs;
     a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
     groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-    const dim3 grid((unsigned)groups);
+    const dim3 grid = flat_grid(groups);
     if (nsl == 1) hipLaunchKernelGGL((kernel_pool_split128_kernel<1, 11, false, 1, 0, 2>), grid, dim3(64), lds2, stream, a);
     else hipLaunchKernelGGL((kernel_pool_split128_kernel<2, 11, false, 1, 0, 2>), grid, dim3(64), lds2, stream, a);
     return check_launch("kernel_pool_split128_kernel<two wavefronts per SIMD>");
@@ -488,7 +499,7 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
   if (groups > a.n_pairs) groups = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
   groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  const dim3 grid((unsigned)groups, (unsigned)(a.n_md > 0 ? a.n_mblk : 1));
+  const dim3 grid = flat_grid(groups);
 #define MM_KP128(NSL, KS) \
   return gated ? launch128<NSL, true, KS>(a, grid, lds, stream) : launch128<NSL, false, KS>(a, grid, lds, stream)
   switch (nsl) {

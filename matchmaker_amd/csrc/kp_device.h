@@ -63,12 +63,32 @@ struct KpArgs {
   const float* md[4];
   int n_md;
   int n_mblk;  // n_mq * n_md = grid.y (0 when n_md = 0)
+  // Flat, XCD-grouped order of a multi launch (kernel_pool128.hip, round 5).  The 2-D grid ran combination after combination:
+  // each document tensor crossed HBM once per QUERY tensor (3 x for Conv-KNRM's 3 x 3), a whole collection apart.  Flat: the
+  // n_mq workgroups that score the same pair range of the same document tensor get the linear ids g, g + 8, g + 16 — same XCD
+  // (workgroup b runs on XCD b % 8: observed, used for speed only), dispatched together — so the second and third reader of a
+  // block find it in that XCD's L2 (a follower cannot overtake the leader without taking over its misses: the three stay
+  // together).  m_ranges = pair ranges per combination (the 2-D grid's x extent); block_x = this workgroup's range.
+  int m_flat;
+  int m_ranges;
+  int block_x;
 };
 
 __device__ __forceinline__ KpArgs kp_block_args(const KpArgs& a) {
   KpArgs b = a;
+  b.block_x = (int)blockIdx.x;
   if (a.n_md > 0) {
-    const int y = blockIdx.y, i = y / a.n_md, t = y - i * a.n_md;
+    int y = blockIdx.y;
+    if (a.m_flat) {
+      const int n_mq = a.n_mblk / a.n_md, period = 8 * n_mq;
+      const int g = (int)blockIdx.x, blk = g / period, r = g - blk * period;
+      const int64_t fr = (int64_t)blk * 8 + (r & 7);                 // flat (pair range, document tensor)
+      const int x = (int)(fr / a.n_md), t = (int)(fr - (int64_t)x * a.n_md);
+      // (the divisions run on the VALU: tell the compiler the results are wave-uniform again — scalar loads hang off them)
+      y = __builtin_amdgcn_readfirstlane((r >> 3) * a.n_md + t);
+      b.block_x = __builtin_amdgcn_readfirstlane(x < a.m_ranges ? x : 0x3fffffff);   // padding workgroups: a range past the pairs, they leave at once
+    }
+    const int i = y / a.n_md, t = y - i * a.n_md;
     b.q = a.mq[i];
     b.d = a.md[t];
     b.w = a.w + y * a.K;

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   const int b = blockIdx.y;
   const int w0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
-  // ---- last-workgroup epilogue (round 4: the region top-k of :254-286 no longer has its own launch) ------------------------
+  // ---- last-workgroup epilogue (MM_TKL_FOLD_REGIONS=1 only; round 4's default: the region top-k of :254-286 without its own launch) ----
   // The "last block" reduction pattern, written to the HIP memory model (round 5; round 4 relied on gfx950's sc1 write-through
   // behaviour alone).  Every workgroup that scores a live tile of document b
   //   1. publishes its 64 partial window scores (agent-scope atomic stores: sc1 write-through),
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
   // just left.  (A release fence in EVERY thread, round 5's first form, cost +0.19 ms per 256-document call — a buffer_wbl2
   // from every wavefront; MM_TKL_EPILOGUE_ORDER=2 keeps it for A/B.)  expected = live tiles x live token groups
   // of the document — dead tiles (past the last kept chunk, tkl_prep_kernel) and groups without a real token neither write
-  // nor arrive.  out == nullptr: the standalone tkl_region_kernel follows (MM_TKL_REGION_KERNEL=1) and this kernel only
+  // nor arrive.  out == nullptr (the DEFAULT since round 5, see mm_tkl_fwd_peaks): the standalone tkl_region_kernel follows and this kernel only
   // publishes.  win / win_final are NOT __restrict__: with one token group (Q <= 10) they are the same buffer (each thread
   // reads and writes only its own windows there).
   const float* const part = win;
@@ -593,8 +593,8 @@ __device__ __forceinline__ void region_topk(float* orig, float* work, float* rv,
   }
 }
 
-// One 256-thread workgroup per document: the standalone form (MM_TKL_REGION_KERNEL=1, A/B runs; since round 4 the LAST window
-// workgroup of a document does this itself, see tkl_window_kernel).  (One wavefront per document spent 16 us on sixteen
+// One 256-thread workgroup per document: the default form (round 4 let the LAST window workgroup of a document do this itself,
+// see tkl_window_kernel: MM_TKL_FOLD_REGIONS=1 for A/B runs).  (One wavefront per document spent 16 us on sixteen
 // dependent 4-byte loads per lane; four wavefronts load the ~1,000 scores of a 2,048-token document in four rounds.)
 __global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* part, int n_planes, int64_t plane,
                                                          const int32_t* __restrict__ q_len, float* win,
@@ -744,9 +744,17 @@ extern "C" int mm_tkl_fwd_peaks(const void* q_ctx, const void* chunks, const flo
     if (n_planes > 65535 || B > 65535) return set_error(MM_EUNSUPPORTED, "tkl: grid limits (B=%lld, Q=%d)", (long long)B, Q);
     const dim3 grid2((unsigned)((W + kWT - 1) / kWT), (unsigned)B, (unsigned)n_planes);
     float* wdst = n_planes > 1 ? planes : win;                         // one group: its plane IS the window-score output
-    // the region top-k runs in the last window workgroup of each document unless the tile's LDS cannot hold the two score
-    // rows (or MM_TKL_REGION_KERNEL asks for the standalone launch of rounds 1-3)
-    fold_regions = !env().tkl_region_kernel && (size_t)(W < 3 ? 3 : W) * 8 <= lds2;
+    // The region top-k is its own launch (tkl_region_kernel) again since round 5.  Round 4 folded it into the last window
+    // workgroup of each document (MM_TKL_FOLD_REGIONS=1 still does, when the tile's LDS holds the two score rows).  Measured on
+    // one box, 256 documents, round-robin (profiles/r05_experiments/tkl_epilogue_orderings.txt):
+    //     standalone launch                                   0.1388 / 0.1396 ms
+    //     folded, round 4's relaxed counter + s_waitcnt       0.1413 / 0.1418     (correct on gfx950's sc1 path, not by the HIP model)
+    //     folded, acq_rel arrival by thread 0 (the default of the folded form: correct by the model)   0.1927 / 0.1914
+    //     folded, release / acquire fences in every thread    0.3367 / 0.3359
+    // A kernel boundary is the cheapest agent-scope release there is: the buffer_wbl2 an in-launch release needs costs more per
+    // workgroup (~1.7 us, MI355X_MICROARCH.md) than the 9.7 us launch it was meant to save, and even the unordered form was not
+    // faster than the launch.
+    fold_regions = env().tkl_fold_regions && (size_t)(W < 3 ? 3 : W) * 8 <= lds2;
     auto launch = [&](auto kern) {
       if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(kern, grid2, dim3(kWThreads), lds2, stream, (const float*)ps, (const int32_t*)slot2p, (const float*)emb, q_mask,

@@ -659,3 +659,28 @@ def test_tkl_region_tie_policy_classifier():
     cs = np.arange(1, 16, dtype=np.float64)
     assert abs(util.tkl_score_at(w, [20, 90, 150], cs) -
                sum(cs[i] * w[j] for i, j in enumerate([20, 90, 150, 19, 89, 149, 21, 91, 151, 18, 88, 148, 22, 92, 152]))) < 1e-12
+
+
+@pytest.mark.parametrize("groups,n_mq,n_md", [(1024, 3, 3), (2048, 3, 3), (7, 3, 3), (1, 1, 1), (33, 2, 4), (100, 4, 1), (2047, 3, 2)])
+def test_flat_xcd_grouped_multi_launch_covers_every_combination_once(groups, n_mq, n_md):
+    """Python mirror of kp_block_args' flat order (csrc/kp_device.h, round 5; grid from kp128_launch's flat_grid): workgroup g of
+    the multi launch (Conv-KNRM's n_mq x n_md match matrices) -> (pair range x, combination y = i * n_md + t).  Every (x, y)
+    exactly once; padding workgroups leave; and the n_mq workgroups that read the same pair range of the same DOCUMENT tensor
+    have ids congruent modulo 8 (same XCD under the observed b % 8 placement) within one window of 8 * n_mq ids."""
+    flat = (groups * n_md + 7) // 8 * 8
+    n_wg = flat * n_mq
+    period = 8 * n_mq
+    seen = np.zeros((groups, n_mq * n_md), dtype=np.int32)
+    readers = {}
+    for g in range(n_wg):
+        blk, r = divmod(g, period)
+        fr = blk * 8 + (r & 7)
+        x, t = divmod(fr, n_md)
+        y = (r >> 3) * n_md + t
+        if x >= groups:
+            continue                                   # block_x = 0x3fffffff: p0 >= n_pairs, the workgroup returns
+        seen[x, y] += 1
+        readers.setdefault((x, t), []).append(g)
+    assert seen.min() == 1 and seen.max() == 1
+    for ids in readers.values():
+        assert len(ids) == n_mq and len({g % 8 for g in ids}) == 1 and max(ids) - min(ids) < period

@@ -392,3 +392,51 @@ def test_candidate_lists_with_a_shared_query_equal_the_pair_per_row_call(E, ppq,
     ref = O.tk_kernel_pool(q[sel // ppq].numpy(), d[sel].numpy(), qm[sel].numpy(), dm.numpy(), MU, SIGMA, prm[2].numpy(), prm[3].numpy(),
                            dtype=np.float64)
     np.testing.assert_allclose(out[sel.to(dev)].cpu().numpy(), ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+def _multi_case(dev, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    B, Q, D, E, n = 9000, 30, 70, 128, 3
+    qs = [torch.relu(torch.randn(B, Q, E, generator=g)) for _ in range(n)]
+    ds = [torch.relu(torch.randn(B, D, E, generator=g)) for _ in range(n)]
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B,), generator=g)[:, None]).float()
+    dm = (torch.arange(D)[None] < torch.randint(0, D + 1, (B,), generator=g)[:, None]).float()
+    w = torch.randn(n * n, 11, generator=g) * 0.01
+    return qs, ds, qm, dm, w
+
+
+def _multi_run(path=None):
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    qs, ds, qm, dm, w = _multi_case(dev)
+    t = lambda x: x.to(dev)
+    got = ops.kernel_pool_multi([t(x) for x in qs], [t(x) for x in ds], t(qm), t(dm), t(torch.tensor(MU)), t(torch.tensor(SIGMA)),
+                                t(torch.ones(11)), t(w))
+    if path:
+        np.save(path, got.cpu().numpy())
+    return got
+
+
+def test_multi_launch_in_flat_xcd_order_with_two_wavefronts_per_simd(tmp_path):
+    """Conv-KNRM's 3 x 3 match matrices at a size where kp128_launch picks the round-5 form (>= 8,192 pairs, E = 128): flat
+    XCD-grouped workgroup order (kp_block_args) + two wavefronts per SIMD.  9,000 pairs vs the fp64 oracle; and BIT-EQUAL to
+    the form of rounds 1-4 (2-D grid, one wavefront per SIMD: MM_KP_MULTI_2D=1 MM_KP128_OCC=1 in a child process) — the order
+    in which workgroups run and the wavefronts per SIMD must not reach the arithmetic."""
+    import os, subprocess, sys
+    dev = util.require_gpu()
+    got = _multi_run()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "old_form.npy")
+    r = subprocess.run([sys.executable, "-c", f"from tests.test_kernel_pool_gpu import _multi_run; _multi_run({path!r})"], cwd=root,
+                       env=dict(os.environ, MM_KP_MULTI_2D="1", MM_KP128_OCC="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    old = np.load(path)
+    assert got.cpu().numpy().tobytes() == old.tobytes()
+    qs, ds, qm, dm, w = _multi_case(dev)
+    sample = np.arange(0, 9000, 9)                                   # every ninth pair against the oracle (1,000 pairs x 9 combinations)
+    ref = np.zeros(sample.size)
+    for i in range(3):
+        for j in range(3):
+            ref += O.tk_kernel_pool(qs[i][sample].numpy(), ds[j][sample].numpy(), qm[sample].numpy(), dm[sample].numpy(), MU, SIGMA,
+                                    np.ones(11, np.float32), w[i * 3 + j].numpy(), dtype=np.float64)
+    np.testing.assert_allclose(got.cpu().numpy()[sample], ref, atol=util.TOL_FP32, rtol=1e-5)

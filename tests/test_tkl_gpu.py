@@ -407,11 +407,11 @@ print("ACCEPTED")
     assert "ACCEPTED" not in r.stdout
 
 
-# ---- the folded region epilogue (csrc/tkl.hip: the last window workgroup of a document runs the region search) -------------
-# Cross-workgroup, cross-XCD hand-off through HBM: publish (agent-scope stores) -> release fence -> acq_rel arrival counter
-# -> acquire fence -> sum the planes.  A missing fence or a stale cached line would show as a score / window / peak that
-# differs from the standalone tkl_region_kernel (MM_TKL_REGION_KERNEL=1: a kernel boundary instead of the hand-off), that
-# changes between repeated calls, or that carries a value left in the workspace by the previous call.
+# ---- the region search: standalone launch (default since round 5) vs the folded epilogue (MM_TKL_FOLD_REGIONS=1: the last window
+# workgroup of a document runs it).  The folded form is a cross-workgroup, cross-XCD hand-off through HBM: publish (agent-scope
+# stores) -> workgroup barrier -> acq_rel arrival counter by thread 0 -> barrier -> sum the planes.  A missing ordering or a stale
+# cached line would show as a score / window / peak that differs from the standalone tkl_region_kernel (a kernel boundary instead
+# of the hand-off), that changes between repeated calls, or that carries a value left in the workspace by the previous call.
 
 def _epilogue_cases(dev):
     """(label, B, Q, D, E, sat, seed): config 3 at 1,024 documents; Q <= 10 (ONE token group: the window output buffer is
@@ -437,7 +437,7 @@ def _epilogue_inputs(dev, B, Q, D, E, sat, seed):
 
 
 def _epilogue_run_all(path=None):
-    """scores / windows / peaks of every case; `path`: save them (the child process under MM_TKL_REGION_KERNEL=1)."""
+    """scores / windows / peaks of every case; `path`: save them (the child process under MM_TKL_FOLD_REGIONS=1)."""
     from matchmaker_amd import ops
     dev = util.require_gpu()
     out = {}
@@ -457,20 +457,21 @@ def test_folded_region_epilogue_is_bit_equal_to_the_standalone_region_kernel(tmp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = str(tmp_path / "standalone.npz")
     r = subprocess.run([sys.executable, "-c", f"from tests.test_tkl_gpu import _epilogue_run_all; _epilogue_run_all({path!r})"], cwd=root,
-                       env=dict(os.environ, MM_TKL_REGION_KERNEL="1"), capture_output=True, text=True, timeout=900)
+                       env=dict(os.environ, MM_TKL_FOLD_REGIONS="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert not os.environ.get("MM_TKL_REGION_KERNEL"), "this process must run the folded (default) path"
-    alone = np.load(path)
-    folded = _epilogue_run_all()
-    assert set(alone.files) == set(folded)
-    for k in sorted(folded):
+    assert not os.environ.get("MM_TKL_FOLD_REGIONS"), "this process must run the default (standalone region kernel) path"
+    folded = np.load(path)
+    alone = _epilogue_run_all()
+    assert set(folded.files) == set(alone)
+    for k in sorted(alone):
         assert folded[k].shape == alone[k].shape and folded[k].tobytes() == alone[k].tobytes(), f"{k}: folded epilogue != standalone region kernel"
-    assert folded["config3_1024.score"].shape == (1024,) and np.isfinite(folded["config3_1024.score"]).all()
-    assert (folded["config3_1024.peaks"][:, 0] != folded["config3_1024.peaks"][:, 1]).all()
+    assert alone["config3_1024.score"].shape == (1024,) and np.isfinite(alone["config3_1024.score"]).all()
+    assert (alone["config3_1024.peaks"][:, 0] != alone["config3_1024.peaks"][:, 1]).all()
 
 
-def test_folded_region_epilogue_is_stable_under_repetition_concurrency_and_a_poisoned_workspace():
-    """200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI with a caller-owned workspace that is filled with NaN
+def test_tkl_forward_is_stable_under_repetition_concurrency_and_a_poisoned_workspace():
+    """(The default path; `MM_TKL_FOLD_REGIONS=1 pytest -k poisoned` runs the same against the folded epilogue.)
+    200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI with a caller-owned workspace that is filled with NaN
     bit patterns (0xFF) before every call — a plane, counter or slot-map entry read before this call wrote it shows up as a
     NaN or a changed bit — while a second stream keeps the headline MaxSim kernel running on all CUs (the window workgroups'
     placement over the XCDs and their arrival order change from call to call)."""
