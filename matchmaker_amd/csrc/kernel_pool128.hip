@@ -86,7 +86,7 @@ __device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint
 template <int NSL, int K, bool W, int KS, int MX = 0, int OCC = 1>
 __global__ void __launch_bounds__(64 * KS, OCC) kernel_pool_split128_kernel(const KpArgs a_in) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
-  static_assert(OCC == 1 || (OCC == 2 && KS == 1 && NSL <= 2 && !MX && !W), "two wavefronts per SIMD: plain pooling at E <= 128");
+  static_assert(OCC == 1 || (OCC == 2 && KS == 1 && NSL <= 2 && !W), "two wavefronts per SIMD: E <= 128, no gate");
   const KpArgs a = kp_block_args(a_in);
   static_assert(!MX || !W, "the fp32 MaxSim mode has no gate");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -424,12 +424,12 @@ bool kp128_maxsim_supported(int Q, int E) {
   return Q <= 32 && E % 64 == 0 && (nsl == 1 || nsl == 2 || nsl == 3 || nsl == 4 || nsl == 6 || nsl == 8 || nsl == 12);
 }
 
-template <int NSL, int KS, int MX>
+template <int NSL, int KS, int MX, int OCC = 1>
 static void launch_mx(const KpArgs& a, const dim3 grid, int lds, hipStream_t stream) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<NSL, 11, false, KS, MX>,
+    (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<NSL, 11, false, KS, MX, OCC>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, KS, MX>), grid, dim3(64 * KS), lds, stream, a);
+  hipLaunchKernelGGL((kernel_pool_split128_kernel<NSL, 11, false, KS, MX, OCC>), grid, dim3(64 * KS), lds, stream, a);
 }
 
 int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask dm, float* out, int64_t n_pairs,
@@ -439,14 +439,21 @@ int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask d
   a.Q = Q; a.D = D; a.E = E; a.d_doc_rows = D; a.clamp_min = 1e-10f;
   const int nsl = E / 64;
   const int ks = nsl > 6 ? 2 : 1;  // 512 / 768: two waves split the K axis (the query tile does not fit one wave)
-  const int lds = kp128_lds_fixed(ks);
-  int64_t groups = (int64_t)kCUs * 4 / ks;
+  // E <= 128: two wavefronts per SIMD (OCC = 2, see the kernel) when MM_KP128_OCC=2 asks for it (A/B; the default stays one)
+  const bool occ2 = nsl <= 2 && env().kp128_occ == 2 && n_pairs >= (int64_t)kCUs * 8 * 4;
+  const int lds = occ2 ? kp128_lds_fixed(1, 2) : kp128_lds_fixed(ks);
+  int64_t groups = occ2 ? (int64_t)kCUs * 8 : (int64_t)kCUs * 4 / ks;
   if (groups > a.n_pairs) groups = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
   groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
   const dim3 grid((unsigned)groups);
   const bool x3 = env().maxsim_f32_terms == 3;  // MM_MAXSIM_F32_TERMS=2: two-term split (operand error 2^-17) for A/B runs
 #define MM_MX(NSL, KS) (x3 ? launch_mx<NSL, KS, 2>(a, grid, lds, stream) : launch_mx<NSL, KS, 1>(a, grid, lds, stream))
+  if (occ2) {
+    if (nsl == 1) x3 ? launch_mx<1, 1, 2, 2>(a, grid, lds, stream) : launch_mx<1, 1, 1, 2>(a, grid, lds, stream);
+    else x3 ? launch_mx<2, 1, 2, 2>(a, grid, lds, stream) : launch_mx<2, 1, 1, 2>(a, grid, lds, stream);
+    return check_launch("kernel_pool_split128_kernel<maxsim, two wavefronts per SIMD>");
+  }
   switch (nsl) {
     case 1: MM_MX(1, 1); break;
     case 2: MM_MX(2, 1); break;
