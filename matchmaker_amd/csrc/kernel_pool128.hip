@@ -439,8 +439,11 @@ int kp128_maxsim_f32(const float* q, const float* d, PackedMask qm, PackedMask d
   a.Q = Q; a.D = D; a.E = E; a.d_doc_rows = D; a.clamp_min = 1e-10f;
   const int nsl = E / 64;
   const int ks = nsl > 6 ? 2 : 1;  // 512 / 768: two waves split the K axis (the query tile does not fit one wave)
-  // E <= 128: two wavefronts per SIMD (OCC = 2, see the kernel) when MM_KP128_OCC=2 asks for it (A/B; the default stays one)
-  const bool occ2 = nsl <= 2 && env().kp128_occ == 2 && n_pairs >= (int64_t)kCUs * 8 * 4;
+  // E <= 128: two wavefronts per SIMD (OCC = 2, see the kernel).  One wavefront per SIMD left its 6 (or 4) MFMAs per K step,
+  // the three-term operand split and the LDS-DMA waits in ONE dependent stream: 64 x 1000 pairs at Q32 / D180 / dim 128,
+  // same box, round-robin: 1.056 / 1.046 ms with one, 0.937 / 0.928 ms with two (0.70 -> 0.79 of the HBM peak;
+  // profiles/r05_experiments/maxsim_fp32_occ.txt).  MM_KP128_OCC=1 forces the old form.
+  const bool occ2 = nsl <= 2 && env().kp128_occ != 1 && n_pairs >= (int64_t)kCUs * 8 * 4;
   const int lds = occ2 ? kp128_lds_fixed(1, 2) : kp128_lds_fixed(ks);
   int64_t groups = occ2 ? (int64_t)kCUs * 8 : (int64_t)kCUs * 4 / ks;
   if (groups > a.n_pairs) groups = a.n_pairs;
