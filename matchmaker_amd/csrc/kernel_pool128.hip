@@ -83,14 +83,20 @@ __device__ __forceinline__ void mx_block(float (&m)[16], const f32x16& acc, uint
 // pair — a lone wavefront per SIMD spends more cycles between the blocks (scalar length / mask lookups with their waits, the
 // log pooling's eleven wave reductions, the store) than in them, and nothing else is resident to fill the gaps; a second
 // wavefront does.  E <= 128 only (the query fragments of wider rows need the whole register file).
-template <int NSL, int K, bool W, int KS, int MX = 0, int OCC = 1>
-__global__ void __launch_bounds__(64 * KS, OCC) kernel_pool_split128_kernel(const KpArgs a_in) {
+// MW > 1 (round 5): the workgroup holds up to MW INDEPENDENT wavefronts — the query tensors of a multi launch (KpArgs::m_flat
+// = 2) — each with its own ring, query tile and scores; they only meet at one s_barrier per block (a rate limiter, see
+// KpArgs).
+template <int NSL, int K, bool W, int KS, int MX = 0, int OCC = 1, int MW = 1>
+__global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel(const KpArgs a_in) {
   static_assert(KS == 1 || KS == 2, "one wave, or two waves splitting the K axis");
   static_assert(OCC == 1 || (OCC == 2 && KS == 1 && NSL <= 2 && !W), "two wavefronts per SIMD: E <= 128, no gate");
-  const KpArgs a = kp_block_args(a_in);
+  static_assert(MW == 1 || (KS == 1 && !W && !MX), "independent wavefronts per workgroup: the plain multi launch only");
+  const int wq = MW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const KpArgs a = kp_block_args(a_in, wq);
   static_assert(!MX || !W, "the fp32 MaxSim mode has no gate");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_wg[];
   constexpr int NBUF = OCC == 2 ? 2 : kS128Nbuf;
+  char* const smem = smem_wg + (MW == 1 ? 0 : wq * kp128_lds_fixed(1, NBUF));      // this wavefront's own LDS region
   const int lane = threadIdx.x & 63;
   const int wv = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 31, h = lane >> 5;
@@ -236,6 +242,9 @@ __global__ void __launch_bounds__(64 * KS, OCC) kernel_pool_split128_kernel(cons
     for (int i = 0; i < 16; ++i) mrun[i] = fill;
 
     for (int t = 0; t < nb; ++t) {
+      // the query-tensor wavefronts of a workgroup (MW > 1) enter every block together: same pairs, same lengths, same trip
+      // counts in all of them, so the barrier is reached by all or by none
+      if constexpr (MW > 1) __builtin_amdgcn_s_barrier();
       f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
       f32x2 ss2 = {0.0f, 0.0f};
 #pragma unroll
@@ -493,6 +502,27 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
     const int64_t flat = (groups * a.n_md + 7) / 8 * 8;               // (range, document tensor) slots, whole groups of 8
     return dim3((unsigned)(flat * (a.n_mblk / a.n_md)), 1u);
   };
+  if (occ2 && a.n_md > 0 && !env().kp_multi_2d && env().kp_multi_wg != 0) {
+    // one workgroup per (pair range, document tensor), its wavefronts = the query tensors (m_flat = 2).  Wavefront slots per
+    // CU: 8 (two per SIMD) in workgroups of n_mq -> 2 x 3 for Conv-KNRM's three n-gram widths
+    const int n_mq = a.n_mblk / a.n_md;
+    const int lds2 = n_mq * kp128_lds_fixed(1, 2);
+    int64_t groups = (int64_t)kCUs * (8 / n_mq) / a.n_md;
+    if (groups < 1) groups = 1;
+    if (groups > a.n_pairs) groups = a.n_pairs;
+    a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
+    groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+    a.m_flat = 2;
+    a.m_ranges = (int)groups;
+    const dim3 grid((unsigned)(groups * a.n_md));
+    if (lds2 > 64 * 1024) {
+      (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<1, 11, false, 1, 0, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+      (void)hipFuncSetAttribute((const void*)kernel_pool_split128_kernel<2, 11, false, 1, 0, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    }
+    if (nsl == 1) hipLaunchKernelGGL((kernel_pool_split128_kernel<1, 11, false, 1, 0, 2, 4>), grid, dim3(64 * n_mq), lds2, stream, a);
+    else hipLaunchKernelGGL((kernel_pool_split128_kernel<2, 11, false, 1, 0, 2, 4>), grid, dim3(64 * n_mq), lds2, stream, a);
+    return check_launch("kernel_pool_split128_kernel<one wavefront per query tensor>");
+  }
   if (occ2) {
     const int lds2 = kp128_lds_fixed(1, 2);
     int64_t groups = (int64_t)kCUs * per_cu;

@@ -69,17 +69,27 @@ struct KpArgs {
   // (workgroup b runs on XCD b % 8: observed, used for speed only), dispatched together — so the second and third reader of a
   // block find it in that XCD's L2 (a follower cannot overtake the leader without taking over its misses: the three stay
   // together).  m_ranges = pair ranges per combination (the 2-D grid's x extent); block_x = this workgroup's range.
+  // m_flat = 2 (round 5, the default of the E = 64n multi launch): ONE workgroup per (pair range, document tensor) whose
+  // n_mq wavefronts are the query tensors — each with its own ring and query tile, no shared state — and meet at an s_barrier
+  // once per 32-token block: a rate limiter that keeps the n_mq readers of a block within one block of each other, so all but
+  // the first find it in the L2 (in the flat order alone the three drifted apart: FETCH_SIZE 47 GB of the 2-D grid's 59).
   int m_flat;
   int m_ranges;
   int block_x;
 };
 
-__device__ __forceinline__ KpArgs kp_block_args(const KpArgs& a) {
+// wq: this wavefront's index in a workgroup of the m_flat = 2 form (0 otherwise)
+__device__ __forceinline__ KpArgs kp_block_args(const KpArgs& a, int wq = 0) {
   KpArgs b = a;
   b.block_x = (int)blockIdx.x;
   if (a.n_md > 0) {
     int y = blockIdx.y;
-    if (a.m_flat) {
+    if (a.m_flat == 2) {
+      const int fr = (int)blockIdx.x;                                // flat (pair range, document tensor)
+      const int x = fr / a.n_md, t = fr - x * a.n_md;
+      y = __builtin_amdgcn_readfirstlane(wq * a.n_md + t);
+      b.block_x = __builtin_amdgcn_readfirstlane(x);
+    } else if (a.m_flat) {
       const int n_mq = a.n_mblk / a.n_md, period = 8 * n_mq;
       const int g = (int)blockIdx.x, blk = g / period, r = g - blk * period;
       const int64_t fr = (int64_t)blk * 8 + (r & 7);                 // flat (pair range, document tensor)
