@@ -41,7 +41,7 @@ const EnvCfg& env() {
     c.tkl_fold_regions = env_int("MM_TKL_FOLD_REGIONS", 0);
     c.kp128_occ = env_int("MM_KP128_OCC", 0);
     c.kp_multi_2d = env_int("MM_KP_MULTI_2D", 0);
-    c.kp_multi_wg = env_int("MM_KP_MULTI_WG", 1);
+    c.kp_multi_wg = env_int("MM_KP_MULTI_WG", 0);
     c.kp_bwd_untiled = env_int("MM_KP_BWD_UNTILED", 0);
     c.kp_bwd_threads = env_int("MM_KP_BWD_THREADS", 1024);
     return c;

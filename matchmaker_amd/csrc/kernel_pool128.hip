@@ -502,7 +502,7 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
     const int64_t flat = (groups * a.n_md + 7) / 8 * 8;               // (range, document tensor) slots, whole groups of 8
     return dim3((unsigned)(flat * (a.n_mblk / a.n_md)), 1u);
   };
-  if (occ2 && a.n_md > 0 && !env().kp_multi_2d && env().kp_multi_wg != 0) {
+  if (occ2 && a.n_md > 0 && !env().kp_multi_2d && env().kp_multi_wg == 1) {
     // one workgroup per (pair range, document tensor), its wavefronts = the query tensors (m_flat = 2).  Wavefront slots per
     // CU: 8 (two per SIMD) in workgroups of n_mq -> 2 x 3 for Conv-KNRM's three n-gram widths
     const int n_mq = a.n_mblk / a.n_md;

@@ -69,10 +69,12 @@ struct KpArgs {
   // (workgroup b runs on XCD b % 8: observed, used for speed only), dispatched together — so the second and third reader of a
   // block find it in that XCD's L2 (a follower cannot overtake the leader without taking over its misses: the three stay
   // together).  m_ranges = pair ranges per combination (the 2-D grid's x extent); block_x = this workgroup's range.
-  // m_flat = 2 (round 5, the default of the E = 64n multi launch): ONE workgroup per (pair range, document tensor) whose
-  // n_mq wavefronts are the query tensors — each with its own ring and query tile, no shared state — and meet at an s_barrier
-  // once per 32-token block: a rate limiter that keeps the n_mq readers of a block within one block of each other, so all but
-  // the first find it in the L2 (in the flat order alone the three drifted apart: FETCH_SIZE 47 GB of the 2-D grid's 59).
+  // m_flat = 2 (round 5, MM_KP_MULTI_WG=1, A/B only): ONE workgroup per (pair range, document tensor) whose n_mq wavefronts
+  // are the query tensors — each with its own ring and query tile, no shared state — and meet at an s_barrier once per
+  // 32-token block: a rate limiter that keeps the n_mq readers of a block within one block of each other (in the flat order
+  // the three drift apart: FETCH_SIZE 47 GB of the 2-D grid's 59).  Bit-equal, and SLOWER than the flat order (9.19 vs 8.40 ms):
+  // workgroups of three wavefronts fill six of a CU's eight two-per-SIMD slots, and the launch is bound by the RBF
+  // evaluations, not by the bytes the barrier saves.
   int m_flat;
   int m_ranges;
   int block_x;

@@ -39,8 +39,9 @@ struct EnvCfg {
   int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
   int kp_bwd_threads = 1024; // MM_KP_BWD_THREADS: 1024 (when its LDS fits) | 512 threads per pair in kernel_pool_bwd_tiled_kernel (A/B runs)
   int kp_bwd_untiled = 0;   // MM_KP_BWD_UNTILED: pooling backward on the per-element kernel of rounds 1-3 (A/B runs)
-  int kp_multi_wg = 1;        // MM_KP_MULTI_WG=0: the multi launch as independent workgroups in flat XCD-grouped order instead of one workgroup per
-                              // (pair range, document tensor) with a wavefront per query tensor (A/B runs)
+  int kp_multi_wg = 0;        // MM_KP_MULTI_WG=1: the multi launch as one workgroup per (pair range, document tensor) with a wavefront per query
+                              // tensor and a rate barrier per block, instead of independent workgroups in flat XCD-grouped order (A/B runs:
+                              // measured SLOWER, 9.19 vs 8.40 ms for Conv-KNRM 3 x 3 — six wavefronts per CU instead of eight)
   int kp_multi_2d = 0;        // MM_KP_MULTI_2D=1: Conv-KNRM's multi launch on the 2-D grid of rounds 1-4 instead of the flat XCD-grouped order (A/B runs)
   int kp128_occ = 0;          // MM_KP128_OCC: 0 = choose by shape, 1 / 2 = wavefronts per SIMD of the 64n-wide pooling kernel (A/B runs)
   int tkl_fold_regions = 0;   // MM_TKL_FOLD_REGIONS=1: TKL's region top-k in the last window workgroup of each document (round 4's default) instead of
