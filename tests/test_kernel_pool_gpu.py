@@ -426,12 +426,14 @@ def test_multi_launch_in_flat_xcd_order_with_two_wavefronts_per_simd(tmp_path):
     dev = util.require_gpu()
     got = _multi_run()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = str(tmp_path / "old_form.npy")
-    r = subprocess.run([sys.executable, "-c", f"from tests.test_kernel_pool_gpu import _multi_run; _multi_run({path!r})"], cwd=root,
-                       env=dict(os.environ, MM_KP_MULTI_2D="1", MM_KP128_OCC="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    old = np.load(path)
-    assert got.cpu().numpy().tobytes() == old.tobytes()
+    # ... and to the wavefront-per-query-tensor workgroups with a rate barrier per block (MM_KP_MULTI_WG=1: built, measured
+    # slower, kept for A/B)
+    for name, env in (("old_form", {"MM_KP_MULTI_2D": "1", "MM_KP128_OCC": "1"}), ("wg_form", {"MM_KP_MULTI_WG": "1"})):
+        path = str(tmp_path / f"{name}.npy")
+        r = subprocess.run([sys.executable, "-c", f"from tests.test_kernel_pool_gpu import _multi_run; _multi_run({path!r})"], cwd=root,
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert got.cpu().numpy().tobytes() == np.load(path).tobytes(), name
     qs, ds, qm, dm, w = _multi_case(dev)
     sample = np.arange(0, 9000, 9)                                   # every ninth pair against the oracle (1,000 pairs x 9 combinations)
     ref = np.zeros(sample.size)
