@@ -1237,7 +1237,10 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   KpArgs a = a0;
   constexpr int NBUF = 3;
   const int lds = NBUF * kSliceBytes + 128 + (W ? 128 * ((a.D + 31) >> 5) : 0);
-  int64_t waves = (int64_t)kCUs * 4;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
+#ifndef MM_KP_WPC
+#define MM_KP_WPC 4            // -DMM_KP_WPC=2 / 3: fewer, longer wavefront streams (A/B builds, tools/build_variant.sh)
+#endif
+  int64_t waves = (int64_t)kCUs * MM_KP_WPC;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;

@@ -17,7 +17,7 @@ row in both).
 from typing import Optional
 
 import torch
-from torch import nn as nn
+from torch import nn
 
 from . import ops
 from .tk import _KernelPoolFn
