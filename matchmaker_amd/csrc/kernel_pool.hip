@@ -1235,12 +1235,18 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a_
 template <int K, bool TKL, bool W = false>
 static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   KpArgs a = a0;
-  constexpr int NBUF = 3;
-  const int lds = NBUF * kSliceBytes + 128 + (W ? 128 * ((a.D + 31) >> 5) : 0);
 #ifndef MM_KP_WPC
 #define MM_KP_WPC 4            // -DMM_KP_WPC=2 / 3: fewer, longer wavefront streams (A/B builds, tools/build_variant.sh)
 #endif
-  int64_t waves = (int64_t)kCUs * MM_KP_WPC;  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
+#ifndef MM_TKL_WPC             // the same two knobs for TKL's stage 1 alone (it is bound by its HBM stream, not by its wavefronts:
+#define MM_TKL_WPC MM_KP_WPC   // three per CU are as fast as four, profiles/r05_experiments/wavefronts_per_cu_tk_tkl.txt)
+#endif
+#ifndef MM_TKL_NBUF
+#define MM_TKL_NBUF 3
+#endif
+  constexpr int NBUF = TKL ? MM_TKL_NBUF : 3;
+  const int lds = NBUF * kSliceBytes + 128 + (W ? 128 * ((a.D + 31) >> 5) : 0);
+  int64_t waves = (int64_t)kCUs * (TKL ? MM_TKL_WPC : MM_KP_WPC);  // one wavefront per SIMD: the fp32 MFMA pipe is the co-limiter
   if (waves > a.n_pairs) waves = a.n_pairs;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
