@@ -68,6 +68,40 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+# ---- host plumbing: the C++ autograd node around the C ABI (csrc_host/mm_autograd.cpp) ------------------------------------
+HOST_SRC = os.path.join(HERE, "csrc_host", "mm_autograd.cpp")
+HOST_LIB = os.path.join(HERE, "csrc_host", "_mm_autograd.so")
+
+
+def build_host(force: bool = False, verbose: bool = True):
+    """g++ -> matchmaker_amd/csrc_host/_mm_autograd.so (a torch extension: needs torch's headers, ~30 s).  Optional: the
+    scoring path does not depend on it (matchmaker_amd/_fast.py falls back to the Python autograd.Function); returns the
+    path, or None when it could not be built."""
+    if not force and not _newer(HOST_LIB, [HOST_SRC, os.path.join(HERE, "..", "include", "mm_native.h")]):
+        if verbose:
+            print(f"[matchmaker_amd.build] kept {os.path.relpath(HOST_LIB, os.path.join(HERE, '..'))}", flush=True)
+        return HOST_LIB
+    try:
+        import sysconfig
+        import torch
+        from torch.utils import cpp_extension as ce
+        inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include", os.path.join(HERE, "..", "include")]
+        lib = ce.library_paths()[0]
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+               "-DTORCH_EXTENSION_NAME=_mm_autograd", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+               "-Wno-deprecated-declarations"] + [f"-I{p}" for p in inc] + \
+              [HOST_SRC, "-o", HOST_LIB, f"-L{lib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+               f"-Wl,-rpath,{lib}", "-ldl"]
+        if verbose:
+            print("[matchmaker_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return HOST_LIB
+    except Exception as e:      # no torch headers / no compiler: the Python node keeps working
+        print(f"[matchmaker_amd.build] host extension NOT built ({e!r}): the Python autograd.Function stays in use", flush=True)
+        return None
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    print(build_host(force="--force" in sys.argv))

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 from transformers import AutoModel, PretrainedConfig, PreTrainedModel
 
-from . import ops
+from . import _fast, ops
 
 
 class ColBERTConfig(PretrainedConfig):
@@ -108,7 +108,14 @@ class ColBERT(PreTrainedModel):
                 d = d.to(q.dtype)
             sim_round, sum_round = True, not ac
         if torch.is_grad_enabled() and (q.requires_grad or d.requires_grad):
-            score = _MaxSimFn.apply(q, d, query_mask, document_mask, sim_round, sum_round)
+            # the training step (train.py:347-348, :503-524).  Its node is C++ when the host extension is there and the rows
+            # need no padding (csrc_host/mm_autograd.cpp: at batch_size_train 32 x 2 the Python node's apply + backward were
+            # 2/3 of the step); the Python autograd.Function otherwise — the same two kernels, the same bits
+            fast = _fast.module()
+            if fast is not None and q.shape[-1] % 8 == 0 and q.dim() == 3:
+                score = fast.maxsim_paired(q, d, query_mask, document_mask, (1 if sim_round else 0) | (2 if sum_round else 0))
+            else:
+                score = _MaxSimFn.apply(q, d, query_mask, document_mask, sim_round, sum_round)
         else:
             score = ops.maxsim(q, d, query_mask, document_mask, 1, sim_round, sum_round)
         return score.to(q.dtype) if sum_round else score      # (16-bit tensors outside autocast: `sum` returns their dtype)

@@ -1,0 +1,161 @@
+// Host plumbing, not a kernel: the paired MaxSim (mm_maxsim_fwd / mm_maxsim_bwd) as a C++ torch::autograd::Function.
+//
+// Why: the reference trains with batch_size_train 32 x 2 = 64 pairs (config/train/defaults.yaml:114; train.py:347-348 forward,
+// :503-524 loss.backward()).  At that size the scoring block's kernels take ~45 us and the step took ~155 us: the rest was
+// Python — torch.autograd.Function.apply building the node, and the backward running as PYTHON on the autograd engine's
+// device thread (a thread hop that also has to take the GIL).  tools/host_step_profile.py: Function.apply path 28 us,
+// run_backward 45 us, of which the backward operator's own Python 20.  The same two C-ABI calls issued from a C++ node need
+// neither the interpreter nor the GIL in the backward.
+//
+// Boundary: this file talks to the scoring library only through include/mm_native.h (dlopen of the path the Python side
+// loaded, so that MM_NATIVE_LIB A/B builds are honoured) and to torch only for tensors, streams and the autograd graph.
+// matchmaker_amd/colbert.py uses it when it was built (matchmaker_amd/build.py) and the call is in its fast-path shape;
+// otherwise the Python autograd.Function (_MaxSimFn) runs — same kernels, same results (tests/test_colbert_dropin_gpu.py
+// compares the two bit for bit).  MM_MAXSIM_PY_AUTOGRAD=1 forces the Python node (A/B runs).
+#include <torch/extension.h>
+
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <dlfcn.h>
+
+#include <string>
+
+#include "mm_native.h"
+
+namespace {
+
+struct Api {
+  void* handle = nullptr;
+  decltype(&mm_maxsim_fwd) fwd = nullptr;
+  decltype(&mm_maxsim_bwd) bwd = nullptr;
+  decltype(&mm_maxsim_workspace_bytes) fwd_ws = nullptr;
+  decltype(&mm_maxsim_bwd_workspace_bytes) bwd_ws = nullptr;
+  decltype(&mm_last_error) last_error = nullptr;
+  decltype(&mm_abi_version) abi = nullptr;
+} api;
+
+void init(const std::string& lib_path) {
+  if (api.handle) return;
+  void* h = dlopen(lib_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  TORCH_CHECK(h, "mm_autograd: cannot load ", lib_path, ": ", dlerror());
+#define MM_SYM(field, name)                                        \
+  api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, #name)); \
+  TORCH_CHECK(api.field, "mm_autograd: ", lib_path, " does not export " #name)
+  MM_SYM(fwd, mm_maxsim_fwd);
+  MM_SYM(bwd, mm_maxsim_bwd);
+  MM_SYM(fwd_ws, mm_maxsim_workspace_bytes);
+  MM_SYM(bwd_ws, mm_maxsim_bwd_workspace_bytes);
+  MM_SYM(last_error, mm_last_error);
+  MM_SYM(abi, mm_abi_version);
+#undef MM_SYM
+  TORCH_CHECK(api.abi() == MM_ABI_VERSION, "mm_autograd: ", lib_path, " has ABI version ", api.abi(), ", built against ",
+              MM_ABI_VERSION);
+  api.handle = h;
+}
+
+int dtype_code(const at::Tensor& t) {
+  switch (t.scalar_type()) {
+    case at::kFloat: return MM_F32;
+    case at::kHalf: return MM_F16;
+    case at::kBFloat16: return MM_BF16;
+    default: TORCH_CHECK(false, "mm_autograd: unsupported dtype ", t.scalar_type());
+  }
+}
+
+// -> (pointer, kind) of a mask argument in the encodings of include/mm_native.h; `keep` holds a converted copy alive
+std::pair<const void*, int> mask_arg(const c10::optional<at::Tensor>& m, int64_t rows, int64_t L, at::Tensor& keep, const char* name) {
+  if (!m.has_value() || !m->defined()) return {nullptr, MM_MASK_NONE};
+  const at::Tensor& t = *m;
+  TORCH_CHECK(t.is_cuda(), "mm_autograd: ", name, " must be a device tensor");
+  if (t.dim() == 1) {
+    TORCH_CHECK(t.size(0) == rows, "mm_autograd: ", name, " has ", t.size(0), " lengths for ", rows, " rows");
+    keep = t.scalar_type() == at::kInt && t.is_contiguous() ? t : t.to(at::kInt).contiguous();
+    return {keep.data_ptr(), MM_MASK_LEN_I32};
+  }
+  TORCH_CHECK(t.dim() == 2 && t.size(0) == rows && t.size(1) == L, "mm_autograd: ", name, " must be [", rows, ", ", L, "]");
+  int kind;
+  keep = t;
+  switch (t.scalar_type()) {
+    case at::kLong: kind = MM_MASK_I64; break;
+    case at::kFloat: kind = MM_MASK_F32; break;
+    case at::kByte:
+    case at::kBool: kind = MM_MASK_U8; break;
+    default: keep = t.ne(0); kind = MM_MASK_U8;
+  }
+  if (!keep.is_contiguous()) keep = keep.contiguous();
+  return {keep.data_ptr(), kind};
+}
+
+void check_rc(int rc, const char* what) { TORCH_CHECK(rc == MM_OK, what, " failed (", rc, "): ", api.last_error()); }
+
+class MaxSimPaired : public torch::autograd::Function<MaxSimPaired> {
+ public:
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& q_in, const at::Tensor& d_in,
+                            const c10::optional<at::Tensor>& q_mask, const c10::optional<at::Tensor>& d_mask, int64_t flags) {
+    TORCH_CHECK(api.handle, "mm_autograd: init(lib_path) was not called");
+    TORCH_CHECK(q_in.is_cuda() && d_in.is_cuda() && q_in.device() == d_in.device(), "mm_autograd: q / d must be on one HIP device");
+    TORCH_CHECK(q_in.dim() == 3 && d_in.dim() == 3 && q_in.scalar_type() == d_in.scalar_type(), "mm_autograd: q / d: [rows, tokens, dim], same dtype");
+    const at::Tensor q = q_in.contiguous(), d = d_in.contiguous();
+    const int64_t B = d.size(0), Q = q.size(1), D = d.size(1), E = d.size(2);
+    TORCH_CHECK(q.size(0) == B && q.size(2) == E, "mm_autograd: pair-per-row layout: q ", q.sizes(), " vs d ", d.sizes());
+    const int dt = dtype_code(q);
+    TORCH_CHECK(E % (dt == MM_F32 ? 4 : 8) == 0, "mm_autograd: rows must be 16-byte multiples (the Python path pads other widths)");
+    at::Tensor qk, dk;
+    const auto qm = mask_arg(q_mask, B, Q, qk, "q_mask");
+    const auto dm = mask_arg(d_mask, B, D, dk, "d_mask");
+    at::Tensor out = at::empty({B}, q.options().dtype(at::kFloat));
+    if (B > 0) {
+      const c10::DeviceGuard guard(q.device());
+      const size_t wsb = api.fwd_ws(B, 1, (int)Q, (int)D, qm.second, dm.second);
+      at::Tensor ws = wsb ? at::empty({(int64_t)wsb}, q.options().dtype(at::kByte)) : at::Tensor();
+      void* stream = c10::hip::getCurrentHIPStream(q.device().index()).stream();
+      check_rc(api.fwd(q.data_ptr(), d.data_ptr(), qm.first, qm.second, dm.first, dm.second, out.data_ptr<float>(), B, 1, (int)Q,
+                       (int)D, (int)E, dt, (int)flags, wsb ? ws.data_ptr() : nullptr, wsb, stream),
+               "mm_maxsim_fwd");
+    }
+    // (nothing of the forward is saved but its inputs: the backward recomputes the similarities on the device)
+    ctx->save_for_backward({q, d, qk.defined() ? qk : at::Tensor(), dk.defined() ? dk : at::Tensor()});
+    ctx->saved_data["qkind"] = (int64_t)qm.second;
+    ctx->saved_data["dkind"] = (int64_t)dm.second;
+    return out;
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &q = saved[0], &d = saved[1], &qk = saved[2], &dk = saved[3];
+    const int qkind = (int)ctx->saved_data["qkind"].toInt(), dkind = (int)ctx->saved_data["dkind"].toInt();
+    const int64_t B = d.size(0), Q = q.size(1), D = d.size(1), E = d.size(2);
+    // gradients in the token vectors' own dtype, as the Python node asks for (grad_dtype = q.dtype): summed in fp32, rounded once
+    at::Tensor gq = at::empty_like(q), gd = at::empty_like(d);
+    if (B > 0) {
+      at::Tensor go = grads[0].reshape({-1});
+      if (go.scalar_type() != at::kFloat) go = go.to(at::kFloat);
+      go = go.contiguous();
+      TORCH_CHECK(go.numel() == B, "mm_autograd: grad_out has ", go.numel(), " elements for ", B, " pairs");
+      const c10::DeviceGuard guard(q.device());
+      const size_t wsb = api.bwd_ws(B, (int)Q, (int)D, qkind, dkind);
+      at::Tensor ws = wsb ? at::empty({(int64_t)wsb}, q.options().dtype(at::kByte)) : at::Tensor();
+      void* stream = c10::hip::getCurrentHIPStream(q.device().index()).stream();
+      const int dt = dtype_code(q);
+      check_rc(api.bwd(q.data_ptr(), d.data_ptr(), qk.defined() ? qk.data_ptr() : nullptr, qkind, dk.defined() ? dk.data_ptr() : nullptr,
+                       dkind, go.data_ptr<float>(), gq.data_ptr(), gd.data_ptr(), dt, B, (int)Q, (int)D, (int)E, dt,
+                       wsb ? ws.data_ptr() : nullptr, wsb, stream),
+               "mm_maxsim_bwd");
+    }
+    return {gq, gd, at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+at::Tensor maxsim_paired(const at::Tensor& q, const at::Tensor& d, const c10::optional<at::Tensor>& q_mask,
+                         const c10::optional<at::Tensor>& d_mask, int64_t flags) {
+  return MaxSimPaired::apply(q, d, q_mask, d_mask, flags);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "C++ autograd node around mm_maxsim_fwd / mm_maxsim_bwd (host plumbing; see the header of mm_autograd.cpp)";
+  m.def("init", &init, "dlopen the scoring library (path of libmm_native.so) and resolve the entry points");
+  m.def("maxsim_paired", &maxsim_paired, "paired MaxSim with a native autograd node", py::arg("q"), py::arg("d"), py::arg("q_mask"),
+        py::arg("d_mask"), py::arg("flags"));
+}

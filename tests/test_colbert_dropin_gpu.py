@@ -160,3 +160,46 @@ def test_graphed_evaluation_equals_eager_and_its_cache_is_bounded():
         want = m.forward({k: v.to(dev) for k, v in batches[2]["query_tokens"].items()},
                          {k: v.to(dev) for k, v in batches[2]["doc_tokens"].items()})
     assert torch.equal(outs[2], want)
+
+
+@pytest.mark.parametrize("dtype,mask_kind", [(torch.float16, "int64"), (torch.bfloat16, "float"), (torch.float32, "bool"),
+                                              (torch.float16, "lengths"), (torch.float16, "none")])
+def test_cpp_autograd_node_equals_the_python_node_bit_for_bit(dtype, mask_kind):
+    """matchmaker_amd/csrc_host/mm_autograd.cpp (the training step's node in C++: no Python in the backward) against
+    colbert._MaxSimFn (the Python autograd.Function): the same two C-ABI calls, so scores and both gradients must be
+    bit-equal — for every mask encoding the drop-in can be handed, through `ColBERT._score` as train.py drives it."""
+    from matchmaker_amd import _fast
+    from matchmaker_amd.colbert import ColBERT, _MaxSimFn
+    dev = util.require_gpu()
+    fast = _fast.module()
+    assert fast is not None, "the host extension is built by python -m matchmaker_amd.build / __graft_entry__.build()"
+    g = torch.Generator().manual_seed(11)
+    B, Q, D, E = 37, 32, 180, 128
+    q0 = torch.nn.functional.normalize(torch.randn(B, Q, E, generator=g), dim=-1).to(dtype).to(dev)
+    d0 = torch.nn.functional.normalize(torch.randn(B, D, E, generator=g), dim=-1).to(dtype).to(dev)
+    ql, dl = torch.randint(1, Q + 1, (B,), generator=g), torch.randint(1, D + 1, (B,), generator=g)
+    mk = {"int64": lambda L, n: (torch.arange(n)[None] < L[:, None]).long(), "float": lambda L, n: (torch.arange(n)[None] < L[:, None]).float(),
+          "bool": lambda L, n: (torch.arange(n)[None] < L[:, None]), "lengths": lambda L, n: L.to(torch.int32), "none": lambda L, n: None}[mask_kind]
+    qm, dm = mk(ql, Q), mk(dl, D)
+    qm, dm = (None if qm is None else qm.to(dev)), (None if dm is None else dm.to(dev))
+    go = torch.randn(B, generator=g).to(dev)
+    sim_round = dtype != torch.float32
+    res = []
+    for use_cpp in (True, False):
+        q, d = q0.clone().requires_grad_(True), d0.clone().requires_grad_(True)
+        s = fast.maxsim_paired(q, d, qm, dm, 1 if sim_round else 0) if use_cpp else _MaxSimFn.apply(q, d, qm, dm, sim_round, False)
+        assert s.requires_grad and s.dtype == torch.float32
+        s.backward(go)
+        res.append((s.detach(), q.grad, d.grad))
+    for a, b, name in zip(res[0], res[1], ("scores", "grad_q", "grad_d")):
+        assert a.dtype == b.dtype and torch.equal(a, b), name
+    assert res[0][1].dtype == dtype and float(res[0][2].float().abs().sum()) > 0
+    # ColBERT._score picks the C++ node by itself (grad enabled, 16-byte rows) and matches it
+    if mask_kind in ("int64", "float", "bool"):
+        q, d = q0.clone().requires_grad_(True), d0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=dtype == torch.float16):
+            sc = ColBERT._score(q, d, qm, dm)
+        assert "MaxSimPaired" in type(sc.grad_fn).__name__, type(sc.grad_fn).__name__
+        sc.backward(go)
+        if dtype == torch.float16:
+            assert torch.equal(sc.detach(), res[0][0]) and torch.equal(q.grad, res[0][1]) and torch.equal(d.grad, res[0][2])

@@ -684,3 +684,29 @@ def test_flat_xcd_grouped_multi_launch_covers_every_combination_once(groups, n_m
     assert seen.min() == 1 and seen.max() == 1
     for ids in readers.values():
         assert len(ids) == n_mq and len({g % 8 for g in ids}) == 1 and max(ids) - min(ids) < period
+
+
+def test_host_extension_builds_and_loads_against_this_torch():
+    """matchmaker_amd/csrc_host/_mm_autograd.so (the C++ autograd node, optional host plumbing): builds with g++ against the
+    installed torch, imports, resolves the C-ABI entry points of the library the ctypes binding loaded, and refuses CPU tensors
+    like every operator; MM_MAXSIM_PY_AUTOGRAD=1 switches it off (the Python node is the fallback)."""
+    import subprocess
+    import sys
+    from matchmaker_amd import build
+    so = build.build_host()
+    assert so and os.path.exists(so)
+    code = """
+import torch
+from matchmaker_amd import _fast
+m = _fast.module()
+print('MOD', m is not None)
+try:
+    m.maxsim_paired(torch.zeros(2, 3, 8), torch.zeros(2, 4, 8), None, None, 0)
+except RuntimeError as e:
+    print('REFUSED', 'HIP device' in str(e))
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert "MOD True" in r.stdout and "REFUSED True" in r.stdout, (r.stdout, r.stderr[-2000:])
+    r = subprocess.run([sys.executable, "-c", "from matchmaker_amd import _fast; print('MOD', _fast.module() is not None)"], cwd=ROOT,
+                       env=dict(os.environ, MM_MAXSIM_PY_AUTOGRAD="1"), capture_output=True, text=True, timeout=300)
+    assert "MOD False" in r.stdout, (r.stdout, r.stderr[-2000:])
