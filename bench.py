@@ -814,9 +814,8 @@ def extra_train_step(steps, cpu_budget):
                "backward_op_us": None if b_ms is None else 1e3 * b_ms,
                "backward_op_over_forward": None if b_ms is None else b_ms / f_ms,
                # device time of the step's kernels (forward + backward operator, each timed back to back) and what is left of
-               # the step: Python + autograd engine + launch gaps.  (The framework's share alone, ops stubbed out on a CPU:
-               # ~54 us per step — Function.apply 10, engine + graph teardown 26 + ... — so a 64-pair step cannot go below
-               # that without leaving torch.autograd.Function.)
+               # the step: Python + autograd engine + launch gaps.  (ColBERT's node is C++ since round 5, csrc_host/mm_autograd.cpp:
+               # with the Python autograd.Function the 64-pair step was ~150 us around ~45 us of kernels.)
                "kernel_us": None if b_ms is None else 1e3 * (f_ms + b_ms),
                "host_us": None if b_ms is None else max(0.0, 1e3 * (s_ms - f_ms - b_ms)),
                "algorithmic_bytes": by,
