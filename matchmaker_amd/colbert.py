@@ -107,15 +107,16 @@ class ColBERT(PreTrainedModel):
             if d.dtype is not q.dtype:
                 d = d.to(q.dtype)
             sim_round, sum_round = True, not ac
-        if torch.is_grad_enabled() and (q.requires_grad or d.requires_grad):
-            # the training step (train.py:347-348, :503-524).  Its node is C++ when the host extension is there and the rows
-            # need no padding (csrc_host/mm_autograd.cpp: at batch_size_train 32 x 2 the Python node's apply + backward were
-            # 2/3 of the step); the Python autograd.Function otherwise — the same two kernels, the same bits
-            fast = _fast.module()
-            if fast is not None and q.shape[-1] % 8 == 0 and q.dim() == 3:
-                score = fast.maxsim_paired(q, d, query_mask, document_mask, (1 if sim_round else 0) | (2 if sum_round else 0))
-            else:
-                score = _MaxSimFn.apply(q, d, query_mask, document_mask, sim_round, sum_round)
+        # The host extension (csrc_host/mm_autograd.cpp: the same C-ABI call from C++, with a C++ autograd node when a gradient
+        # is needed) takes the call whenever it was built and the rows need no padding: at batch_size_train 32 x 2 the Python
+        # node's apply + backward were 2/3 of the training step (train.py:347-348, :503-524: 147 -> 71 us), and eval.py's
+        # 512-pair calls are bound by the host too (ops.maxsim's Python: ~10 us around ~4 us of HBM time).  Otherwise the
+        # Python paths below — the same kernels, the same bits.
+        fast = _fast.module()
+        if fast is not None and q.is_cuda and q.dim() == 3 and d.dim() == 3 and q.shape[0] == d.shape[0] and q.shape[-1] % 8 == 0:
+            score = fast.maxsim_paired(q, d, query_mask, document_mask, (1 if sim_round else 0) | (2 if sum_round else 0))
+        elif torch.is_grad_enabled() and (q.requires_grad or d.requires_grad):
+            score = _MaxSimFn.apply(q, d, query_mask, document_mask, sim_round, sum_round)
         else:
             score = ops.maxsim(q, d, query_mask, document_mask, 1, sim_round, sum_round)
         return score.to(q.dtype) if sum_round else score      # (16-bit tensors outside autocast: `sum` returns their dtype)
