@@ -469,12 +469,9 @@ def test_folded_region_epilogue_is_bit_equal_to_the_standalone_region_kernel(tmp
     assert (alone["config3_1024.peaks"][:, 0] != alone["config3_1024.peaks"][:, 1]).all()
 
 
-def test_tkl_forward_is_stable_under_repetition_concurrency_and_a_poisoned_workspace():
-    """(The default path; `MM_TKL_FOLD_REGIONS=1 pytest -k poisoned` runs the same against the folded epilogue.)
-    200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI with a caller-owned workspace that is filled with NaN
-    bit patterns (0xFF) before every call — a plane, counter or slot-map entry read before this call wrote it shows up as a
-    NaN or a changed bit — while a second stream keeps the headline MaxSim kernel running on all CUs (the window workgroups'
-    placement over the XCDs and their arrival order change from call to call)."""
+def _stability_run():
+    """200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI, poisoned workspace, racing side stream; see the test."""
+
     from matchmaker_amd import ops, _lib, synth
     dev = util.require_gpu()
     L = _lib.lib()
@@ -509,3 +506,19 @@ def test_tkl_forward_is_stable_under_repetition_concurrency_and_a_poisoned_works
     torch.cuda.synchronize()
     assert not bad, f"calls that differ from the first one (call, scores, windows, peaks): {bad[:10]}"
     assert torch.isfinite(s0).all() and torch.isfinite(w0).all()
+    return True
+
+
+def test_tkl_forward_is_stable_under_repetition_concurrency_and_a_poisoned_workspace():
+    """Run for the default path (standalone region kernel) in this process and for the folded epilogue (MM_TKL_FOLD_REGIONS=1: the
+    cross-workgroup hand-off, where a missing ordering would show exactly here) in a child process.
+    200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI with a caller-owned workspace that is filled with NaN
+    bit patterns (0xFF) before every call — a plane, counter or slot-map entry read before this call wrote it shows up as a
+    NaN or a changed bit — while a second stream keeps the headline MaxSim kernel running on all CUs (the window workgroups'
+    placement over the XCDs and their arrival order change from call to call)."""
+    import os, subprocess, sys
+    assert _stability_run()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "from tests.test_tkl_gpu import _stability_run; print('STABLE', _stability_run())"], cwd=root,
+                       env=dict(os.environ, MM_TKL_FOLD_REGIONS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "STABLE True" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
