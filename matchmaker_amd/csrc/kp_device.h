@@ -72,7 +72,7 @@ struct KpArgs {
   // m_flat = 2 (round 5, MM_KP_MULTI_WG=1, A/B only): ONE workgroup per (pair range, document tensor) whose n_mq wavefronts
   // are the query tensors — each with its own ring and query tile, no shared state — and meet at an s_barrier once per
   // 32-token block: a rate limiter that keeps the n_mq readers of a block within one block of each other (in the flat order
-  // the three drift apart: FETCH_SIZE 47 GB of the 2-D grid's 59).  Bit-equal, and SLOWER than the flat order (9.19 vs 8.40 ms):
+  // the three drift apart: FETCH_SIZE 46.9 GB per launch against the 2-D grid's 49.9, 22.9 with the barrier).  Bit-equal, and SLOWER than the flat order (9.19 vs 8.40 ms):
   // workgroups of three wavefronts fill six of a CU's eight two-per-SIMD slots, and the launch is bound by the RBF
   // evaluations, not by the bytes the barrier saves.
   int m_flat;
