@@ -94,3 +94,53 @@ def test_full_record_goes_to_an_earlier_line_and_to_a_file(tmp_path):
     assert any(l.startswith("FULL_RECORD {") for l in out[:-1])
     full = json.loads(next(l for l in out if l.startswith("FULL_RECORD "))[len("FULL_RECORD "):])
     assert full["n_gpus"] == json.loads(out[-1])["n_gpus"] == 1
+
+
+def _hbm_fracs(o, path=""):
+    """every roofline object of the record whose bound is HBM -> (path, frac)"""
+    if isinstance(o, dict):
+        r = o.get("roofline")
+        if isinstance(r, dict) and r.get("bound") == "hbm" and isinstance(r.get("frac"), (int, float)):
+            yield path, r["frac"]
+        for k, v in o.items():
+            if k != "roofline":
+                yield from _hbm_fracs(v, path + "/" + k)
+
+
+def test_no_hbm_bound_leg_claims_more_than_the_box_streams():
+    """the variants leg divided PADDED bytes by the time of kernels that skip padded rows and printed
+    0.92-0.96 of the spec peak on a box whose calibrated stream was 0.82 of it.  Over the newest committed full record of
+    `python bench.py` (round 6 on): no HBM-bound `roofline.frac` may exceed calibrated_stream / 8000 by more than 3 %."""
+    import glob
+    import pytest
+    recs = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))
+            if int(os.path.basename(f)[1:3]) >= 6]
+    if not recs:
+        pytest.skip("no round-6 full record committed yet")
+    rec = json.load(open(recs[-1]))
+    cal = rec["roofline"]["calibrated_stream_GBps"] / 8000.0
+    fr = list(_hbm_fracs(rec.get("extra", {}), "extra")) + [("headline", rec["roofline"]["frac"])]
+    assert len(fr) >= 8
+    over = [(p, f) for p, f in fr if f > cal * 1.03]
+    assert not over, (cal, over)
+    v = rec["extra"]["variants"]
+    for name in ("knrm", "tk_sparse", "idcm_sampler_ck", "idcm_sampler_ck_small", "conv_knrm_3x3"):
+        r = v[name]["roofline"]
+        assert r["needed_bytes"] <= v[name]["algorithmic_bytes_padded"]
+        assert r["frac"] <= r["frac_padded_bytes"]
+
+
+def test_variants_leg_prices_needed_bytes_in_the_round5_record():
+    """the same rule applied to round 5's committed record with the corrected accounting: needed bytes / ms stays under the
+    box's calibrated stream for every variant (the record's own `frac` did not)"""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")))
+    cal = rec["roofline"]["calibrated_stream_GBps"]
+    bad = 0
+    for name, leg in rec["extra"]["variants"].items():
+        if not isinstance(leg, dict) or "ms" not in leg:
+            continue
+        need = leg["bytes_of_rows_below_the_document_lengths"] + (leg["algorithmic_bytes_padded"] - leg["pairs"] * leg["shape_QDE"][1]
+                                                                  * leg["shape_QDE"][2] * 4 * (3 if "conv" in name else 1))
+        assert need / (leg["ms"] * 1e-3) / 1e9 <= cal * 1.03, name
+        bad += leg["roofline"]["frac"] * 8000.0 > cal * 1.03
+    assert bad >= 3      # what round 5 printed: three legs above the stream
