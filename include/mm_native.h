@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3 /* 2: `flags` on the MaxSim forwards (the reference's 16-bit dtype flow); mm_tkl_fwd's ascending chunk_slot
+#define MM_ABI_VERSION 4 /* 4: mm_kernel_pool_ex_fwd2 / mm_kernel_pool_ex_bwd2 (the forward hands its pooled kernel sums to the backward).
+                          * 3: 2: `flags` on the MaxSim forwards (the reference's 16-bit dtype flow); mm_tkl_fwd's ascending chunk_slot
                             contract and workspace layout.  3: + mm_tkl_fwd_peaks (the region search's three peak indices) */
 
 /* element types of the embedding tensors */
@@ -209,6 +210,23 @@ int mm_kernel_pool_ex_fwd(const void* q, const void* d,
                           int Q, int D, int E, int K, int dtype,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* mm_kernel_pool_ex_fwd with one more optional output, for training (train.py:347-348 forward, :503-524 backward):
+ *   pooled [n_pairs, Q, K] float32 or NULL: the pooled kernel sums pkq[i][k] = sum_j mask_j gate_j exp(-(cos_ij - mu_k)^2 / (2 sigma_k^2))
+ *   (ecai20_tk.py:120, before kernel_alpha_scaler / clamp / log), one row per query token.  Every position of the document
+ *   enters each of them, so the backward cannot form a gradient before it has them; handed to mm_kernel_pool_ex_bwd2 they
+ *   save its pooling pre-pass — the document's second trip through HBM.  Rows of padded / masked query tokens are unspecified. */
+int mm_kernel_pool_ex_fwd2(const void* q, const void* d,
+                           const void* q_mask, int q_mask_kind,
+                           const void* d_mask, int d_mask_kind,
+                           const float* d_gate,
+                           const int32_t* pair_query, int64_t n_queries,
+                           const float* mu, const float* sigma, const float* alpha, const float* w,
+                           float clamp_min,
+                           float* out, float* per_kernel, float* pooled,
+                           int64_t n_pairs, int64_t pairs_per_query,
+                           int Q, int D, int E, int K, int dtype,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Several (query tensor, document tensor) combinations pooled in ONE launch and summed: Conv-KNRM scores every
  * n-gram width of the query against every n-gram width of the document (n_grams^2 match matrices,
  * matchmaker/models/conv_knrm.py:130-132) and its dense layer (:137) is a weighted sum over all of them:
@@ -254,6 +272,20 @@ int mm_kernel_pool_ex_bwd(const void* q, const void* d,
                           float* grad_alpha, float* grad_w,
                           int64_t n_pairs, int Q, int D, int E, int K,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* mm_kernel_pool_ex_bwd with the forward's pooled kernel sums: pooled [n_pairs, Q, K] as written by mm_kernel_pool_ex_fwd2 on
+ * the SAME inputs, or NULL (then the backward pools them itself first and needs the workspace
+ * mm_kernel_pool_bwd_workspace_bytes reports).  Same gradients either way (the sums are the same arithmetic). */
+int mm_kernel_pool_ex_bwd2(const void* q, const void* d,
+                           const void* q_mask, int q_mask_kind,
+                           const void* d_mask, int d_mask_kind,
+                           const float* d_gate,
+                           const float* mu, const float* sigma, const float* alpha, const float* w,
+                           float clamp_min, const float* pooled,
+                           const float* grad_out, float* grad_q, float* grad_d, float* grad_gate,
+                           float* grad_alpha, float* grad_w,
+                           int64_t n_pairs, int Q, int D, int E, int K,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * TKL: match + RBF kernels per document position, sliding-window (30, stride 2) pooling with

@@ -13,7 +13,7 @@ MM_F32, MM_F16, MM_BF16 = 0, 1, 2
 MASK_NONE, MASK_LEN_I32, MASK_U8, MASK_I64, MASK_F32 = 0, 1, 2, 3, 4
 TKL_SAT_EMBEDDING, TKL_SAT_LOG = 0, 1
 SIM_ROUND, SUM_ROUND = 1, 2          # MM_SIM_ROUND / MM_SUM_ROUND
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c = ctypes
 _vp, _i64, _i, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
@@ -36,6 +36,10 @@ SIGNATURES = {
                                 _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_ex_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _c.c_float, _vp, _vp, _i64, _i64,
                                    _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_kernel_pool_ex_fwd2": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _c.c_float, _vp, _vp, _vp, _i64, _i64,
+                                    _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_kernel_pool_ex_bwd2": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _c.c_float, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_ex_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _c.c_float, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_tkl_bwd_workspace_bytes": (_sz, [_i64, _i]),

@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
         pk[k] = pk2[k >> 1][k & 1];
         pk[k] += __shfl_xor(pk[k], 32, 64);
       }
-      finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
+      finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1);
     }
   }
 }
@@ -731,14 +731,14 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
         for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
         redist_reduce<K>(pk, np, lane);
         const bool count = rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u);
-        finish_pool<K>(a, pair, pk, count, lane, rbf);
+        finish_pool<K>(a, pair, pk, count, lane, rbf, rsub == 0 ? rtk : -1);
       } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           pk[k] = pk2[k >> 1][k & 1];
           pk[k] += __shfl_xor(pk[k], 32, 64);
         }
-        finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
+        finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1);
       }
     }
   }
@@ -1215,6 +1215,7 @@ __global__ void __launch_bounds__(64) kernel_pool_generic_kernel(const KpArgs a_
       if (k < nk) {
         const float pkk = pk2[k >> 1][k & 1];
         const float v = pkk + __shfl_xor(pkk, 32, 64);
+        if (a.pooled && h == 0 && qtok < Q) a.pooled[(pair * Q + qtok) * nk + k] = v;
         float lg = __logf(fmaxf(v * rbf.alpha[k], a.clamp_min));
         tot[k] += wave_sum((qvalid && h == 0) ? lg : 0.0f);
       }
@@ -1371,6 +1372,17 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
                                      const float* sigma, const float* alpha, const float* w, float clamp_min, float* out,
                                      float* per_kernel, int64_t n_pairs, int64_t pairs_per_query, int Q, int D, int E,
                                      int K, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  return mm_kernel_pool_ex_fwd2(q, d, q_mask, q_mask_kind, d_mask, d_mask_kind, d_gate, pair_query, n_queries, mu, sigma, alpha, w,
+                                clamp_min, out, per_kernel, nullptr, n_pairs, pairs_per_query, Q, D, E, K, dtype, workspace,
+                                workspace_bytes, stream_);
+}
+
+extern "C" int mm_kernel_pool_ex_fwd2(const void* q, const void* d, const void* q_mask, int q_mask_kind,
+                                      const void* d_mask, int d_mask_kind, const float* d_gate,
+                                      const int32_t* pair_query, int64_t n_queries, const float* mu,
+                                      const float* sigma, const float* alpha, const float* w, float clamp_min, float* out,
+                                      float* per_kernel, float* pooled, int64_t n_pairs, int64_t pairs_per_query, int Q, int D,
+                                      int E, int K, int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!q || !d || !out || !mu || !sigma || !alpha || !w) return set_error(MM_EINVAL, "kernel_pool: null pointer");
   if (dtype != MM_F32)
@@ -1385,7 +1397,7 @@ extern "C" int mm_kernel_pool_ex_fwd(const void* q, const void* d, const void* q
   if (n_pairs == 0) return MM_OK;
   KpArgs a{};
   a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w;
-  a.out = out; a.per_kernel = per_kernel; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
+  a.out = out; a.per_kernel = per_kernel; a.pooled = pooled; a.n_pairs = n_pairs; a.ppq = pairs_per_query;
   a.Q = Q; a.D = D; a.E = E; a.K = K;
   a.d_doc_rows = D; a.d_row0 = 0;
   a.dw = d_gate; a.clamp_min = clamp_min; a.pair_q = pair_query;

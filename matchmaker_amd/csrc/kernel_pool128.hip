@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
 #pragma unroll
       for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
       redist_reduce<K>(pk, np, lane);
-      finish_pool<K>(a, pair, pk, rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u), lane, rbf);
+      finish_pool<K>(a, pair, pk, rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u), lane, rbf, rsub == 0 ? rtk : -1);
       continue;
     }
 #pragma unroll
@@ -397,12 +397,12 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
       pk[k] += __shfl_xor(pk[k], 32, 64);
     }
     if constexpr (KS == 1) {
-      finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
+      finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1);
     } else {
       static_assert(K > 6, "wave 1 pools kernels 6..K-1");
       // each wave pools the kernels it evaluated; wave 1 hands its weighted partial to wave 0
-      const float part = wv == 0 ? pool_partial<K, 0, 6>(a, pair, pk, qvalid && lane < 32, lane, rbf)
-                                 : pool_partial<K, 6, K>(a, pair, pk, qvalid && lane < 32, lane, rbf);
+      const float part = wv == 0 ? pool_partial<K, 0, 6>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1)
+                                 : pool_partial<K, 6, K>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1);
       if (wv == 1 && lane == 0) xtot[p_toggle * 4] = part;
       __syncthreads();
       if (wv == 0 && lane == 0) a.out[pair] = part + xtot[p_toggle * 4];

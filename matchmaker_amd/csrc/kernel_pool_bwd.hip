@@ -23,37 +23,9 @@
 // and width (the [Q,D] tiles are swept DT positions at a time): what matters there is that loss.backward() stays on the
 // device without a [B,Q,D,K] tensor.  Pair-per-row layout (the one train.py feeds: neuralIR_encoder.py:86-87).
 #include "mm_internal.h"
+#include "kp_bwd.h"
 
 namespace mm {
-
-constexpr int kBK = 32;  // max kernels
-
-struct KpBwdArgs {
-  const float* q;
-  const float* d;
-  PackedMask qm, dm;
-  const float* mu;
-  const float* sigma;
-  const float* alpha;
-  const float* w;
-  const float* go;
-  const float* dw;  // optional gate [n_pairs, D]
-  float* gdw;       // optional grad of the gate [n_pairs, D]
-  float clamp_min;
-  float* gq;
-  float* gd;
-  float* galpha;  // [n_pairs, K]
-  float* gw;      // [n_pairs, K]
-  int64_t n_pairs;
-  int Q, D, E, K;
-};
-
-__device__ __forceinline__ bool mask_bit(const PackedMask& m, int64_t row, int words, int pos, int L) {
-  int len = m.len ? m.len[row] : L;
-  if (pos >= len) return false;
-  if (m.bits) return (m.bits[row * words + (pos >> 5)] >> (pos & 31)) & 1u;
-  return true;
-}
 
 // LDS: cosine + gradient tiles [Q][DT] (DT document positions at a time) + per-pair vectors.  Documents longer than
 // one tile (max_doc_length 2000 in tk.yaml-style training configs) take two sweeps over their tiles: the first pools
@@ -284,7 +256,6 @@ __host__ __device__ inline size_t kp_bwd_tiled_lds_bytes(int Q, int E, int Dpad,
           5 * 32 + 4 * kTK + (nthr / 128) * 1024) * 4;
 }
 
-__device__ __forceinline__ constexpr int mrow(int i) { return (i & 3) + 8 * (i >> 2); }   // C/D layout of the 32x32 MFMA: acc[i] of lane l = row mrow(i) + 4 (l >> 5), column l & 31
 
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
@@ -709,16 +680,19 @@ __global__ void __launch_bounds__(NTHR) kernel_pool_bwd_tiled_kernel(const KpBwd
 
 using namespace mm;
 
+// masks as the kernels read them + the pooled kernel sums [n_pairs, Q, K <= 16] the split kernel's pooling pre-pass hands to its
+// gradient pass (kernel_pool_bwd_split.hip; unused when the caller passes the forward's sums, mm_kernel_pool_ex_bwd2)
 extern "C" size_t mm_kernel_pool_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind) {
-  return packed_mask_bytes(q_mask_kind, n_pairs, Q) + packed_mask_bytes(d_mask_kind, n_pairs, D);
+  const size_t masks = packed_mask_bytes(q_mask_kind, n_pairs, Q) + packed_mask_bytes(d_mask_kind, n_pairs, D);
+  return ((masks + 255) & ~(size_t)255) + kp_bwd_split_ws_bytes(n_pairs, Q, 16);
 }
 
-extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
-                                     int d_mask_kind, const float* d_gate, const float* mu, const float* sigma,
-                                     const float* alpha, const float* w, float clamp_min, const float* grad_out,
-                                     float* grad_q, float* grad_d, float* grad_gate, float* grad_alpha, float* grad_w,
-                                     int64_t n_pairs, int Q, int D, int E, int K, void* workspace, size_t workspace_bytes,
-                                     void* stream_) {
+extern "C" int mm_kernel_pool_ex_bwd2(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
+                                      int d_mask_kind, const float* d_gate, const float* mu, const float* sigma,
+                                      const float* alpha, const float* w, float clamp_min, const float* pooled,
+                                      const float* grad_out, float* grad_q, float* grad_d, float* grad_gate, float* grad_alpha,
+                                      float* grad_w, int64_t n_pairs, int Q, int D, int E, int K, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!q || !d || !mu || !sigma || !alpha || !w || !grad_out || !grad_q || !grad_d || !grad_alpha || !grad_w)
     return set_error(MM_EINVAL, "kernel_pool_bwd: null pointer");
@@ -728,7 +702,29 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
   if (K > kBK) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: K=%d kernels (max %d)", K, kBK);
   if (n_pairs == 0) return MM_OK;
   if (n_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "kernel_pool_bwd: too many pairs for one launch");
-  // the tiled kernel whenever its tiles fit (every shape the reference's configs train at); the per-element kernel otherwise
+  // The split-bf16 streaming kernel (kernel_pool_bwd_split.hip) for every shape the reference's configs train at (Q <= 32,
+  // 11 kernels, E <= 384); MM_KP_BWD_F32=1 keeps the exact-f32 tiled kernel below as its parity twin (A/B runs).
+  if (kp_bwd_split_supported(Q, E, K) && !env().kp_bwd_f32 && !env().kp_bwd_untiled &&
+      !(((uintptr_t)q | (uintptr_t)d | (uintptr_t)grad_q | (uintptr_t)grad_d) & 15)) {
+    KpBwdArgs a{};
+    a.q = (const float*)q; a.d = (const float*)d; a.mu = mu; a.sigma = sigma; a.alpha = alpha; a.w = w; a.go = grad_out;
+    a.dw = d_gate; a.gdw = grad_gate; a.clamp_min = clamp_min;
+    a.gq = grad_q; a.gd = grad_d; a.galpha = grad_alpha; a.gw = grad_w; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E; a.K = K;
+    char* ws = (char*)workspace;
+    size_t left = workspace ? workspace_bytes : 0;
+    if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
+    if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+    float* pkq_ws = nullptr;
+    if (!pooled) {
+      const size_t skip = (size_t)(-(intptr_t)ws) & 255, need = kp_bwd_split_ws_bytes(n_pairs, Q, K);
+      if (left < skip + need)
+        return set_error(MM_EINVAL, "kernel_pool_bwd: workspace too small for the pooled sums (%zu bytes left, %zu needed; "
+                                    "mm_kernel_pool_bwd_workspace_bytes)", left, skip + need);
+      pkq_ws = (float*)(ws + skip);
+    }
+    return kp_bwd_split_launch(a, pooled, pkq_ws, stream);
+  }
+  // the exact-f32 tiled kernel whenever its tiles fit; the per-element kernel otherwise
   {
     const int Dpad = (D + 31) & ~31;
     const int nthr = (env().kp_bwd_threads == 1024 && kp_bwd_tiled_lds_bytes(Q, E, Dpad, 1024) <= 150 * 1024) ? 1024 : 512;
@@ -781,6 +777,17 @@ extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q
     (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kernel_pool_bwd_kernel, dim3((unsigned)n_pairs), dim3(256), lds, stream, a, DT);
   return check_launch("kernel_pool_bwd_kernel");
+}
+
+extern "C" int mm_kernel_pool_ex_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
+                                     int d_mask_kind, const float* d_gate, const float* mu, const float* sigma,
+                                     const float* alpha, const float* w, float clamp_min, const float* grad_out,
+                                     float* grad_q, float* grad_d, float* grad_gate, float* grad_alpha, float* grad_w,
+                                     int64_t n_pairs, int Q, int D, int E, int K, void* workspace, size_t workspace_bytes,
+                                     void* stream_) {
+  return mm_kernel_pool_ex_bwd2(q, d, q_mask, q_mask_kind, d_mask, d_mask_kind, d_gate, mu, sigma, alpha, w, clamp_min, nullptr,
+                                grad_out, grad_q, grad_d, grad_gate, grad_alpha, grad_w, n_pairs, Q, D, E, K, workspace,
+                                workspace_bytes, stream_);
 }
 
 extern "C" int mm_kernel_pool_bwd(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,

@@ -16,6 +16,10 @@ struct KpArgs {
   const float* w;
   float* out;
   float* per_kernel;  // optional [n_pairs, K]
+  // optional [n_pairs, Q, K]: the pooled kernel sums pkq[i][k] BEFORE alpha / clamp / log (ecai20_tk.py:120), one row per query
+  // token — what the backward needs before it can form any gradient (mm_kernel_pool_ex_bwd2: saves its pooling pre-pass, i.e. the
+  // second trip of the document through HBM).  Rows of padded / masked query tokens may stay unwritten (the backward never reads them).
+  float* pooled;
   int64_t n_pairs;
   int64_t ppq;
   int Q, D, E, K;
@@ -383,9 +387,15 @@ __device__ __forceinline__ void redist_reduce(float (&pk)[kMaxK], int np, int la
 
 // log-sum pooling of one pair over kernels K0..K1-1: pk[k] (this lane's query token, both halves already
 // combined); writes per_kernel, returns sum_k w_k * pooled_k (wave-uniform).
+// tok: the query token whose sums this lane holds (-1: a lane that holds a copy or nothing) — only used to hand the sums out
 template <int K, int K0 = 0, int K1 = K>
 __device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool count_lane,
-                                              int lane, const Rbf& rbf) {
+                                              int lane, const Rbf& rbf, int tok) {
+  if (a.pooled && tok >= 0 && tok < a.Q) {
+    float* dst = a.pooled + (pair * a.Q + tok) * K;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) dst[k] = pk[k];
+  }
   float total = 0.0f;
 #pragma unroll
   for (int k = K0; k < K1; ++k) {
@@ -400,8 +410,8 @@ __device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, con
 
 template <int K>
 __device__ __forceinline__ void finish_pool(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool count_lane,
-                                            int lane, const Rbf& rbf) {
-  const float total = pool_partial<K>(a, pair, pk, count_lane, lane, rbf);
+                                            int lane, const Rbf& rbf, int tok) {
+  const float total = pool_partial<K>(a, pair, pk, count_lane, lane, rbf, tok);
   if (lane == 0) a.out[pair] = total;
 }
 

@@ -356,7 +356,7 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
                 mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor,
                 pairs_per_query: int = 1, return_per_kernel: bool = False,
                 d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10,
-                pair_query: Optional[torch.Tensor] = None):
+                pair_query: Optional[torch.Tensor] = None, return_pooled: bool = False):
     """TK kernel pooling (matchmaker/models/published/ecai20_tk.py:105-124).
 
     q [n_queries, Q, E], d [n_pairs, D, E] float32 contextualised embeddings; mu/sigma/alpha/w [K].
@@ -364,7 +364,9 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     clamp_min: floor inside the log (1e-4: IDCM sampler, sigir21_idcm.py:185);
     pair_query [n_pairs] int (optional): row of q each pair scores against (ragged groups; replaces
     pairs_per_query; equal neighbours reuse the query tile).
-    Returns float32 [n_pairs] (and per_kernel [n_pairs, K] when asked)."""
+    Returns float32 [n_pairs] (and per_kernel [n_pairs, K] when asked; and, with return_pooled, the pooled kernel sums
+    [n_pairs, Q, K] of :120 as the LAST element — what kernel_pool_bwd(pooled=...) takes to skip its pooling pre-pass; rows of
+    padded query tokens are unspecified)."""
     dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate, pair_query)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != torch.float32 or d.dtype != torch.float32:
@@ -397,21 +399,26 @@ def kernel_pool(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor]
     L = _lib.lib()
     out = torch.empty(B, dtype=torch.float32, device=dev)
     pk = torch.empty((B, K), dtype=torch.float32, device=dev) if return_per_kernel else None
+    pooled = torch.empty((B, Q, K), dtype=torch.float32, device=dev) if return_pooled else None
     if B:
         q, d, E = _pad_rows(q, d, 4)
         with _on(dev):
             wsb = _ws_bytes(L.mm_kernel_pool_workspace_bytes, max(B, nq), 1 if pq is not None else pairs_per_query, Q, D, qk, dk)
             st = _stream(dev)
             ws = _workspace(dev, wsb, st)
-            rc = L.mm_kernel_pool_ex_fwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
-                                         gate.data_ptr() if gate is not None else None,
-                                         pq.data_ptr() if pq is not None else None, nq, mu.data_ptr(),
-                                         sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
-                                         out.data_ptr(), pk.data_ptr() if pk is not None else None, B,
-                                         pairs_per_query, Q, D, E, K, _lib.MM_F32,
-                                         ws.data_ptr() if ws is not None else None, wsb, st)
-        _lib.check(rc, "mm_kernel_pool_ex_fwd")
-    return (out, pk) if return_per_kernel else out
+            rc = L.mm_kernel_pool_ex_fwd2(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
+                                          gate.data_ptr() if gate is not None else None,
+                                          pq.data_ptr() if pq is not None else None, nq, mu.data_ptr(),
+                                          sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
+                                          out.data_ptr(), pk.data_ptr() if pk is not None else None,
+                                          pooled.data_ptr() if pooled is not None else None, B,
+                                          pairs_per_query, Q, D, E, K, _lib.MM_F32,
+                                          ws.data_ptr() if ws is not None else None, wsb, st)
+        _lib.check(rc, "mm_kernel_pool_ex_fwd2")
+    res = (out, pk) if return_per_kernel else (out,)
+    if return_pooled:
+        res = res + (pooled,)
+    return res if len(res) > 1 else out
 
 
 def kernel_pool_multi(q_list, d_list, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor], mu: torch.Tensor,
@@ -471,11 +478,12 @@ def _gate(d_gate, B, D):
 
 def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor], d_mask: Optional[torch.Tensor],
                     mu: torch.Tensor, sigma: torch.Tensor, alpha: torch.Tensor, w: torch.Tensor, grad_out: torch.Tensor,
-                    d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10):
-    """Backward of kernel_pool in the pair-per-row layout (mm_kernel_pool_ex_bwd).  Returns float32
+                    d_gate: Optional[torch.Tensor] = None, clamp_min: float = 1e-10, pooled: Optional[torch.Tensor] = None):
+    """Backward of kernel_pool in the pair-per-row layout (mm_kernel_pool_ex_bwd2).  Returns float32
     (grad_q [B,Q,E], grad_d [B,D,E], grad_alpha [K], grad_w [K]) and, with d_gate, grad_gate [B,D] as a
-    fifth element."""
-    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, grad_out, d_gate)
+    fifth element.  pooled [B,Q,K]: the forward's pooled kernel sums (kernel_pool(..., return_pooled=True) on the same inputs);
+    without them the backward pools them itself first (the document crosses HBM twice)."""
+    dev = _dev_check(q, d, q_mask, d_mask, mu, sigma, alpha, w, grad_out, d_gate, pooled)
     q, d = _emb(q, "q"), _emb(d, "d")
     if q.dtype != torch.float32 or d.dtype != torch.float32:
         raise NativeError("kernel_pool_bwd: float32 embeddings only")
@@ -500,17 +508,22 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
     gw = torch.zeros((B, K), dtype=torch.float32, device=dev)
     gate = _gate(d_gate, B, D)
     gg = torch.zeros((B, D), dtype=torch.float32, device=dev) if gate is not None else None
+    if pooled is not None:
+        if pooled.dtype != torch.float32 or tuple(pooled.shape) != (B, Q, K):
+            raise NativeError(f"pooled has shape {tuple(pooled.shape)} / {pooled.dtype}, expected float32 {(B, Q, K)}")
+        pooled = pooled.detach().contiguous()
     if B:
         with torch.cuda.device(dev):
             wsb = L.mm_kernel_pool_bwd_workspace_bytes(B, Q, D, qk, dk)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-            rc = L.mm_kernel_pool_ex_bwd(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
-                                         gate.data_ptr() if gate is not None else None, mu.data_ptr(),
-                                         sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
-                                         go.data_ptr(), gq.data_ptr(), gd.data_ptr(),
-                                         gg.data_ptr() if gg is not None else None, ga.data_ptr(), gw.data_ptr(),
-                                         B, Q, D, E, K, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
-        _lib.check(rc, "mm_kernel_pool_ex_bwd")
+            rc = L.mm_kernel_pool_ex_bwd2(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
+                                          gate.data_ptr() if gate is not None else None, mu.data_ptr(),
+                                          sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), float(clamp_min),
+                                          pooled.data_ptr() if pooled is not None else None,
+                                          go.data_ptr(), gq.data_ptr(), gd.data_ptr(),
+                                          gg.data_ptr() if gg is not None else None, ga.data_ptr(), gw.data_ptr(),
+                                          B, Q, D, E, K, ws.data_ptr() if ws is not None else None, wsb, _stream(dev))
+        _lib.check(rc, "mm_kernel_pool_ex_bwd2")
     if E != E0:
         gq, gd = gq[..., :E0].contiguous(), gd[..., :E0].contiguous()
     if gate is not None:

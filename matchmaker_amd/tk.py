@@ -28,20 +28,27 @@ def sinusoid_positions(dim: int, length: int, min_timescale: float = 1.0, max_ti
 
 
 class _KernelPoolFn(torch.autograd.Function):
-    """Native forward (mm_kernel_pool_ex_fwd) and native backward (mm_kernel_pool_ex_bwd) of the pooling
+    """Native forward (mm_kernel_pool_ex_fwd2) and native backward (mm_kernel_pool_ex_bwd2) of the pooling
     block for the training path (train.py:347-348 / :503-524).  gate / clamp_min: the TK-Sparse and IDCM
-    variants (ops.kernel_pool)."""
+    variants (ops.kernel_pool).  The forward hands its pooled kernel sums (ecai20_tk.py:120, [B, Q, K]: 880 bytes per pair at
+    Q = 20) to the backward, which then reads the documents once instead of twice."""
 
     @staticmethod
     def forward(ctx, q, d, q_mask, d_mask, mu, sigma, alpha, w, gate=None, clamp_min=1e-10):
-        ctx.save_for_backward(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate)
         ctx.clamp_min = clamp_min
-        return ops.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate=gate, clamp_min=clamp_min)
+        if any(ctx.needs_input_grad) and q.shape[0] == d.shape[0]:
+            out, pooled = ops.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate=gate, clamp_min=clamp_min, return_pooled=True)
+        else:
+            out, pooled = ops.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, d_gate=gate, clamp_min=clamp_min), None
+        ctx.has_pooled = pooled is not None
+        ctx.save_for_backward(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate, pooled)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        q, d, q_mask, d_mask, mu, sigma, alpha, w, gate = ctx.saved_tensors
-        r = ops.kernel_pool_bwd(q, d, q_mask, d_mask, mu, sigma, alpha, w, g, d_gate=gate, clamp_min=ctx.clamp_min)
+        q, d, q_mask, d_mask, mu, sigma, alpha, w, gate, pooled = ctx.saved_tensors
+        r = ops.kernel_pool_bwd(q, d, q_mask, d_mask, mu, sigma, alpha, w, g, d_gate=gate, clamp_min=ctx.clamp_min,
+                                pooled=pooled if ctx.has_pooled else None)
         gq, gd, ga, gw = r[:4]
         gg = r[4].view_as(gate) if gate is not None else None
         return gq, gd, None, None, None, None, ga.view_as(alpha), gw.view_as(w), gg, None

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(L, name), name
-    assert L.mm_abi_version() == 3 == _lib.ABI_VERSION
+    assert L.mm_abi_version() == 4 == _lib.ABI_VERSION
     # size queries are pure host arithmetic: callable without a GPU
     assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_NONE, _lib.MASK_LEN_I32) == 0
     assert L.mm_maxsim_workspace_bytes(10, 1, 32, 180, _lib.MASK_I64, _lib.MASK_I64) > 0
@@ -48,7 +48,7 @@ def test_header_is_plain_c_and_a_c_client_links_the_library(tmp_path):
 #include <string.h>
 #include "mm_native.h"
 int main(void) {
-  if (mm_abi_version() != MM_ABI_VERSION || MM_ABI_VERSION != 3) return 1;
+  if (mm_abi_version() != MM_ABI_VERSION || MM_ABI_VERSION != 4) return 1;
   if (mm_tkl_fwd_peaks(NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 4, 100, 52, 20, 300, 11, MM_TKL_SAT_EMBEDDING, NULL, 0, NULL) != MM_EINVAL) return 6;
   if (mm_maxsim_workspace_bytes(10, 1, 32, 180, MM_MASK_I64, MM_MASK_I64) == 0) return 2;
   if (mm_tkl_workspace_bytes(4, 100, 52, 20, 11) == 0) return 3;
