@@ -161,9 +161,12 @@ def test_kernel_pool_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
                                              alpha.to(dev), w.to(dev), go.to(dev), pooled=pooled)
     assert torch.equal(leaves[0].grad, gq2) and torch.equal(leaves[1].grad, gd2)
     np.testing.assert_allclose(leaves[3].grad.cpu().numpy(), gw2.cpu().numpy(), atol=1e-6)
+    # (the two paths may sit on different forward kernels — E = 8 pools on the generic exact-f32 kernel, the pre-pass always on
+    # split-bf16 cosines — and the sigma = 1e-3 exact-match kernel turns a 2^-18 cosine difference into 4e-3 of its activation:
+    # both are held to the fp64 gradients below, and to each other at twice that bound)
     for got, want in ((gq2, gq), (gd2, gd), (ga2, ga), (gw2, gw)):
         scale = max(1.0, float(want.abs().max()))
-        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5 * scale, rtol=1e-3)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=4e-4 * scale, rtol=4e-3)
     for got, want, name in ((gq2, r64[0], "grad_q"), (gd2, r64[1], "grad_d"), (ga2, r64[2], "grad_alpha"), (gw2, r64[3], "grad_w")):
         want = want.numpy()
         scale = max(1.0, float(np.abs(want).max()))
