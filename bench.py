@@ -817,7 +817,7 @@ def extra_train_step(steps, cpu_budget):
     dev = torch.device("cuda", torch.cuda.current_device())
     res = {}
 
-    def leg(name, B, fwd, step_native, step_eager, fwd_bytes, grad_bytes, n_timed, bwd_op=None):
+    def leg(name, B, fwd, step_native, step_eager, fwd_bytes, grad_bytes, n_timed, bwd_op=None, fwd_bytes_padded=None):
         with torch.no_grad():
             f_ms = gpu_time_ms(fwd, n_timed)
             b_ms = gpu_time_ms(bwd_op, n_timed) if bwd_op is not None else None
@@ -836,6 +836,8 @@ def extra_train_step(steps, cpu_budget):
                "algorithmic_bytes": by,
                "roofline": {"bound": "hbm", "achieved": by / (s_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if fwd_bytes_padded is not None:     # the kernels skip the 32-row blocks past a document's length: `frac` prices the rows they need
+            row["roofline"]["frac_padded_bytes"] = (2 * fwd_bytes_padded + grad_bytes) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         try:
             if LEAN:
                 raise RuntimeError("skipped (--lean: the profiled run holds the native kernels only)")
@@ -901,8 +903,18 @@ def extra_train_step(steps, cpu_budget):
         def t_eager():
             zero()
             TP.tk_kernel_pool(tq, td, tqm, tdm, mu.view(1, 1, 1, -1), sg.view(1, 1, 1, -1), al.view(1, 1, -1), w.view(1, -1)).backward(go)
-        leg("tk_pooling_q20_d200_e300", B, t_fwd, t_native, t_eager, B * ((Dt + Qt) * Et * 4 + 4 * (Dt + Qt) + 4),
-            B * (Dt + Qt) * Et * 4 + 2 * B * 11 * 4, steps, bwd_op=lambda: ops.kernel_pool_bwd(tq, td, tqm, tdm, mu, sg, al, w, go))
+        # The backward operator as the step runs it: with the forward's pooled kernel sums (mm_kernel_pool_ex_fwd2 -> _ex_bwd2).
+        # Bytes: forward and backward each read the 32-row blocks below a document's length (the kernels skip the rest), the
+        # backward writes EVERY gradient row (zeros past the length).
+        with torch.no_grad():
+            pooled = ops.kernel_pool(tq, td, tqm, tdm, mu, sg, al, w, return_pooled=True)[1]
+        rows = int((((tdm.sum(1).long() + 31) // 32) * 32).clamp(max=Dt).sum())
+        small = B * (Qt * Et * 4 + 4 * (Dt + Qt) + 4)
+        leg("tk_pooling_q20_d200_e300", B, t_fwd, t_native, t_eager, rows * Et * 4 + small,
+            B * (Dt + Qt) * Et * 4 + 2 * B * 11 * 4, steps,
+            bwd_op=lambda: ops.kernel_pool_bwd(tq, td, tqm, tdm, mu, sg, al, w, go, pooled=pooled),
+            fwd_bytes_padded=B * Dt * Et * 4 + small)
+        del pooled
         del tq, td
         torch.cuda.empty_cache()
 

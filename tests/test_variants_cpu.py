@@ -72,7 +72,8 @@ def _oracle_kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, clamp_min=1e-
     n = lambda t: t.detach().cpu().numpy()
     s = O.idcm_sampler_scores(n(q), n(d), n(q_mask), n(d_mask), n(mu).reshape(-1), n(sigma).reshape(-1),
                               n(alpha).reshape(-1), n(w).reshape(-1), 0.0)
-    return torch.from_numpy(s.astype(np.float32))
+    s = torch.from_numpy(s.astype(np.float32))
+    return (s, None) if kw.get("return_pooled") else s      # (the training node asks for the pooled sums; the stand-in has none)
 
 
 @pytest.mark.parametrize("fname,ctx_kind", [("idcm_ck.npz", "ck"), ("idcm_ck_small.npz", "ck-small")])
