@@ -812,7 +812,7 @@ def extra_train_step(steps, cpu_budget):
     from oracle import torch_port as TP
     from matchmaker_amd import ops, synth
     from matchmaker_amd.colbert import ColBERT
-    from matchmaker_amd.tk import _KernelPoolFn
+    from matchmaker_amd.tk import kernel_pool_train
     from matchmaker_amd.tkl import TKL_sigir20, _TKLScoreFn, chunk_documents
     dev = torch.device("cuda", torch.cuda.current_device())
     res = {}
@@ -898,7 +898,7 @@ def extra_train_step(steps, cpu_budget):
 
         def t_native():
             zero()
-            _KernelPoolFn.apply(tq, td, tqm, tdm, mu, sg, al, w).backward(go)
+            kernel_pool_train(tq, td, tqm, tdm, mu, sg, al, w).backward(go)      # (the C++ node when the host extension is built)
 
         def t_eager():
             zero()

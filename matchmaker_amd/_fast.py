@@ -26,6 +26,11 @@ def module():
             m = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(m)
             _lib.lib()                      # the scoring library itself must load (fails loudly if it is missing)
+            # the artefact ships with the snapshot: under a torch other than the one it was compiled against its autograd-context
+            # layout may differ — refuse it BEFORE the first call (matchmaker_amd.build rebuilds on the same mismatch)
+            built = m.built_torch_version() if hasattr(m, "built_torch_version") else None
+            if built != torch.__version__.split("+")[0]:
+                raise RuntimeError(f"built against torch {built}, running under {torch.__version__}")
             m.init(_lib.LIB_PATH)
             _mod = m
         except Exception as e:              # built against another torch, ...: keep the Python node, say so once

@@ -77,7 +77,14 @@ def build_host(force: bool = False, verbose: bool = True):
     """g++ -> matchmaker_amd/csrc_host/_mm_autograd.so (a torch extension: needs torch's headers, ~30 s).  Optional: the
     scoring path does not depend on it (matchmaker_amd/_fast.py falls back to the Python autograd.Function); returns the
     path, or None when it could not be built."""
-    if not force and not _newer(HOST_LIB, [HOST_SRC, os.path.join(HERE, "..", "include", "mm_native.h")]):
+    stamp = HOST_LIB + ".torch"
+    try:
+        import torch as _t
+        cur = _t.__version__
+    except Exception:
+        cur = None
+    same_torch = os.path.exists(stamp) and open(stamp).read().strip() == str(cur)
+    if not force and same_torch and not _newer(HOST_LIB, [HOST_SRC, os.path.join(HERE, "..", "include", "mm_native.h")]):
         if verbose:
             print(f"[matchmaker_amd.build] kept {os.path.relpath(HOST_LIB, os.path.join(HERE, '..'))}", flush=True)
         return HOST_LIB
@@ -95,6 +102,8 @@ def build_host(force: bool = False, verbose: bool = True):
         if verbose:
             print("[matchmaker_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        with open(stamp, "w") as f:      # the torch it was compiled against (a snapshot may land beside another one: rebuild then)
+            f.write(torch.__version__)
         return HOST_LIB
     except Exception as e:      # no torch headers / no compiler: the Python node keeps working
         print(f"[matchmaker_amd.build] host extension NOT built ({e!r}): the Python autograd.Function stays in use", flush=True)

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import ops
 from .knrm import kernel_mus
-from .tk import _KernelPoolFn
+from .tk import kernel_pool_train
 
 
 def kernel_sigmas(n_kernels: int):
@@ -76,7 +76,7 @@ class Conv_KNRM(nn.Module):
                 for dg in d_grams:
                     wb = w[block * K:(block + 1) * K]
                     if needs_grad:
-                        s = _KernelPoolFn.apply(qg, dg, qm.float(), dm.float(), mu, sigma, self._ones, wb)
+                        s = kernel_pool_train(qg, dg, qm.float(), dm.float(), mu, sigma, self._ones, wb)
                     else:
                         s = ops.kernel_pool(qg, dg, qm, dm, mu, sigma, self._ones, wb)
                     score = s if score is None else score + s

@@ -1,4 +1,5 @@
-// Host plumbing, not a kernel: the paired MaxSim (mm_maxsim_fwd / mm_maxsim_bwd) as a C++ torch::autograd::Function.
+// Host plumbing, not a kernel: the paired MaxSim (mm_maxsim_fwd / mm_maxsim_bwd) and the TK kernel pooling
+// (mm_kernel_pool_ex_fwd2 / mm_kernel_pool_ex_bwd2) as C++ torch::autograd::Functions.
 //
 // Why: the reference trains with batch_size_train 32 x 2 = 64 pairs (config/train/defaults.yaml:114; train.py:347-348 forward,
 // :503-524 loss.backward()).  At that size the scoring block's kernels take ~45 us and the step took ~155 us: the rest was
@@ -30,6 +31,10 @@ struct Api {
   decltype(&mm_maxsim_bwd) bwd = nullptr;
   decltype(&mm_maxsim_workspace_bytes) fwd_ws = nullptr;
   decltype(&mm_maxsim_bwd_workspace_bytes) bwd_ws = nullptr;
+  decltype(&mm_kernel_pool_ex_fwd2) kp_fwd = nullptr;
+  decltype(&mm_kernel_pool_ex_bwd2) kp_bwd = nullptr;
+  decltype(&mm_kernel_pool_workspace_bytes) kp_fwd_ws = nullptr;
+  decltype(&mm_kernel_pool_bwd_workspace_bytes) kp_bwd_ws = nullptr;
   decltype(&mm_last_error) last_error = nullptr;
   decltype(&mm_abi_version) abi = nullptr;
 } api;
@@ -45,6 +50,10 @@ void init(const std::string& lib_path) {
   MM_SYM(bwd, mm_maxsim_bwd);
   MM_SYM(fwd_ws, mm_maxsim_workspace_bytes);
   MM_SYM(bwd_ws, mm_maxsim_bwd_workspace_bytes);
+  MM_SYM(kp_fwd, mm_kernel_pool_ex_fwd2);
+  MM_SYM(kp_bwd, mm_kernel_pool_ex_bwd2);
+  MM_SYM(kp_fwd_ws, mm_kernel_pool_workspace_bytes);
+  MM_SYM(kp_bwd_ws, mm_kernel_pool_bwd_workspace_bytes);
   MM_SYM(last_error, mm_last_error);
   MM_SYM(abi, mm_abi_version);
 #undef MM_SYM
@@ -63,10 +72,12 @@ int dtype_code(const at::Tensor& t) {
 }
 
 // -> (pointer, kind) of a mask argument in the encodings of include/mm_native.h; `keep` holds a converted copy alive
-std::pair<const void*, int> mask_arg(const c10::optional<at::Tensor>& m, int64_t rows, int64_t L, at::Tensor& keep, const char* name) {
+std::pair<const void*, int> mask_arg(const c10::optional<at::Tensor>& m, int64_t rows, int64_t L, at::Tensor& keep, const char* name,
+                                     const at::Device& dev) {
   if (!m.has_value() || !m->defined()) return {nullptr, MM_MASK_NONE};
   const at::Tensor& t = *m;
-  TORCH_CHECK(t.is_cuda(), "mm_autograd: ", name, " must be a device tensor");
+  // (a mask on ANOTHER device — DataParallel misuse — would hand the kernel a pointer it cannot read: ops._dev_check's rule)
+  TORCH_CHECK(t.is_cuda() && t.device() == dev, "mm_autograd: ", name, " must be on the vectors' device (", dev, "), got ", t.device());
   if (t.dim() == 1) {
     TORCH_CHECK(t.size(0) == rows, "mm_autograd: ", name, " has ", t.size(0), " lengths for ", rows, " rows");
     keep = t.scalar_type() == at::kInt && t.is_contiguous() ? t : t.to(at::kInt).contiguous();
@@ -101,8 +112,8 @@ class MaxSimPaired : public torch::autograd::Function<MaxSimPaired> {
     const int dt = dtype_code(q);
     TORCH_CHECK(E % (dt == MM_F32 ? 4 : 8) == 0, "mm_autograd: rows must be 16-byte multiples (the Python path pads other widths)");
     at::Tensor qk, dk;
-    const auto qm = mask_arg(q_mask, B, Q, qk, "q_mask");
-    const auto dm = mask_arg(d_mask, B, D, dk, "d_mask");
+    const auto qm = mask_arg(q_mask, B, Q, qk, "q_mask", q.device());
+    const auto dm = mask_arg(d_mask, B, D, dk, "d_mask", q.device());
     at::Tensor out = at::empty({B}, q.options().dtype(at::kFloat));
     if (B > 0) {
       const c10::DeviceGuard guard(q.device());
@@ -129,6 +140,7 @@ class MaxSimPaired : public torch::autograd::Function<MaxSimPaired> {
     at::Tensor gq = at::empty_like(q), gd = at::empty_like(d);
     if (B > 0) {
       at::Tensor go = grads[0].reshape({-1});
+      TORCH_CHECK(go.device() == q.device(), "mm_autograd: grad_out on ", go.device(), ", the vectors on ", q.device());
       if (go.scalar_type() != at::kFloat) go = go.to(at::kFloat);
       go = go.contiguous();
       TORCH_CHECK(go.numel() == B, "mm_autograd: grad_out has ", go.numel(), " elements for ", B, " pairs");
@@ -151,11 +163,122 @@ at::Tensor maxsim_paired(const at::Tensor& q, const at::Tensor& d, const c10::op
   return MaxSimPaired::apply(q, d, q_mask, d_mask, flags);
 }
 
+// TK kernel pooling in the pair-per-row layout (ecai20_tk.py:105-124 through mm_kernel_pool_ex_fwd2; train.py:347-348 forward,
+// :503-524 backward).  At batch_size_train 32 x 2 the step was 242 us of which 94 were the Python node.
+// The forward hands its pooled kernel sums to the backward (one trip of the documents through HBM instead of two).
+at::Tensor vec_f32(const at::Tensor& t, int64_t K, const char* name, const at::Device& dev) {
+  TORCH_CHECK(t.device() == dev, "mm_autograd: ", name, " on ", t.device(), ", the embeddings on ", dev);
+  at::Tensor v = t.reshape({-1});
+  if (v.scalar_type() != at::kFloat) v = v.to(at::kFloat);
+  v = v.contiguous();
+  TORCH_CHECK(v.numel() == K, "mm_autograd: ", name, " has ", v.numel(), " elements for ", K, " kernels");
+  return v;
+}
+
+class KernelPool : public torch::autograd::Function<KernelPool> {
+ public:
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& q_in, const at::Tensor& d_in,
+                            const c10::optional<at::Tensor>& q_mask, const c10::optional<at::Tensor>& d_mask, const at::Tensor& mu_in,
+                            const at::Tensor& sigma_in, const at::Tensor& alpha_in, const at::Tensor& w_in,
+                            const c10::optional<at::Tensor>& gate_in, double clamp_min) {
+    TORCH_CHECK(api.handle, "mm_autograd: init(lib_path) was not called");
+    TORCH_CHECK(q_in.is_cuda() && d_in.is_cuda() && q_in.device() == d_in.device(), "mm_autograd: q / d must be on one HIP device");
+    TORCH_CHECK(q_in.dim() == 3 && d_in.dim() == 3 && q_in.scalar_type() == at::kFloat && d_in.scalar_type() == at::kFloat,
+                "mm_autograd: kernel pooling takes float32 [rows, tokens, dim] embeddings (tk.yaml use_fp16: False)");
+    const at::Tensor q = q_in.contiguous(), d = d_in.contiguous();
+    const int64_t B = d.size(0), Q = q.size(1), D = d.size(1), E = d.size(2), K = mu_in.numel();
+    TORCH_CHECK(q.size(0) == B && q.size(2) == E, "mm_autograd: pair-per-row layout: q ", q.sizes(), " vs d ", d.sizes());
+    TORCH_CHECK(E % 4 == 0, "mm_autograd: rows must be 16-byte multiples (the Python path pads other widths)");
+    const at::Device dev = q.device();
+    const at::Tensor mu = vec_f32(mu_in, K, "mu", dev), sigma = vec_f32(sigma_in, K, "sigma", dev), alpha = vec_f32(alpha_in, K, "alpha", dev),
+                     w = vec_f32(w_in, K, "w", dev);
+    at::Tensor gate;
+    if (gate_in.has_value() && gate_in->defined()) {
+      TORCH_CHECK(gate_in->device() == dev, "mm_autograd: d_gate on ", gate_in->device(), ", the embeddings on ", dev);
+      gate = gate_in->reshape({B, -1}).to(at::kFloat).contiguous();
+      TORCH_CHECK(gate.size(1) == D, "mm_autograd: d_gate has shape ", gate_in->sizes(), " for ", B, " documents of ", D, " tokens");
+    }
+    at::Tensor qk, dk;
+    const auto qm = mask_arg(q_mask, B, Q, qk, "q_mask", dev);
+    const auto dm = mask_arg(d_mask, B, D, dk, "d_mask", dev);
+    at::Tensor out = at::empty({B}, q.options());
+    at::Tensor pooled = at::empty({B, Q, K}, q.options());
+    if (B > 0) {
+      const c10::DeviceGuard guard(dev);
+      const size_t wsb = api.kp_fwd_ws(B, 1, (int)Q, (int)D, qm.second, dm.second);
+      at::Tensor ws = wsb ? at::empty({(int64_t)wsb}, q.options().dtype(at::kByte)) : at::Tensor();
+      void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+      check_rc(api.kp_fwd(q.data_ptr(), d.data_ptr(), qm.first, qm.second, dm.first, dm.second, gate.defined() ? gate.data_ptr<float>() : nullptr,
+                          nullptr, 0, mu.data_ptr<float>(), sigma.data_ptr<float>(), alpha.data_ptr<float>(), w.data_ptr<float>(),
+                          (float)clamp_min, out.data_ptr<float>(), nullptr, pooled.data_ptr<float>(), B, 1, (int)Q, (int)D, (int)E, (int)K,
+                          MM_F32, wsb ? ws.data_ptr() : nullptr, wsb, stream),
+               "mm_kernel_pool_ex_fwd2");
+    }
+    ctx->save_for_backward({q, d, qk.defined() ? qk : at::Tensor(), dk.defined() ? dk : at::Tensor(), mu, sigma, alpha, w,
+                            gate.defined() ? gate : at::Tensor(), pooled});
+    ctx->saved_data["qkind"] = (int64_t)qm.second;
+    ctx->saved_data["dkind"] = (int64_t)dm.second;
+    ctx->saved_data["clamp"] = clamp_min;
+    ctx->saved_data["alpha_shape"] = alpha_in.sizes().vec();
+    ctx->saved_data["w_shape"] = w_in.sizes().vec();
+    ctx->saved_data["gate_shape"] = gate.defined() ? gate_in->sizes().vec() : std::vector<int64_t>{};
+    return out;
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &q = saved[0], &d = saved[1], &qk = saved[2], &dk = saved[3], &mu = saved[4], &sigma = saved[5], &alpha = saved[6],
+                     &w = saved[7], &gate = saved[8], &pooled = saved[9];
+    const int qkind = (int)ctx->saved_data["qkind"].toInt(), dkind = (int)ctx->saved_data["dkind"].toInt();
+    const int64_t B = d.size(0), Q = q.size(1), D = d.size(1), E = d.size(2), K = mu.numel();
+    at::Tensor gq = at::empty_like(q), gd = at::empty_like(d);
+    at::Tensor ga = at::zeros({B, K}, q.options()), gw = at::zeros({B, K}, q.options());
+    at::Tensor gg = gate.defined() ? at::zeros({B, D}, q.options()) : at::Tensor();
+    if (B > 0) {
+      at::Tensor go = grads[0].reshape({-1});
+      TORCH_CHECK(go.device() == q.device(), "mm_autograd: grad_out on ", go.device(), ", the embeddings on ", q.device());
+      if (go.scalar_type() != at::kFloat) go = go.to(at::kFloat);
+      go = go.contiguous();
+      TORCH_CHECK(go.numel() == B, "mm_autograd: grad_out has ", go.numel(), " elements for ", B, " pairs");
+      const c10::DeviceGuard guard(q.device());
+      const size_t wsb = api.kp_bwd_ws(B, (int)Q, (int)D, qkind, dkind);
+      at::Tensor ws = wsb ? at::empty({(int64_t)wsb}, q.options().dtype(at::kByte)) : at::Tensor();
+      void* stream = c10::hip::getCurrentHIPStream(q.device().index()).stream();
+      check_rc(api.kp_bwd(q.data_ptr(), d.data_ptr(), qk.defined() ? qk.data_ptr() : nullptr, qkind, dk.defined() ? dk.data_ptr() : nullptr,
+                          dkind, gate.defined() ? gate.data_ptr<float>() : nullptr, mu.data_ptr<float>(), sigma.data_ptr<float>(),
+                          alpha.data_ptr<float>(), w.data_ptr<float>(), (float)ctx->saved_data["clamp"].toDouble(), pooled.data_ptr<float>(),
+                          go.data_ptr<float>(), gq.data_ptr<float>(), gd.data_ptr<float>(), gg.defined() ? gg.data_ptr<float>() : nullptr,
+                          ga.data_ptr<float>(), gw.data_ptr<float>(), B, (int)Q, (int)D, (int)E, (int)K, wsb ? ws.data_ptr() : nullptr, wsb,
+                          stream),
+               "mm_kernel_pool_ex_bwd2");
+    }
+    // per-pair parameter rows -> one deterministic sum on the device, in the parameters' own shapes
+    at::Tensor gas = ga.sum(0).reshape(ctx->saved_data["alpha_shape"].toIntVector());
+    at::Tensor gws = gw.sum(0).reshape(ctx->saved_data["w_shape"].toIntVector());
+    if (gg.defined()) gg = gg.reshape(ctx->saved_data["gate_shape"].toIntVector());
+    return {gq, gd, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gas, gws, gg, at::Tensor()};
+  }
+};
+
+at::Tensor kernel_pool(const at::Tensor& q, const at::Tensor& d, const c10::optional<at::Tensor>& q_mask,
+                       const c10::optional<at::Tensor>& d_mask, const at::Tensor& mu, const at::Tensor& sigma, const at::Tensor& alpha,
+                       const at::Tensor& w, const c10::optional<at::Tensor>& gate, double clamp_min) {
+  return KernelPool::apply(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate, clamp_min);
+}
+
+// the torch this file was compiled against: _fast.module() refuses the extension under another one (an artefact that
+// dlopens against an ABI-incompatible torch would crash the hot path instead of leaving it to the Python node)
+std::string built_torch_version() { return TORCH_VERSION; }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node around mm_maxsim_fwd / mm_maxsim_bwd (host plumbing; see the header of mm_autograd.cpp)";
   m.def("init", &init, "dlopen the scoring library (path of libmm_native.so) and resolve the entry points");
+  m.def("built_torch_version", &built_torch_version, "TORCH_VERSION of the headers this extension was compiled against");
+  m.def("kernel_pool", &kernel_pool, "TK kernel pooling (pair-per-row) with a native autograd node", py::arg("q"), py::arg("d"),
+        py::arg("q_mask"), py::arg("d_mask"), py::arg("mu"), py::arg("sigma"), py::arg("alpha"), py::arg("w"), py::arg("gate"),
+        py::arg("clamp_min"));
   m.def("maxsim_paired", &maxsim_paired, "paired MaxSim with a native autograd node", py::arg("q"), py::arg("d"), py::arg("q_mask"),
         py::arg("d_mask"), py::arg("flags"));
 }

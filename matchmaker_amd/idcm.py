@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .tk import _KernelPoolFn
+from .tk import kernel_pool_train
 
 MU = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]     # sigir21_idcm.py:106
 SIGMA = [0.1] * 11                                                    # :107
@@ -39,7 +39,7 @@ def sampler_scores(query_ctx: torch.Tensor, document_ctx: torch.Tensor, query_ma
     if needs_grad:
         if pair_query is not None:                         # the native backward works pair per row
             q, query_mask = q.index_select(0, pair_query), query_mask.index_select(0, pair_query)
-        s = _KernelPoolFn.apply(q, d, query_mask.float(), document_mask.float(), mu.reshape(-1), sigma.reshape(-1),
+        s = kernel_pool_train(q, d, query_mask.float(), document_mask.float(), mu.reshape(-1), sigma.reshape(-1),
                                 alpha.reshape(-1), w.reshape(-1), None, 1e-4)
     else:
         s = ops.kernel_pool(q, d, query_mask, document_mask, mu, sigma, alpha, w, clamp_min=1e-4,

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .tk import _KernelPoolFn
+from .tk import kernel_pool_train
 
 
 def kernel_mus(n_kernels: int) -> List[float]:
@@ -67,7 +67,7 @@ class KNRM(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (q, d, self.dense.weight))
         per_kernel = None
         if needs_grad:
-            score = _KernelPoolFn.apply(q, d, query_pad_oov_mask.float(), document_pad_oov_mask.float(),
+            score = kernel_pool_train(q, d, query_pad_oov_mask.float(), document_pad_oov_mask.float(),
                                         self.mu.view(-1), self.sigma.view(-1), self._ones, w)
         else:
             score, per_kernel = ops.kernel_pool(q, d, query_pad_oov_mask, document_pad_oov_mask, self.mu, self.sigma,

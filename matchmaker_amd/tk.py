@@ -6,12 +6,13 @@ The contextualiser (positional encoding + nn.TransformerEncoder + mixer, :95-96 
 PyTorch, as in the reference.  Called from NeuralIR_Encoder.forward (neuralIR_encoder.py:86-87).
 """
 import math
+import os
 from typing import List
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _fast, ops
 
 
 def sinusoid_positions(dim: int, length: int, min_timescale: float = 1.0, max_timescale: float = 1.0e4) -> torch.Tensor:
@@ -52,6 +53,19 @@ class _KernelPoolFn(torch.autograd.Function):
         gq, gd, ga, gw = r[:4]
         gg = r[4].view_as(gate) if gate is not None else None
         return gq, gd, None, None, None, None, ga.view_as(alpha), gw.view_as(w), gg, None
+
+
+def kernel_pool_train(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate=None, clamp_min=1e-10):
+    """The pooling block WITH an autograd node (train.py:347-348 / :503-524): the C++ node of csrc_host/mm_autograd.cpp when the
+    host extension was built and the call is in its shape (float32, pair-per-row, 16-byte rows) — at batch_size_train 32 x 2 the
+    Python node's apply + backward were 94 of the step's 242 us — else the Python autograd.Function; the same two C-ABI calls
+    (mm_kernel_pool_ex_fwd2 / _ex_bwd2) either way.  MM_KP_PY_AUTOGRAD=1 forces the Python node (A/B runs, tests)."""
+    fast = _fast.module()
+    if (fast is not None and hasattr(fast, "kernel_pool") and os.environ.get("MM_KP_PY_AUTOGRAD", "0") in ("", "0")
+            and q.is_cuda and q.dtype == torch.float32 and d.dtype == torch.float32 and q.dim() == 3 and d.dim() == 3
+            and q.shape[0] == d.shape[0] and q.shape[-1] % 4 == 0 and q.shape[1] <= 32):
+        return fast.kernel_pool(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate, float(clamp_min))
+    return _KernelPoolFn.apply(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate, clamp_min)
 
 
 class ECAI20_TK(nn.Module):
@@ -106,7 +120,7 @@ class ECAI20_TK(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (q, d, w, self.kernel_alpha_scaler))
         if needs_grad:
-            score = _KernelPoolFn.apply(q, d, query_mask.float(), document_mask.float(), self.mu.view(-1),
+            score = kernel_pool_train(q, d, query_mask.float(), document_mask.float(), self.mu.view(-1),
                                         self.sigma.view(-1), self.kernel_alpha_scaler.view(-1), w.view(-1))
             per_kernel = None
         else:

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .tk import _KernelPoolFn, sinusoid_positions
+from .tk import kernel_pool_train, sinusoid_positions
 
 
 class CIKM20_TK_Sparse(nn.Module):
@@ -81,7 +81,7 @@ class CIKM20_TK_Sparse(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (q, d, w, self.kernel_alpha_scaler, document_stop_words))
         if needs_grad:
-            score = _KernelPoolFn.apply(q, d, query_mask.float(), document_mask.float(), self.mu.view(-1),
+            score = kernel_pool_train(q, d, query_mask.float(), document_mask.float(), self.mu.view(-1),
                                         self.sigma.view(-1), self.kernel_alpha_scaler.view(-1), w.view(-1),
                                         document_stop_words.squeeze(1).float())
             per_kernel = None

@@ -173,6 +173,42 @@ def test_kernel_pool_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
         np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), want, atol=2e-4 * scale, rtol=2e-3, err_msg=name + " (pooled path)")
 
 
+@pytest.mark.parametrize("gated", [False, True])
+def test_cpp_autograd_node_of_the_pooling_block_equals_the_python_node(monkeypatch, gated):
+    """tk.kernel_pool_train: the C++ torch::autograd::Function (csrc_host/mm_autograd.cpp KernelPool) and the Python
+    autograd.Function issue the same two C-ABI calls: scores and every gradient bit-equal (TK shape, float masks with a hole,
+    TK-Sparse's gate, IDCM's floor)."""
+    from matchmaker_amd import _fast
+    from matchmaker_amd.tk import kernel_pool_train
+    dev = util.require_gpu()
+    if _fast.module() is None or not hasattr(_fast.module(), "kernel_pool"):
+        pytest.skip("host extension not built (python -m matchmaker_amd.build)")
+    g = torch.Generator().manual_seed(77)
+    B, Q, D, E = 6, 20, 200, 300
+    q = torch.randn(B, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B, 1), generator=g)).float()
+    dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (B, 1), generator=g)).float()
+    dm[0, 1] = 0.0
+    gate = torch.relu(torch.randn(B, D, generator=g)) if gated else None
+    alpha = torch.rand(11, generator=g) + 0.5
+    w = torch.randn(11, generator=g) * 0.3
+    go = torch.randn(B, generator=g)
+    mu, sigma = torch.tensor(MU), torch.tensor(SIGMA)
+
+    def run(py):
+        monkeypatch.setenv("MM_KP_PY_AUTOGRAD", "1" if py else "0")
+        leaves = [t.to(dev).requires_grad_(True) for t in ((q, d, alpha, w) + ((gate,) if gated else ()))]
+        s = kernel_pool_train(leaves[0], leaves[1], qm.to(dev), dm.to(dev), mu.to(dev), sigma.to(dev), leaves[2].view(1, 1, -1),
+                              leaves[3].view(1, -1), leaves[4] if gated else None, 1e-4 if gated else 1e-10)
+        (s * go.to(dev)).sum().backward()
+        return [s.detach()] + [t.grad for t in leaves]
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
+
+
 def test_knrm_dropin_matches_reference_golden_and_trains():
     """matchmaker_amd.knrm.KNRM (native pooling) vs the real KNRM.forward outputs (knrm.py:44-92), and its
     backward vs autograd through the oracle's torch port of the same ops."""
