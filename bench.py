@@ -650,6 +650,34 @@ def extra_eval_batch(steps, cpu_budget):
         torch.cuda.empty_cache()
     except Exception as e:
         res["colbert_dim128_bf16"]["graph_replay"] = {"error": repr(e)[:300]}
+    # the batched entry (mm_maxsim_fwd_batched: ColBERT.score_batches / rerank.evaluate_batches(score_group=16)): sixteen resident
+    # batches per launch — for a caller that holds the token vectors of several batches; bit-equal scores (checked here)
+    try:
+        make = colbert_batch_maker(Q, D, E, torch.bfloat16)
+        batches = [make() for _ in range(32)]
+        groups = [batches[i:i + 16] for i in range(0, 32, 16)]
+        got = ColBERT.score_batches(groups[0])
+        same = all(bool(torch.equal(x, ColBERT._score(*b))) for x, b in zip(got, groups[0]))
+        for _ in range(5):
+            for gr in groups:
+                ColBERT.score_batches(gr)
+        torch.cuda.synchronize()
+        n_calls = 200
+        t0 = time.perf_counter()
+        for i in range(n_calls):
+            ColBERT.score_batches(groups[i % 2])
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_done = time.perf_counter() - t0
+        byc = Bc * ((D + Q) * E * 2 + 8 * (D + Q) + 4)
+        res["colbert_dim128_bf16"]["batched_entry"] = {
+            "batches_per_launch": 16, "us_per_call_completed": 1e6 * t_done / n_calls / 16, "us_per_call_host_issue": 1e6 * t_issue / n_calls / 16,
+            "frac": 16 * byc / (t_done / n_calls) / 1e9 / HBM_PEAK_GBS, "scores_bit_equal_to_per_batch_calls": same,
+            "what": "ColBERT.score_batches: sixteen 512-pair batches per mm_maxsim_fwd_batched launch; us per 512-pair batch"}
+        del batches, groups, got
+        torch.cuda.empty_cache()
+    except Exception as e:
+        res["colbert_dim128_bf16"]["batched_entry"] = {"error": repr(e)[:300]}
     run("colbert_published_dim768_fp16", 3, colbert_batch_maker(38, 200, 768, torch.float16), lambda b: ColBERT._score(*b),
         Bc * ((200 + 38) * 768 * 2 + 8 * (200 + 38) + 4))
     prm = [torch.tensor(MU, device=dev), torch.full((11,), 0.1, device=dev), torch.ones(11, device=dev),

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4 /* 4: mm_kernel_pool_ex_fwd2 / mm_kernel_pool_ex_bwd2 (the forward hands its pooled kernel sums to the backward).
+#define MM_ABI_VERSION 4 /* 4: mm_kernel_pool_ex_fwd2 / mm_kernel_pool_ex_bwd2 (the forward hands its pooled kernel sums to the backward),
+                          *    mm_maxsim_fwd_batched (several eval.py-sized batches per launch).
                           * 3: 2: `flags` on the MaxSim forwards (the reference's 16-bit dtype flow); mm_tkl_fwd's ascending chunk_slot
                             contract and workspace layout.  3: + mm_tkl_fwd_peaks (the region search's three peak indices) */
 
@@ -96,6 +97,27 @@ int mm_maxsim_fwd(const void* q, const void* d,
                   int64_t n_pairs, int64_t pairs_per_query,
                   int Q, int D, int E, int dtype, int flags,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Several pair-per-row batches of ONE shape scored by ONE launch: the scoring block of ColBERT.forward (colbert.py:68-75) as
+ * eval.py:82-108 drives it — `batch_size_eval: 512` pairs per model.forward (config/train/defaults.yaml:115) — for a caller that
+ * holds the token vectors of several batches (matchmaker_amd/rerank.py evaluate_batches(score_group=...)).  A 512-pair call at
+ * dim 128 is 3.6 us of HBM time behind a ~9 us launch chain; the group pays the chain once.
+ *   batches[i]: q [n_pairs, Q, E], d [n_pairs, D, E] (16-bit vectors, 16-byte aligned), q_mask [n_pairs, Q] / d_mask [n_pairs, D]
+ *   (int64 tokenizer masks, or NULL for all of them), out [n_pairs] float32; the descriptors are HOST memory (read during the call).
+ *   Shapes the pair-per-row kernel takes (Q <= 32, E in {128, 256, 384, 512, 768}, even Q and D <= 256 with masks); anything
+ *   else returns MM_EUNSUPPORTED and the caller scores batch by batch with mm_maxsim_fwd.  n_batches <= MM_MAXSIM_MAX_BATCHES.
+ * Scores: bit-equal to mm_maxsim_fwd on each batch alone (same kernel body; flags as there). */
+#define MM_MAXSIM_MAX_BATCHES 16
+typedef struct {
+  const void* q;
+  const void* d;
+  const void* q_mask;
+  const void* d_mask;
+  float* out;
+  int64_t n_pairs;
+} mm_maxsim_batch_t;
+int mm_maxsim_fwd_batched(const mm_maxsim_batch_t* batches, int n_batches, int q_mask_kind, int d_mask_kind,
+                          int Q, int D, int E, int dtype, int flags, void* stream);
 
 /* All-pairs MaxSim: out[i, j] over query i x document j.
  * Replaces ColBERT.forward_inbatch_aggregation       matchmaker/models/colbert.py:154-162

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mm_last_error": (_c.c_char_p, []),
     "mm_maxsim_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
     "mm_maxsim_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mm_maxsim_fwd_batched": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mm_maxsim_inbatch_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i]),
     "mm_maxsim_inbatch_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_maxsim_ragged_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),

@@ -121,6 +121,44 @@ class ColBERT(PreTrainedModel):
             score = ops.maxsim(q, d, query_mask, document_mask, 1, sim_round, sum_round)
         return score.to(q.dtype) if sum_round else score      # (16-bit tensors outside autocast: `sum` returns their dtype)
 
+    @staticmethod
+    def score_batches(batches):
+        """The scoring block of SEVERAL forward calls at once: `batches` = [(query_vecs, document_vecs, query_mask, document_mask),
+        ...] as _score takes them, all of one shape.  One launch for the group (ops.maxsim_batched) where the pair-per-row
+        kernel takes the shape — eval.py's 512-pair batches (defaults.yaml:115) are 3.6 us of HBM time behind a ~9 us launch
+        chain each — else one _score per batch.  No autograd (evaluation).  Returns the list of score tensors, bit-equal to
+        [_score(*b) for b in batches]."""
+        batches = list(batches)
+        if len(batches) < 2:
+            return [ColBERT._score(*b) for b in batches]
+        ac = torch.is_autocast_enabled("cuda")
+        prepared, flags = [], None
+        for q, d, qm, dm in batches:
+            if q.dtype is torch.float32:
+                if not ac:
+                    return [ColBERT._score(*b) for b in batches]          # fp32 scoring: the split-bf16 kernels, call by call
+                adt = torch.get_autocast_dtype("cuda")
+                q, d = q.to(adt), d.to(adt)
+                f = (ac, False)
+            else:
+                if d.dtype is not q.dtype:
+                    d = d.to(q.dtype)
+                f = (True, not ac)
+            if flags is None:
+                flags = f
+            same = (f == flags and q.shape[1:] == prepared[0][0].shape[1:] and d.shape[1:] == prepared[0][1].shape[1:]
+                    and q.dtype == prepared[0][0].dtype) if prepared else True
+            if not same or q.dim() != 3 or q.shape[0] != d.shape[0] or (qm is None) != (dm is None) \
+                    or (qm is not None and (qm.dtype != torch.int64 or dm.dtype != torch.int64)):
+                return [ColBERT._score(*b) for b in batches]
+            prepared.append((q, d, qm, dm))
+        try:
+            with torch.no_grad():
+                scores = ops.maxsim_batched(prepared, sim_round=flags[0], sum_round=flags[1])
+        except ops.NativeError:                                           # a shape the pair-per-row kernel does not take
+            return [ColBERT._score(*b) for b in batches]
+        return [s.to(p[0].dtype) if flags[1] else s for s, p in zip(scores, prepared)]
+
     def forward(self, query: Dict[str, torch.LongTensor], document: Dict[str, torch.LongTensor],
                 use_fp16: bool = True, output_secondary_output: bool = False):
         """colbert.py:54-86 — same arguments and return conventions."""

@@ -47,13 +47,13 @@ __device__ __forceinline__ void issue_masks(const char* dm_row, const uint32_t (
 }
 
 template <int DT, int NBUF, int NSL, bool I64>
-__global__ void __launch_bounds__(64) maxsim_pair_kernel(const MaxsimArgs a) {
+__device__ __forceinline__ void maxsim_pair_body(const MaxsimArgs& a, const int block_x) {
   static_assert(NBUF >= 2 && NBUF <= 4, "6-bit x 4 unit FIFO");
   constexpr int RB = NSL * 256;  // bytes per token row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t p0 = (int64_t)blockIdx.x * a.pairs_per_wave;
+  const int64_t p0 = (int64_t)block_x * a.pairs_per_wave;
   const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
   if (p0 >= p1) return;
   const int D = a.D, Q = a.Q;
@@ -271,6 +271,69 @@ __global__ void __launch_bounds__(64) maxsim_pair_kernel(const MaxsimArgs a) {
   }
 }
 
+template <int DT, int NBUF, int NSL, bool I64>
+__global__ void __launch_bounds__(64) maxsim_pair_kernel(const MaxsimArgs a) {
+  maxsim_pair_body<DT, NBUF, NSL, I64>(a, (int)blockIdx.x);
+}
+
+// Several pair-per-row batches of ONE shape in one launch (mm_maxsim_fwd_batched): blockIdx.y picks the batch's tensors out of
+// the kernel argument itself (no descriptor table in memory, no copy); everything else is maxsim_pair_kernel — the scores of a
+// batch are bit-equal to its own mm_maxsim_fwd call (same pairs per wavefront order inside a pair: a pair never spans wavefronts).
+// Why: eval.py's 512-pair calls (defaults.yaml:115) at dim 128 are 3.6 us of HBM time behind a ~9 us launch chain; a caller
+// that holds several tokenised batches (rerank.evaluate_batches(score_group=...)) pays that chain once per group.
+constexpr int kMaxBatches = MM_MAXSIM_MAX_BATCHES;
+struct MaxsimBatches {
+  const void* q[kMaxBatches];
+  const void* d[kMaxBatches];
+  const int64_t* qm64[kMaxBatches];
+  const int64_t* dm64[kMaxBatches];
+  float* out[kMaxBatches];
+  int64_t n_pairs[kMaxBatches];
+};
+
+template <int DT, int NBUF, int NSL, bool I64>
+__global__ void __launch_bounds__(64) maxsim_pair_batched_kernel(const MaxsimArgs a_in, const MaxsimBatches bt) {
+  MaxsimArgs a = a_in;
+  const int y = blockIdx.y;
+  a.q = bt.q[y];
+  a.d = bt.d[y];
+  a.qm64 = bt.qm64[y];
+  a.dm64 = bt.dm64[y];
+  a.out = bt.out[y];
+  a.n_pairs = bt.n_pairs[y];
+  maxsim_pair_body<DT, NBUF, NSL, I64>(a, (int)blockIdx.x);
+}
+
+template <int DT, int NSL, bool I64>
+static int launch_pair_batched(const MaxsimArgs& a0, const MaxsimBatches& bt, int nb, int64_t total, int64_t max_pairs, hipStream_t stream) {
+  MaxsimArgs a = a0;
+  const int nbuf = env().maxsim_nbuf >= 3 ? 3 : 2;
+  const int lds = nbuf * kBlkBytes + (I64 ? kMaskRaw + kMaskEntries * kMaskEntry * 4 : 0);
+  int wpc = env().maxsim_wpc > 0 ? env().maxsim_wpc : 4;
+  if (wpc > 8) wpc = 8;
+  int64_t waves = (int64_t)kCUs * wpc;                   // over ALL batches
+  if (waves > total) waves = total;
+  a.pairs_per_wave = (total + waves - 1) / waves;
+  const int64_t gx = (max_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+  const dim3 grid((unsigned)gx, (unsigned)nb);
+  if (nbuf == 3)
+    hipLaunchKernelGGL((maxsim_pair_batched_kernel<DT, 3, NSL, I64>), grid, dim3(64), lds, stream, a, bt);
+  else
+    hipLaunchKernelGGL((maxsim_pair_batched_kernel<DT, 2, NSL, I64>), grid, dim3(64), lds, stream, a, bt);
+  return check_launch("maxsim_pair_batched_kernel");
+}
+
+template <int DT, bool I64>
+static int launch_pair_batched_e(const MaxsimArgs& a, const MaxsimBatches& bt, int nb, int64_t total, int64_t max_pairs, hipStream_t stream) {
+  switch (a.E / 128) {
+    case 1: return launch_pair_batched<DT, 1, I64>(a, bt, nb, total, max_pairs, stream);
+    case 2: return launch_pair_batched<DT, 2, I64>(a, bt, nb, total, max_pairs, stream);
+    case 3: return launch_pair_batched<DT, 3, I64>(a, bt, nb, total, max_pairs, stream);
+    case 4: return launch_pair_batched<DT, 4, I64>(a, bt, nb, total, max_pairs, stream);
+    default: return launch_pair_batched<DT, 6, I64>(a, bt, nb, total, max_pairs, stream);
+  }
+}
+
 template <int DT, int NSL, bool I64>
 static int launch_pair(const MaxsimArgs& a0, hipStream_t stream) {
   MaxsimArgs a = a0;
@@ -315,3 +378,41 @@ int maxsim_pair_launch(const MaxsimArgs& a, int dtype, bool i64, hipStream_t str
 }
 
 }  // namespace mm
+
+using namespace mm;
+
+extern "C" int mm_maxsim_fwd_batched(const mm_maxsim_batch_t* batches, int n_batches, int q_mask_kind, int d_mask_kind, int Q, int D,
+                                     int E, int dtype, int flags, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!batches || n_batches < 1) return set_error(MM_EINVAL, "maxsim_batched: no batches");
+  if (n_batches > kMaxBatches) return set_error(MM_EUNSUPPORTED, "maxsim_batched: %d batches (at most %d per launch)", n_batches, kMaxBatches);
+  if (Q <= 0 || D <= 0 || E <= 0) return set_error(MM_EINVAL, "maxsim_batched: bad shape");
+  if (!maxsim_pair_supported(Q, E, dtype))
+    return set_error(MM_EUNSUPPORTED, "maxsim_batched: Q=%d E=%d dtype=%d is not the pair-per-row kernel's (16-bit vectors, Q <= 32, "
+                                      "E in {128, 256, 384, 512, 768}): call mm_maxsim_fwd per batch", Q, E, dtype);
+  const bool i64 = q_mask_kind == MM_MASK_I64 && d_mask_kind == MM_MASK_I64;
+  if (!i64 && !(q_mask_kind == MM_MASK_NONE && d_mask_kind == MM_MASK_NONE))
+    return set_error(MM_EUNSUPPORTED, "maxsim_batched: masks are either both int64 tokenizer masks or both absent");
+  MaxsimArgs a{};
+  a.Q = Q; a.D = D; a.E = E; a.ppq = 1; a.rnd = flags & (MM_SIM_ROUND | MM_SUM_ROUND);
+  MaxsimBatches bt{};
+  int64_t total = 0, max_pairs = 0;
+  for (int i = 0; i < n_batches; ++i) {
+    const mm_maxsim_batch_t& b = batches[i];
+    if (b.n_pairs < 0 || (b.n_pairs > 0 && (!b.q || !b.d || !b.out))) return set_error(MM_EINVAL, "maxsim_batched: batch %d: null pointer", i);
+    if (((uintptr_t)b.q | (uintptr_t)b.d) & 15) return set_error(MM_EINVAL, "maxsim_batched: batch %d: q / d must be 16-byte aligned", i);
+    if (i64 && (!b.q_mask || !b.d_mask || !maxsim_pair_i64_supported(Q, D, b.q_mask, b.d_mask)))
+      return set_error(MM_EUNSUPPORTED, "maxsim_batched: batch %d: int64 masks need even Q, D <= 256 and 16-byte aligned rows", i);
+    bt.q[i] = b.q; bt.d[i] = b.d; bt.qm64[i] = (const int64_t*)b.q_mask; bt.dm64[i] = (const int64_t*)b.d_mask;
+    bt.out[i] = b.out; bt.n_pairs[i] = b.n_pairs;
+    total += b.n_pairs;
+    max_pairs = b.n_pairs > max_pairs ? b.n_pairs : max_pairs;
+  }
+  if (total == 0) return MM_OK;
+  if (max_pairs > 0x7fffffffLL) return set_error(MM_EUNSUPPORTED, "maxsim_batched: too many pairs in one batch");
+  if (dtype == MM_BF16)
+    return i64 ? launch_pair_batched_e<MM_BF16, true>(a, bt, n_batches, total, max_pairs, stream)
+               : launch_pair_batched_e<MM_BF16, false>(a, bt, n_batches, total, max_pairs, stream);
+  return i64 ? launch_pair_batched_e<MM_F16, true>(a, bt, n_batches, total, max_pairs, stream)
+             : launch_pair_batched_e<MM_F16, false>(a, bt, n_batches, total, max_pairs, stream);
+}

@@ -6,6 +6,7 @@ output (+ a small mask-packing workspace from torch's caching allocator), never 
 keeps no state, so it is re-entrant from nn.DataParallel's per-GPU threads
 (matchmaker/train.py:201).  CPU tensors are rejected: there is no CPU fallback.
 """
+import ctypes
 import threading
 from typing import Optional
 
@@ -210,6 +211,62 @@ def maxsim(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Tensor] = No
                              ws.data_ptr() if ws is not None else None, wsb, st)
     _lib.check(rc, "mm_maxsim_fwd")
     return out
+
+
+class _MaxsimBatch(ctypes.Structure):      # mm_maxsim_batch_t (include/mm_native.h)
+    _fields_ = [("q", ctypes.c_void_p), ("d", ctypes.c_void_p), ("q_mask", ctypes.c_void_p), ("d_mask", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("n_pairs", ctypes.c_int64)]
+
+
+MAXSIM_MAX_BATCHES = 16
+
+
+def maxsim_batched(batches, sim_round: bool = False, sum_round: bool = False):
+    """Several pair-per-row batches of ONE shape scored by one launch (mm_maxsim_fwd_batched): `batches` = a sequence of
+    (q [B, Q, E], d [B, D, E], q_mask, d_mask) with 16-bit vectors and either int64 tokenizer masks ([B, Q] / [B, D]) or None for
+    both, everywhere.  Returns the list of float32 score tensors [B] (views of one allocation), bit-equal to maxsim() on
+    each batch.  Raises NativeError(MM_EUNSUPPORTED ...) for shapes the pair-per-row kernel does not take (callers fall back
+    to one maxsim() per batch); more than MAXSIM_MAX_BATCHES batches go out in several launches."""
+    batches = list(batches)
+    if not batches:
+        return []
+    q0, d0, qm0, dm0 = batches[0]
+    dev = _dev_check(*[t for b in batches for t in b])
+    Q, E, D = q0.shape[1], q0.shape[2], d0.shape[1]
+    has_masks = qm0 is not None
+    total = sum(b[1].shape[0] for b in batches)
+    out = torch.empty(total, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    keep, views, recs, off = [], [], [], 0
+    for q, d, qm, dm in batches:
+        q, d = _emb(q, "q"), _emb(d, "d")
+        if q.dtype != q0.dtype or d.dtype != q0.dtype or q.dtype == torch.float32:
+            raise NativeError("maxsim_batched: 16-bit vectors of one dtype in every batch")
+        if q.shape[1:] != (Q, E) or d.shape[1:] != (D, E) or q.shape[0] != d.shape[0]:
+            raise NativeError(f"maxsim_batched: every batch must be pair-per-row [B, {Q}, {E}] / [B, {D}, {E}], got {tuple(q.shape)} / {tuple(d.shape)}")
+        if (qm is not None) != has_masks or (dm is not None) != has_masks:
+            raise NativeError("maxsim_batched: masks for every batch or for none")
+        B = d.shape[0]
+        if has_masks:
+            if qm.dtype != torch.int64 or dm.dtype != torch.int64 or tuple(qm.shape) != (B, Q) or tuple(dm.shape) != (B, D):
+                raise NativeError("maxsim_batched: masks are the tokenizer's int64 [B, Q] / [B, D] tensors")
+            qm, dm = qm.contiguous(), dm.contiguous()
+        keep.append((q, d, qm, dm))
+        o = out[off:off + B]
+        views.append(o)
+        recs.append(_MaxsimBatch(q.data_ptr(), d.data_ptr(), qm.data_ptr() if has_masks else None,
+                                 dm.data_ptr() if has_masks else None, o.data_ptr(), B))
+        off += B
+    kind = _lib.MASK_I64 if has_masks else _lib.MASK_NONE
+    with _on(dev):
+        st = _stream(dev)
+        for i in range(0, len(recs), MAXSIM_MAX_BATCHES):
+            part = recs[i:i + MAXSIM_MAX_BATCHES]
+            arr = (_MaxsimBatch * len(part))(*part)
+            rc = L.mm_maxsim_fwd_batched(ctypes.cast(arr, ctypes.c_void_p), len(part), kind, kind, Q, D, E, _DT[q0.dtype],
+                                         (1 if sim_round else 0) | (2 if sum_round else 0), st)
+            _lib.check(rc, "mm_maxsim_fwd_batched")
+    return views
 
 
 def hbm_stream_probe(t: torch.Tensor, nt: bool = True) -> None:

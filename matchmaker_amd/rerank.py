@@ -82,9 +82,12 @@ class _GraphedForward:
 
 
 def evaluate_batches(model, batches: Iterable[dict], use_fp16: bool = True, device=None,
-                     output_secondary_output: bool = False, graph: bool = False) -> Dict[str, List[Tuple[str, float]]]:
+                     output_secondary_output: bool = False, graph: bool = False, score_group: int = 1) -> Dict[str, List[Tuple[str, float]]]:
     """batches: dicts with "query_tokens", "doc_tokens" (HF tokenizer dicts), "query_id", "doc_id" (lists),
     the fields eval.py reads.  Returns the unrolled results of eval.py:189-203.
+    score_group > 1 (models with forward_representation + score_batches: the ColBERT drop-in): the encoder runs batch by batch
+    as in eval.py:108, the scoring block of `score_group` consecutive batches is ONE launch (mm_maxsim_fwd_batched) and their
+    scores come back with one `.cpu()` — same scores, same result order.
     graph=True: every batch shape's forward is captured once in a HIP graph and replayed (_GraphedForward) — for models
     whose forward is capturable (no host synchronisation, no data-dependent shapes: ColBERT, TK; not TKL, whose chunk
     packing is data dependent as in the reference)."""
@@ -96,6 +99,36 @@ def evaluate_batches(model, batches: Iterable[dict], use_fp16: bool = True, devi
         device = t.device
     validation_results: Dict[str, List[Tuple[str, float]]] = {}
     graphed = _GraphedForward(model, use_fp16, output_secondary_output, torch.device(device)) if graph else None
+    grouped = score_group > 1 and graphed is None and not output_secondary_output \
+        and hasattr(model, "score_batches") and hasattr(model, "forward_representation")
+    if grouped:
+        pend = []      # (batch_orig, query_vecs, document_vecs, query mask, document mask)
+
+        def flush():
+            if not pend:
+                return
+            with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+                scores = model.score_batches([p[1:] for p in pend])
+            flat = torch.cat([s.float().reshape(-1) for s in scores]).cpu()          # :161 — one piece per group
+            off = 0
+            for (bo, *_), s in zip(pend, scores):
+                for i, qid in enumerate(bo["query_id"]):
+                    validation_results.setdefault(qid, []).append((bo["doc_id"][i], float(flat[off + i])))
+                off += s.numel()
+            pend.clear()
+        with torch.no_grad():
+            for batch_orig in batches:
+                with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+                    batch = _to_device({k: batch_orig[k] for k in ("query_tokens", "doc_tokens")}, device)
+                    qv = model.forward_representation(batch["query_tokens"])
+                    dv = model.forward_representation(batch["doc_tokens"])
+                if pend and (qv.shape[1:] != pend[0][1].shape[1:] or dv.shape[1:] != pend[0][2].shape[1:]):
+                    flush()                                    # eval.py pads every batch to its own longest sequence
+                pend.append((batch_orig, qv, dv, batch["query_tokens"]["attention_mask"], batch["doc_tokens"]["attention_mask"]))
+                if len(pend) >= score_group:
+                    flush()
+            flush()
+        return validation_results
     with torch.no_grad():
         for batch_orig in batches:
             if graphed is not None:

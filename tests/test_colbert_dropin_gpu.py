@@ -126,6 +126,70 @@ def test_full_forward_matches_the_real_colbert_class_end_to_end():
     assert np.array_equal(np.argsort(-score.cpu().numpy(), kind="stable"), np.argsort(-g["forward"], kind="stable"))
 
 
+@pytest.mark.parametrize("dt,Q,D,E,masks", [(torch.bfloat16, 32, 180, 128, True), (torch.float16, 32, 180, 128, True),
+                                             (torch.float16, 30, 200, 768, True), (torch.bfloat16, 32, 180, 128, False)])
+def test_batched_scoring_entry_is_bit_equal_to_per_batch_calls(dt, Q, D, E, masks):
+    """mm_maxsim_fwd_batched (ops.maxsim_batched / ColBERT.score_batches): several eval.py-sized pair-per-row batches in one
+    launch — same kernel body as the per-batch call, so every score must be the same bits; batches of different sizes, ragged
+    int64 tokenizer masks with holes, more batches than one launch takes, and a shape it refuses (odd D) falling back."""
+    from matchmaker_amd import ops
+    from matchmaker_amd.colbert import ColBERT
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 1000 + E)
+    batches = []
+    for B in (512, 512, 37, 512, 1, 300) + (512,) * 13:          # 19 batches: two launches
+        q = (torch.randn(B, Q, E, generator=g) / E ** 0.5).to(dt).to(dev)
+        d = (torch.randn(B, D, E, generator=g) / E ** 0.5).to(dt).to(dev)
+        if masks:
+            qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B, 1), generator=g)).long()
+            dm = (torch.arange(D)[None] < torch.randint(1, D + 1, (B, 1), generator=g)).long()
+            dm[0, min(3, D - 1)] = 0
+            batches.append((q, d, qm.to(dev), dm.to(dev)))
+        else:
+            batches.append((q, d, None, None))
+    for sim_round, sum_round in ((True, False), (True, True), (False, False)):
+        got = ops.maxsim_batched(batches, sim_round=sim_round, sum_round=sum_round)
+        for b, s in zip(batches, got):
+            assert torch.equal(s, ops.maxsim(b[0], b[1], b[2], b[3], 1, sim_round, sum_round))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = ColBERT.score_batches(batches)
+        w = [ColBERT._score(*b) for b in batches]
+    assert all(torch.equal(x, y) and x.dtype == y.dtype for x, y in zip(a, w))
+    # a shape the pair-per-row kernel refuses (odd D with int64 masks): score_batches falls back to per-batch calls
+    if masks:
+        odd = [(b[0], b[1][:, :D - 1].contiguous(), b[2], b[3][:, :D - 1].contiguous()) for b in batches[:3]]
+        with pytest.raises(ops.NativeError):
+            ops.maxsim_batched(odd)
+        with torch.no_grad():
+            a = ColBERT.score_batches(odd)
+            w = [ColBERT._score(*b) for b in odd]
+        assert all(torch.equal(x, y) for x, y in zip(a, w))
+
+
+def test_grouped_evaluation_equals_the_batch_by_batch_loop():
+    """rerank.evaluate_batches(score_group=4): encoder per batch, scoring block of four batches per launch, one .cpu() per group —
+    the same unrolled results as eval.py's batch-by-batch loop (scores and arrival order), across a shape change and a short
+    last batch."""
+    from matchmaker_amd import rerank
+    dev = util.require_gpu()
+    m = _model(dev)
+    g = torch.Generator().manual_seed(5)
+
+    def batch(B, Q, D, tag):
+        ql, dl = torch.randint(3, Q + 1, (B,), generator=g), torch.randint(8, D + 1, (B,), generator=g)
+        mk = lambda L, n: {"input_ids": torch.randint(1, 500, (B, n), generator=g),
+                           "attention_mask": (torch.arange(n)[None] < L[:, None]).long()}
+        return {"query_tokens": mk(ql, Q), "doc_tokens": mk(dl, D), "query_id": [f"q{tag}_{i % 3}" for i in range(B)],
+                "doc_id": [f"d{tag}_{i}" for i in range(B)]}
+    batches = [batch(16, 32, 180, i) for i in range(6)] + [batch(16, 30, 170, 6), batch(16, 32, 180, 7), batch(5, 32, 180, 8)]
+    eager = rerank.evaluate_batches(m, batches, use_fp16=True)
+    grouped = rerank.evaluate_batches(m, batches, use_fp16=True, score_group=4)
+    assert eager.keys() == grouped.keys()
+    for k in eager:
+        assert [d for d, _ in eager[k]] == [d for d, _ in grouped[k]]
+        np.testing.assert_array_equal([s for _, s in eager[k]], [s for _, s in grouped[k]])
+
+
 def test_graphed_evaluation_equals_eager_and_its_cache_is_bounded():
     """rerank.evaluate_batches(graph=True): one HIP-graph capture per batch shape, replayed — same scores as the eager loop,
     incl. a short last batch (another shape) and the secondary-output convention; the capture cache is an LRU (eval.py pads
