@@ -26,10 +26,16 @@ _TABLE = [
 ]
 
 
+_idcm_note_given = False
+
+
 def patch_matchmaker(strict: bool = False):
     """Rebinds the reference's model classes to the matchmaker_amd drop-ins.  Returns the list of
     "module.attribute" names that were rebound.  Modules that cannot be imported (optional dependencies of the
-    reference that are not installed) are skipped unless strict=True."""
+    reference that are not installed) are skipped unless strict=True.
+    IDCM is not in the table (see above): when its module is importable a one-time warning says so — rounds 3-4 rebound it,
+    and a caller relying on that would otherwise run the reference's eager sampler without notice."""
+    global _idcm_note_given
     done = []
     for ref_mod, ref_attr, our_mod, our_attr in _TABLE:
         try:
@@ -44,4 +50,14 @@ def patch_matchmaker(strict: bool = False):
         all_mod = sys.modules.get("matchmaker.models.all")      # `from ... import *` copies made earlier
         if all_mod is not None and hasattr(all_mod, ref_attr):
             setattr(all_mod, ref_attr, ours)
+    if not _idcm_note_given:
+        try:
+            importlib.import_module("matchmaker.models.published.sigir21_idcm")
+            import warnings
+            warnings.warn("matchmaker_amd.patch_matchmaker: IDCM is NOT patched (its passage sampler is inline in IDCM.forward); "
+                          "apply the three-line edit of INTEGRATION.md section 3 to call matchmaker_amd.idcm.sampler_scores",
+                          stacklevel=2)
+        except Exception:
+            pass
+        _idcm_note_given = True
     return done

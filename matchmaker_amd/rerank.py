@@ -36,6 +36,7 @@ class _GraphedForward:
         from collections import OrderedDict
         self.model, self.use_fp16, self.sec, self.device = model, use_fp16, output_secondary_output, device
         self.entries = OrderedDict()
+        self.failed = OrderedDict()      # shapes whose capture failed (bounded on its own: they do not push live graphs out)
         self.max_graphs = max_graphs
         self.eager_calls = 0
 
@@ -48,6 +49,9 @@ class _GraphedForward:
     def __call__(self, batch_orig):
         parts = {k: batch_orig[k] for k in ("query_tokens", "doc_tokens")}
         key = tuple((k, n, tuple(t.shape), t.dtype) for k in parts for n, t in sorted(parts[k].items()))
+        if key in self.failed:                                 # a shape whose capture failed before: eager, every time
+            self.eager_calls += 1
+            return self._run(_to_device(parts, self.device))
         entry = self.entries.get(key, False)
         if entry is False:
             static = _to_device(parts, self.device)
@@ -61,18 +65,22 @@ class _GraphedForward:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     out = self._run(static)
-            except Exception:                                  # not capturable (data-dependent shapes, a host sync): eager, every time
-                self.entries[key] = entry = None
+            except RuntimeError as e:                          # not capturable (data-dependent shapes, a host sync): eager, every time
+                if "out of memory" in str(e).lower():          # (an OOM is not a property of the shape: let the caller see it)
+                    raise
+                import warnings
+                warnings.warn(f"rerank: HIP-graph capture failed for batch shape {key[0][2:]} ({str(e)[:120]}); this shape runs eagerly")
+                self.failed[key] = True
+                while len(self.failed) > 4 * self.max_graphs:
+                    self.failed.popitem(last=False)
                 self.eager_calls += 1
-                return eager_out
+                torch.cuda.synchronize(self.device)            # leave no half-open capture state behind
+                return self._run(static)                       # recomputed AFTER the failed capture (the warm-up result predates it)
             entry = self.entries[key] = (g, static, out)
             while len(self.entries) > self.max_graphs:         # least recently replayed shape goes (its pool is freed with it)
                 self.entries.popitem(last=False)
         elif key in self.entries:
             self.entries.move_to_end(key)
-        if entry is None:                                      # a shape whose capture failed before
-            self.eager_calls += 1
-            return self._run(_to_device(parts, self.device))
         g, static, out = entry
         for k, v in parts.items():
             for n, t in v.items():

@@ -315,8 +315,15 @@ def _tkl_case(seed, nq, C, dev):
     # the fp32 / fp64 oracles of a draw depend on the seed alone: the exact-f32 twin (a child process, same draws) reads what
     # the split-bf16 test computed instead of spending another minute of host time on the same numbers
     import hashlib, os, tempfile
-    key = hashlib.sha1(open(TP.__file__, "rb").read() + open(__file__, "rb").read()).hexdigest()[:12]
-    cache = os.path.join(tempfile.gettempdir(), f"mm_tkl_rank_oracle_{key}_seed{seed}_{nq}x{C}.npz")
+    # (keyed on the oracle's source AND on the very inputs: the tensors, the packed parameters, the torch version — a change
+    # of the drop-in's parameter draw order or of torch's generator must not meet a stale oracle; per repo, not in /tmp)
+    hsh = hashlib.sha1(open(TP.__file__, "rb").read() + torch.__version__.encode())
+    for t_ in (q_ctx, chunks, cmask.float(), slot.float(), qm, params.detach().cpu().float()):
+        hsh.update(np.ascontiguousarray(t_.detach().cpu().numpy()).tobytes())
+    key = hsh.hexdigest()[:16]
+    cdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "oracle_cache")
+    os.makedirs(cdir, exist_ok=True)
+    cache = os.path.join(cdir, f"mm_tkl_rank_oracle_{key}_seed{seed}_{nq}x{C}.npz")
     ref = {}
     if os.path.exists(cache):
         z = np.load(cache)
