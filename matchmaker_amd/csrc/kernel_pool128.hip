@@ -411,6 +411,218 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conv-KNRM's multi launch, one wavefront per (pair range, DOCUMENT tensor) looping over the query tensors (round 6).
+//
+// The flat XCD-grouped order above gives every (query tensor, document tensor) combination its own wavefront: each block of a
+// document n-gram tensor is streamed by n_mq wavefronts that drift apart — FETCH_SIZE 46.9 GB per Conv-KNRM 3 x 3 launch for
+// 13.7 GB of needed rows (profiles/r05_experiments/conv_knrm_fetch_size_per_launch_form.txt) — and split to bf16 n_mq times.
+// Here a block crosses HBM and the operand split ONCE: the wavefront keeps the n_mq query tiles of its pair as B fragments
+// (AGPRs: 3 x 64 registers at E = 128), splits the block's rows once (64 registers of A fragments), and runs products +
+// RBF epilogue for the query tensors back to back, n_mq sets of running kernel sums in registers.  Same MFMA order, same
+// epilogue as kernel_pool_split128_kernel: every combination's score is the same bits; the partial rows are summed in
+// (i, t) order by the same kp_sum_blocks_kernel.  One wavefront per SIMD (the fragments need the register file).
+// MEASURED (64 x 1000 pairs, Q30 / D200 / E128, same box, round-robin; tools/conv_knrm_ab.sh): FETCH_SIZE 22.5 GB per launch
+// (13.7 GB of document rows + 8.8 GB of query tiles, each read by the three document-tensor wavefronts of its pair) against
+// 47.3 GB — and 9.68 ms against 8.65 ms.  The launch is bound by the 40.5 G RBF evaluations (5 VALU instructions per kernel
+// pair and row: ~5 ms of VALU issue at best), and ONE wavefront per SIMD cannot overlap their latencies the way the two thinner
+// wavefronts of the per-combination form do; saving 25 GB of traffic the HBM was not saturated by buys nothing.  Kept as
+// MM_KP_MULTI_LOOP=1 for A/B runs; the per-combination form stays the default.
+template <int NSL, int K, int NQ>
+__global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NBUF = kS128Nbuf;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int fr = (int)blockIdx.x;
+  const int bx = __builtin_amdgcn_readfirstlane(fr / a.n_md);
+  const int td = __builtin_amdgcn_readfirstlane(fr - bx * a.n_md);          // this wavefront's document tensor
+  const int64_t p0 = (int64_t)bx * a.pairs_per_wave;
+  const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
+  if (p0 >= p1) return;
+  constexpr int E = 64 * NSL;
+  constexpr int RB = E * 4;
+  const int D = a.D, Q = a.Q;
+  const int nblk_tot = (D + 31) >> 5;
+  const int rows_last = D - 32 * (nblk_tot - 1);
+  char* ring = smem;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  float* rdbuf = (float*)(smem + NBUF * kS128Bytes);
+
+  uint32_t voff[kS128Instr], voff_tail[kS128Instr];
+#pragma unroll
+  for (int n = 0; n < kS128Instr; ++n) {
+    const int s = 64 * n + lane;
+    const int row = s >> 4, c = (s & 15) ^ (row & 15);
+    const int row_t = row < rows_last ? row : rows_last - 1;
+    voff[n] = (uint32_t)(row * RB + c * 16);
+    voff_tail[n] = (uint32_t)(row_t * RB + c * 16);
+  }
+  uint32_t aoff[kS128Steps][2];
+#pragma unroll
+  for (int p = 0; p < kS128Steps; ++p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) aoff[p][j] = (uint32_t)(r * 256 + (((4 * p + 2 * h + j) ^ (r & 15)) << 4));
+
+  Rbf rbf;
+  load_rbf<K>(a.mu, a.sigma, a.alpha, nullptr, rbf);
+
+  const char* dbase = (const char*)a.md[td];
+  auto doc_len = [&](int64_t p) -> int {
+    int len = a.dm.len ? (int)sload_u32(a.dm.len, p) : D;
+    return len < 0 ? 0 : (len > D ? D : len);
+  };
+  int64_t pp = p0;
+  int pt = 0, ps = 0, pn = 0;
+  while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+  int pbuf = 0, cbuf = 0, inflight = 0;
+  auto top_up = [&]() {
+    while (pp < p1 && inflight < NBUF) {
+      const char* g = dbase + (pp * (int64_t)D + (int64_t)pt * 32) * RB + ps * 256;
+      if (pt == nblk_tot - 1 && rows_last != 32)
+        issue_slice8(g, voff_tail, lds0 + (uint32_t)pbuf * kS128Bytes);
+      else
+        issue_slice8(g, voff, lds0 + (uint32_t)pbuf * kS128Bytes);
+      pbuf = (pbuf + 1 == NBUF) ? 0 : pbuf + 1;
+      ++inflight;
+      if (++ps == NSL) {
+        ps = 0;
+        if (++pt == pn) {
+          pt = 0;
+          ++pp;
+          while (pp < p1 && (pn = (doc_len(pp) + 31) >> 5) == 0) ++pp;
+        }
+      }
+    }
+  };
+  top_up();
+
+  bf16x8 qhi[NQ][NSL][kS128Steps], qlo[NQ][NSL][kS128Steps];
+  float rq[NQ];
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) rq[iq] = 0.0f;
+  bool qvalid = false;
+  int64_t cur_q = -1;
+  int64_t qi = p0 / a.ppq;
+  int64_t q_left = a.ppq - (p0 - qi * a.ppq);
+
+  for (int64_t pair = p0; pair < p1; ++pair) {
+    if (q_left == 0) {
+      ++qi;
+      q_left = a.ppq;
+    }
+    --q_left;
+    if (qi != cur_q) {
+      cur_q = qi;
+      const int qr = r < Q ? r : Q - 1;
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        const char* qrow = (const char*)a.mq[iq] + (qi * Q + qr) * RB + h * 32;
+        float ss = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+#pragma unroll
+          for (int p = 0; p < kS128Steps; ++p) {
+            const f32x4 x0 = *(const f32x4*)(qrow + s * 256 + p * 64);
+            const f32x4 x1 = *(const f32x4*)(qrow + s * 256 + p * 64 + 16);
+            split8(x0, x1, qhi[iq][s][p], qlo[iq][s][p]);
+            qhi[iq][s][p] = to_agpr(qhi[iq][s][p]);
+            qlo[iq][s][p] = to_agpr(qlo[iq][s][p]);
+            ss += sumsq4(x0) + sumsq4(x1);
+          }
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        rq[iq] = 1.0f / (sqrtf(ss) + 1e-13f);
+      }
+      const int qlen = a.qm.len ? (int)sload_u32(a.qm.len, qi) : Q;
+      qvalid = r < Q && r < qlen;
+      if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
+    }
+    const int len = doc_len(pair);
+    const int nb = (len + 31) >> 5;
+    f32x2 pk2[NQ][kMaxK / 2];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq)
+#pragma unroll
+      for (int k = 0; k < kMaxK / 2; ++k) pk2[iq][k] = f32x2{0.0f, 0.0f};
+
+    for (int t = 0; t < nb; ++t) {
+      // the block's rows: LDS -> registers -> bf16 hi / lo A fragments, ONCE for all query tensors; row norms on the way
+      bf16x8 ah[NSL][kS128Steps], al[NSL][kS128Steps];
+      f32x2 ss2 = {0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NSL; ++s) {
+        top_up();
+        wait_slices8(inflight - 1);
+        const char* buf = ring + cbuf * kS128Bytes;
+        f32x4 x[2 * kS128Steps];
+#pragma unroll
+        for (int p = 0; p < kS128Steps; ++p) {
+          x[2 * p] = *(const f32x4*)(buf + aoff[p][0]);
+          x[2 * p + 1] = *(const f32x4*)(buf + aoff[p][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;      // the slice is in registers: its slot goes back to the producer now
+        --inflight;
+        top_up();
+#pragma unroll
+        for (int p = 0; p < kS128Steps; ++p) {
+          split8(x[2 * p], x[2 * p + 1], ah[s][p], al[s][p]);
+          const f32x2 a0 = {x[2 * p][0], x[2 * p][1]}, a1 = {x[2 * p][2], x[2 * p][3]};
+          const f32x2 b0 = {x[2 * p + 1][0], x[2 * p + 1][1]}, b1 = {x[2 * p + 1][2], x[2 * p + 1][3]};
+          ss2 += a0 * a0;
+          ss2 += a1 * a1;
+          ss2 += b0 * b0;
+          ss2 += b1 * b1;
+        }
+      }
+      float ss = ss2[0] + ss2[1];
+      ss += __shfl_xor(ss, 32, 64);
+      if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      float rdr[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
+        rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
+      }
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+#pragma unroll
+          for (int p = 0; p < kS128Steps; ++p) {
+            acc_hh = mfma_bf16(ah[s][p], qhi[iq][s][p], acc_hh);
+            acc_lh = mfma_bf16(al[s][p], qhi[iq][s][p], acc_lh);
+            acc_xl = mfma_bf16(ah[s][p], qlo[iq][s][p], acc_xl);
+            acc_xl = mfma_bf16(al[s][p], qlo[iq][s][p], acc_xl);
+          }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+        rbf_block<K>(pk2[iq], acc, rdr, rq[iq], va, h, rbf);
+      }
+    }
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+      float pk[kMaxK];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        pk[k] = pk2[iq][k >> 1][k & 1];
+        pk[k] += __shfl_xor(pk[k], 32, 64);
+      }
+      const int y = iq * a.n_md + td;                                  // combination (i, t): its bin weights, its partial row
+      sload_vec<K>(a.w + y * K, rbf.w);
+      const float total = pool_partial<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, -1);
+      if (lane == 0) a.out[(int64_t)y * a.n_pairs + pair] = total;
+    }
+  }
+}
+
 bool kp128_supported(int Q, int D, int E, bool gated) {
   if (Q > 32 || E % 64) return false;
   const int nsl = E / 64;
@@ -502,6 +714,20 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
     const int64_t flat = (groups * a.n_md + 7) / 8 * 8;               // (range, document tensor) slots, whole groups of 8
     return dim3((unsigned)(flat * (a.n_mblk / a.n_md)), 1u);
   };
+  // Conv-KNRM's multi launch at E <= 128 with three query tensors: one wavefront per (pair range, document tensor) looping over
+  // the query tensors (kernel_pool_multi128_kernel): every document block crosses HBM once — and slower, see there (MM_KP_MULTI_LOOP=1: A/B only).
+  if (a.n_md > 0 && !gated && nsl <= 2 && a.n_mblk / a.n_md == 3 && env().kp_multi_loop && !a.pair_q) {
+    const int ldsm = kp128_lds_fixed(1);
+    int64_t groups = (int64_t)kCUs * 4 / a.n_md;
+    if (groups < 1) groups = 1;
+    if (groups > a.n_pairs) groups = a.n_pairs;
+    a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
+    groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
+    const dim3 grid((unsigned)(groups * a.n_md));
+    if (nsl == 1) hipLaunchKernelGGL((kernel_pool_multi128_kernel<1, 11, 3>), grid, dim3(64), ldsm, stream, a);
+    else hipLaunchKernelGGL((kernel_pool_multi128_kernel<2, 11, 3>), grid, dim3(64), ldsm, stream, a);
+    return check_launch("kernel_pool_multi128_kernel");
+  }
   if (occ2 && a.n_md > 0 && !env().kp_multi_2d && env().kp_multi_wg == 1) {
     // one workgroup per (pair range, document tensor), its wavefronts = the query tensors (m_flat = 2).  Wavefront slots per
     // CU: 8 (two per SIMD) in workgroups of n_mq -> 2 x 3 for Conv-KNRM's three n-gram widths

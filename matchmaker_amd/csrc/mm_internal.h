@@ -43,6 +43,9 @@ struct EnvCfg {
   int kp_multi_wg = 0;        // MM_KP_MULTI_WG=1: the multi launch as one workgroup per (pair range, document tensor) with a wavefront per query
                               // tensor and a rate barrier per block, instead of independent workgroups in flat XCD-grouped order (A/B runs:
                               // measured SLOWER, 9.19 vs 8.40 ms for Conv-KNRM 3 x 3 — six wavefronts per CU instead of eight)
+  int kp_multi_loop = 0;      // MM_KP_MULTI_LOOP=1: Conv-KNRM's multi launch as one wavefront per (pair range, document tensor) looping over the query
+                              // tensors (kernel_pool_multi128_kernel, round 6: every document block crosses HBM once — 22.5 GB fetched instead of
+                              // 47.3 — but 9.68 vs 8.65 ms: one wavefront per SIMD cannot hide the RBF epilogue that bounds the launch; A/B runs)
   int kp_multi_2d = 0;        // MM_KP_MULTI_2D=1: Conv-KNRM's multi launch on the 2-D grid of rounds 1-4 instead of the flat XCD-grouped order (A/B runs)
   int kp128_occ = 0;          // MM_KP128_OCC: 0 = choose by shape, 1 / 2 = wavefronts per SIMD of the 64n-wide pooling kernel (A/B runs)
   int tkl_fold_regions = 0;   // MM_TKL_FOLD_REGIONS=1: TKL's region top-k in the last window workgroup of each document (round 4's default) instead of
