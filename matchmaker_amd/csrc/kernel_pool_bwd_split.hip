@@ -141,33 +141,48 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
 
   // ---- LDS-DMA of this wavefront's slice (see BwdGeo) ---------------------------------------------------------------------
   const int rows_last = D - 32 * (dwords - 1);
-  auto issue_block = [&](int b, int NG, int E) {
+  // per block: the two per-lane source offsets (even / odd instruction) of this wavefront's slice, then per granule v the two
+  // instructions that fill its chunks 4v..4v+3
+  auto block_offsets = [&](int b, int E, uint32_t& o0, uint32_t& o1, int& r0, int& r1) {
     const int RB = E * 4;
-    const char* g = db + (int64_t)b * 32 * RB;
     const int rmax = (b == dwords - 1) ? rows_last - 1 : 31;  // rows past D: clamped re-reads of the last row (their G is 0)
-    int r0 = r_ ^ h_, r1 = r0 ^ 2;                            // instruction n, chunk 2n + h: row slot ^ (chunk & 3) = r ^ h ^ 2 (n & 1)
+    r0 = r_ ^ h_;                                             // instruction n, chunk 2n + h: row slot ^ (chunk & 3) = r ^ h ^ 2 (n & 1)
+    r1 = r0 ^ 2;
     r0 = r0 < rmax ? r0 : rmax;
     r1 = r1 < rmax ? r1 : rmax;
-    const uint32_t o0 = (uint32_t)(r0 * RB + (16 * t + 4 * h_) * 4), o1 = (uint32_t)(r1 * RB + (16 * t + 8 + 4 * h_) * 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every LDS read of the slice has returned
+    o0 = (uint32_t)(r0 * RB + (16 * t + 4 * h_) * 4);
+    o1 = (uint32_t)(r1 * RB + (16 * t + 8 + 4 * h_) * 4);
+  };
+  auto issue_granule = [&](int b, int v, int NG, int E, uint32_t o0, uint32_t o1, int r0, int r1) {
+    const int RB = E * 4;
+    const char* g = db + (int64_t)b * 32 * RB;
+    const int gi = t + 4 * v;                                 // (wave-uniform)
+    if (gi < NG) {
 #pragma unroll
-    for (int n = 0; n < Geo::NI; ++n) {
-      const int gi = t + 4 * (n >> 1);                        // granule of the instruction (wave-uniform)
-      if (gi < NG) {
-        uint32_t v = ((n & 1) ? o1 : o0) + (uint32_t)(256 * (n >> 1));
+      for (int odd = 0; odd < 2; ++odd) {
+        uint32_t vo = (odd ? o1 : o0) + (uint32_t)(256 * v);
         if (16 * gi + 16 > E) {                               // the partial last granule: columns past E re-read its last chunk
-          const int col = 16 * gi + 8 * (n & 1) + 4 * h_;     // (finite filler: their query operands are zeros)
-          v = (uint32_t)(((n & 1) ? r1 : r0) * RB + (col < E - 4 ? col : E - 4) * 4);
+          const int col = 16 * gi + 8 * odd + 4 * h_;         // (finite filler: their query operands are zeros)
+          vo = (uint32_t)((odd ? r1 : r0) * RB + (col < E - 4 ? col : E - 4) * 4);
         }
-        glds16(g, v, ds_lds + n * 1024);
+        glds16(g, vo, ds_lds + (2 * v + odd) * 1024);
       }
     }
+  };
+  auto issue_block = [&](int b, int NG, int E) {
+    uint32_t o0, o1;
+    int r0, r1;
+    block_offsets(b, E, o0, o1, r0, r1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every LDS read of the slice has returned
+#pragma unroll
+    for (int v = 0; v < NGW; ++v) issue_granule(b, v, NG, E, o0, o1, r0, r1);
   };
 #if MM_KP_BWD_PHASE_TIMES
   float ph[11] = {0};
   long long t_last = __builtin_readcyclecounter();
 #endif
   if (nb > 0) issue_block(0, NG, E);
+
 
   // ---- per-lane validity of the 4-float windows it squares for the row norms (columns < E) -------------------------------------
   uint32_t nvalid = 0;
@@ -184,9 +199,17 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   Rbf rbf;
   load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
   const float g = MODE ? a.go[pair] : 0.0f;
+  float pkv[K];                                               // MODE 1: the forward's pooled sums of this lane's token
+#pragma unroll
+  for (int k = 0; k < K; ++k) pkv[k] = 1.0f;
   {
     const int e16 = lane & 15, kg = lane >> 4;
     const int rc = r_ < Q ? r_ : Q - 1;
+    if (MODE) {                                               // (same batch of loads as the query rows: one memory round trip)
+      const float* pp = pkq_in + (pair * Q + rc) * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) pkv[k] = pp[k];
+    }
     f32x4 xa[NGW][2];
     float yb[NGW][8];
 #pragma unroll
@@ -245,13 +268,8 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   for (int k = 0; k < K; ++k) pk0[k] = 0.0f;
   if (MODE) {
     // A_ik of token r -> LDS (read back per block: eleven registers less across the block loop), parameter gradients of the pair
-    float lw[K], la[K], av[12], pkv[K];
+    float lw[K], la[K], av[12];
     av[11] = 0.0f;
-    {
-      const float* pp = pkq_in + (pair * Q + (r_ < Q ? r_ : Q - 1)) * K;
-#pragma unroll
-      for (int k = 0; k < K; ++k) pkv[k] = pp[k];
-    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float pk = pkv[k];
@@ -527,21 +545,27 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
         };
         float dvc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (vlast >= 0) load_dv(0, dvc);
-        if (vlast == 0 && b + 1 < nb) issue_block(b + 1, NG, E);
+        // The slice goes back to the LDS-DMA granule by granule: once granule v's column values are in registers (the split
+        // below consumed them, and the grad_d pass is done with the whole slice) its four chunks are refilled with the next
+        // block's — two LDS-DMA instructions per granule between the MFMAs instead of a burst of ten behind one wait (the
+        // burst: 2.0 k cycles per block and wavefront, and the next block's rows requested a whole pass later).
+        uint32_t o0 = 0, o1 = 0;
+        int r0 = 0, r1 = 0;
+        const bool refill = b + 1 < nb;
+        if (refill) block_offsets(b + 1, E, o0, o1, r0, r1);
 #pragma unroll
         for (int v = 0; v < NGW; ++v) {
           if (v <= vlast) {
             float dvn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (v + 1 < NGW && v + 1 <= vlast) {
-              load_dv(v + 1, dvn);
-              if (v + 1 == vlast && b + 1 < nb) {
-                KPS_PH(7);
-                issue_block(b + 1, NG, E);   // the slice's last read has returned (lgkmcnt(0) inside): refill it
-                KPS_PH(10);                  // LDS-DMA issue
-              }
-            }
+            if (v + 1 < NGW && v + 1 <= vlast) load_dv(v + 1, dvn);
             bf16x8 bh, bl;
             split8(f32x4{dvc[0], dvc[1], dvc[2], dvc[3]}, f32x4{dvc[4], dvc[5], dvc[6], dvc[7]}, bh, bl);
+            if (refill) {
+              asm volatile("" : "+v"(bh), "+v"(bl));          // (the refill below is ordered behind the values' arrival)
+              KPS_PH(7);
+              issue_granule(b + 1, v, NG, E, o0, o1, r0, r1);
+              KPS_PH(10);                                     // LDS-DMA issue
+            }
             accq[v][0] = mfma16(bh, gsh0, accq[v][0]);
             accq[v][0] = mfma16(bh, gsl0, accq[v][0]);
             accq[v][0] = mfma16(bl, gsh0, accq[v][0]);
