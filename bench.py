@@ -1094,7 +1094,7 @@ def extra_variants(steps, cpu_budget):
            torch.linspace(-0.014, 0.014, 11, device=dev)]
     res = {}
 
-    def one(name, Qv, Dv, Ev, n_d=1, gate=False, clamp=1e-10, n_q=1, ref="", kern=None):
+    def one(name, Qv, Dv, Ev, n_d=1, gate=False, clamp=1e-10, n_q=1, ref="", kern=None, pats=("r06*variants*pmc*.json",)):
         q = [torch.randn(nq if n_q == 1 and n_d == 1 else B, Qv, Ev, generator=g, device=dev) for _ in range(n_q)]
         d = [torch.randn(B, Dv, Ev, generator=g, device=dev) for _ in range(n_d)]
         q_len = torch.randint(3, Qv + 1, (q[0].shape[0],), generator=g, device=dev).to(torch.int32)
@@ -1118,7 +1118,7 @@ def extra_variants(steps, cpu_budget):
                 "frac": need / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "needed_bytes": need,
                 "frac_padded_bytes": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}
         tr = None
-        for pat in ("r06*variants*pmc*.json", "r06*conv*pmc*.json"):
+        for pat in pats:
             tr = tr or (profile_summary(pat, kern, "_hbm_traffic_bytes_per_dispatch") if kern else None)
         if tr is not None:
             roof["traffic"] = tr[0]
@@ -1130,8 +1130,16 @@ def extra_variants(steps, cpu_budget):
         del q, d
         torch.cuda.empty_cache()
 
+    # MM_BENCH_VARIANTS=a,b: a subset (profiling runs: Conv-KNRM's multi launch and IDCM's ck-small sampler are the SAME kernel
+    # instantiation, so their counters can only be told apart in separate processes)
+    subset = [x for x in os.environ.get("MM_BENCH_VARIANTS", "").split(",") if x]
+    _one = one
+
+    def one(name, *a, **kw):
+        if not subset or name in subset:
+            _one(name, *a, **kw)
     one("knrm", 30, 200, 300, kern="kernel_pool_split_kernel<3, 11, 3, false, false, false, 1>", ref="models/knrm.py:52-84 (alpha = 1, x 0.01 folded into the weights)")
-    one("conv_knrm_3x3", 30, 200, 128, n_d=3, n_q=3, kern="conv_knrm", ref="models/conv_knrm.py:144-170: n_grams^2 = 9 poolings + dense, one launch (pair-per-row)")
+    one("conv_knrm_3x3", 30, 200, 128, n_d=3, n_q=3, kern="kernel_pool_split128_kernel<2, 11, false, 1, 0, 2", pats=("r06*conv_knrm*pmc*.json",), ref="models/conv_knrm.py:144-170: n_grams^2 = 9 poolings + dense, one launch (pair-per-row)")
     one("tk_sparse", 30, 200, 300, gate=True, kern="kernel_pool_split_kernel<3, 11, 3, false, false, true, 1>", ref="published/cikm20_tk_sparse.py:106-146 (stop-word gate)")
     one("idcm_sampler_ck", 30, 64, 768, clamp=1e-4, kern="kernel_pool_split128_kernel<6,", ref="published/sigir21_idcm.py:182-186, sample_context ck (768-d)")
     one("idcm_sampler_ck_small", 30, 64, 128, clamp=1e-4, kern="kernel_pool_split128_kernel<2,", ref="published/sigir21_idcm.py:182-186, sample_context ck-small (128-d)")

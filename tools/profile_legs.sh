@@ -6,7 +6,7 @@
 # per pmc leg additionally FETCH_SIZE / WRITE_SIZE / SQ passes (own runs, --kernel-trace only) -> <leg>_pmc.json
 set -u
 TAG=${1:-r03}
-LEGS=${2:-"headline dropin_forward published_checkpoint maxsim_fp32 all_pairs tk tkl dot_topk eval_batch"}
+LEGS=${2-"headline dropin_forward published_checkpoint maxsim_fp32 all_pairs tk tkl dot_topk eval_batch"}
 PMCL=${3-"headline tk tkl dot_topk all_pairs"}   # "" = no counter passes
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -39,7 +39,7 @@ for L in $PMCL; do
 done
 
 # TKL on full 2,048-token documents (the bench leg runs config 3's own lengths)
-if [ -n "$PMCL" ]; then
+if [ -n "$PMCL" ] && [ -z "${SKIP_TKLFULL:-}" ]; then
 CMD="python tools/bench_tkl.py --full --steps 5"
 rm -rf $O/pmc_tklfull; mkdir -p $O/pmc_tklfull
 rocprofv3 --kernel-trace --stats -d $O/pmc_tklfull/trace -o t -- $CMD > $O/pmc_tklfull/trace.log 2>&1
