@@ -367,7 +367,7 @@ def extra_tk(steps, cpu_budget):
            "dtype": "fp32 (split-bf16 operands: x = hi + lo, 3 bf16 MFMAs hi.hi + lo.hi + hi.lo, fp32 accumulation)", "ms": ms,
            "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by, "flop": B * (2 * Qt * Dt * Et + 2 * (Qt + Dt) * Et),
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r05_tk_trace.json (counters: profiles/r04_tk_pmc.json, kernel unchanged)"}
+           "kernel": "kernel_pool_split_kernel", "profile": "profiles/r06_tk_trace.json, profiles/r06_tk_pmc.json"}
     del q, d
     torch.cuda.empty_cache()
     try:
@@ -442,7 +442,7 @@ def extra_tkl(steps, cpu_budget):
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "needed_bytes": by_needed, "frac_needed_bytes": by_needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> + tkl_region_kernel: the whole mm_tkl_fwd call",
-           "profile": "profiles/r05_tkl_pmc.json, profiles/r05_tkl_trace.json (full documents: profiles/r05_tklfull_pmc.json)"}
+           "profile": "profiles/r06_tkl_pmc.json, profiles/r06_tkl_trace.json (full documents: profiles/r06_tklfull_pmc.json)"}
     try:
         if not LEAN:
             out["exact_f32_mfma"] = tkl_exact_f32_subprocess()
@@ -543,7 +543,7 @@ def extra_maxsim_fp32(steps, cpu_budget):
            "dtype": "fp32 (three-term split-bf16 operands x = hi + lo + c, 6 bf16 MFMAs per K step, fp32 accumulation)",
            "ms": ms, "pairs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-           "kernel": "kernel_pool_split128_kernel<MX, two wavefronts per SIMD> (csrc/kernel_pool128.hip)", "profile": "profiles/r05_maxsim_fp32_trace.json, profiles/r05_maxsim_fp32_pmc.json"}
+           "kernel": "kernel_pool_split128_kernel<MX, two wavefronts per SIMD> (csrc/kernel_pool128.hip)", "profile": "profiles/r06_maxsim_fp32_trace.json, profiles/r06_maxsim_fp32_pmc.json"}
     if cpu_budget > 0:
         from oracle import torch_port as TP
         n = 1000
@@ -805,7 +805,7 @@ def extra_dot_topk(steps, cpu_budget):
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
            "kernel": "dot_stream_kernel (sample + filter) + sample_tau_kernel + topk_rows_kernel (whole mm_dot_topk_fwd call, wall clock)",
-           "profile": "profiles/r05_dot_topk_trace.json (counters: profiles/r03_dot_topk_pmc.json, kernel unchanged)"}
+           "profile": "profiles/r06_dot_topk_trace.json (counters: profiles/r03_dot_topk_pmc.json, kernel unchanged; power / clock: profiles/r06_experiments/dot_topk_power_trace.txt)"}
     if not LEAN:
         # what the vendor GEMM reaches on THIS box: the same product (one 262,144-passage slice, fp16 scores written, no
         # top-k) and a square 8192^3 — the matrix rate the board's power budget allows, next to the 2.5 PFLOP/s nominal peak
@@ -1000,7 +1000,7 @@ def extra_train_step(steps, cpu_budget):
         torch.cuda.empty_cache()
     res["note"] = ("step = forward + backward of the scoring block alone (encoders / contextualisers are PyTorch on both sides and "
                    "not part of it); TKL's backward recomputes only the <= 15 windows per document that carry gradient")
-    res["profile"] = "profiles/r05_train_step_trace.json"
+    res["profile"] = "profiles/r06_train_step_trace.json (the pooling backward alone: profiles/r06_tk_bwd_trace.json, r06_tk_bwd_pmc.json, r06_tk_bwd_phases.txt)"
     return res
 
 
@@ -1039,7 +1039,7 @@ def extra_ragged_aggregate(steps, cpu_budget):
                         "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "one_query_1000_candidates_us": 1e3 * ms1,
            "kernel": "maxsim_stream_kernel<RAG> (CSR ranges into the store, no gather, no padding)",
-           "profile": "profiles/r05_ragged_aggregate_trace.json"}
+           "profile": "profiles/r06_ragged_aggregate_trace.json"}
     if not LEAN:
         # the reference's loop: one forward_aggregation per candidate (dense_retrieval.py:400-410), 1000 calls for one query
         m = ColBERT.__new__(ColBERT)
