@@ -392,6 +392,49 @@ def test_rerank_helpers_follow_eval_py_and_core_metrics():
         assert mod.unrolled_to_ranked_result(got) == ranked
 
 
+def test_grouped_evaluation_host_logic_groups_by_shape_and_keeps_arrival_order():
+    """rerank.evaluate_batches(score_group=N) — the host side of the batched scoring entry (mm_maxsim_fwd_batched): the encoder is
+    called batch by batch, score_batches once per group of <= N consecutive batches of ONE shape (a shape change closes the
+    group early: eval.py pads every batch to its own longest sequence), the results are the batch-by-batch loop's, in arrival
+    order; a model without score_batches, secondary output, or graph=True keep the per-batch route."""
+    import torch
+    from matchmaker_amd import rerank
+    calls = []
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward_representation(self, tokens, sequence_type=None):
+            return tokens["input_ids"].float().unsqueeze(-1)
+
+        def score_batches(self, batches):
+            calls.append([tuple(q.shape[1:]) + tuple(d.shape[1:]) for q, d, _, _ in batches])
+            return [d.sum((1, 2)) - q.sum((1, 2)) for q, d, _, _ in batches]
+
+        def forward(self, query, document, use_fp16=True, output_secondary_output=False):
+            s = document["input_ids"].float().sum(-1) - query["input_ids"].float().sum(-1)
+            return (s, {}) if output_secondary_output else s
+
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for b, (n, Lq, Ld) in enumerate([(5, 4, 6)] * 5 + [(5, 3, 6)] + [(5, 4, 6)] * 2 + [(2, 4, 6)]):
+        mk = lambda L: {"input_ids": torch.randint(0, 3, (n, L), generator=g), "attention_mask": torch.ones(n, L, dtype=torch.long)}
+        batches.append({"query_tokens": mk(Lq), "doc_tokens": mk(Ld), "query_id": [f"q{(b * 5 + i) // 7}" for i in range(n)],
+                        "doc_id": [f"d{b}_{i}" for i in range(n)]})
+    want = rerank.evaluate_batches(Model(), batches, use_fp16=False, device="cpu")
+    assert not calls
+    got = rerank.evaluate_batches(Model(), batches, use_fp16=False, device="cpu", score_group=4)
+    assert got == want
+    # nine batches: four, then one alone (the fifth; the sixth has another shape), the odd shape alone, then the last three
+    assert [len(c) for c in calls] == [4, 1, 1, 3]
+    assert all(len(set(c)) == 1 for c in calls)
+    calls.clear()
+    assert rerank.evaluate_batches(Model(), batches, use_fp16=False, device="cpu", score_group=4, output_secondary_output=True) == want
+    assert not calls                                         # secondary output: the per-batch route
+
+
 @pytest.mark.parametrize("Bq,Bd,NQT", [(32, 32, 4), (1030, 37, 4), (3, 5, 2), (2, 1, 4), (1024, 1024, 4), (7, 20000, 4), (513, 9, 2),
                                        (130, 70, 4)])
 def test_tiled_all_pairs_work_map_covers_every_pair_once(Bq, Bd, NQT):
