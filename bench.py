@@ -902,8 +902,13 @@ def extra_train_step(steps, cpu_budget):
             q.grad = d.grad = None
             with torch.autocast("cuda", dtype=torch.float16):
                 TP.maxsim_forward(q, d, qm, dm).backward(go)
-        leg("colbert_fp16_autocast_q32_d180_e128", B, c_fwd, c_native, c_eager, B * ((D + Q) * E * 2 + 8 * (D + Q) + 4),
-            B * (D + Q) * E * 2, steps, bwd_op=lambda: ops.maxsim_bwd(q, d, qm, dm, go, grad_dtype=q.dtype))
+        # bytes: forward and backward each read the 32-row document blocks below the (MSMARCO-shaped) lengths — the kernels skip the
+        # rest — + the query tiles and int64 masks; the backward writes EVERY gradient row (zeros past the length)
+        rows_c = int((((dm.sum(1) + 31) // 32) * 32).clamp(max=D).sum())
+        small_c = B * (Q * E * 2 + 8 * (D + Q) + 4)
+        leg("colbert_fp16_autocast_q32_d180_e128", B, c_fwd, c_native, c_eager, rows_c * E * 2 + small_c,
+            B * (D + Q) * E * 2, steps, bwd_op=lambda: ops.maxsim_bwd(q, d, qm, dm, go, grad_dtype=q.dtype),
+            fwd_bytes_padded=B * D * E * 2 + small_c)
         del q, d
 
         # ---- TK pooling (tk.yaml: fp32, Q = 20 / D = 200 / dim = 300)
