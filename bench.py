@@ -866,6 +866,34 @@ def extra_train_step(steps, cpu_budget):
                             "frac": by / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if fwd_bytes_padded is not None:     # the kernels skip the 32-row blocks past a document's length: `frac` prices the rows they need
             row["roofline"]["frac_padded_bytes"] = (2 * fwd_bytes_padded + grad_bytes) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if B <= 2048 and bwd_op is not None:
+            # The step's two operator calls (forward, backward — no autograd engine: capturing loss.backward() is not something
+            # train.py does either) captured once into a hipGraph and replayed: what the DEVICE needs for them back to back.  In
+            # train.py these launches queue behind the encoder's, so this — not the host-bound eager interval above — is what a
+            # small batch adds to an iteration.  (Not `step_us`: the reference's loop is eager, and so is this leg's headline.)
+            try:
+                def both():
+                    fwd()
+                    bwd_op()
+                with torch.no_grad():
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(3):
+                            both()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        both()
+                    g_ms = gpu_time_ms(graph.replay, n_timed)
+                row["graphed_kernels_us"] = 1e3 * g_ms
+                row["graphed_kernels_over_forward"] = g_ms / f_ms
+                del graph
+            except Exception as e:
+                row["graphed_kernels_us"] = None
+                row["graphed_kernels_error"] = repr(e)[:200]
+                torch.cuda.synchronize()
         try:
             if LEAN:
                 raise RuntimeError("skipped (--lean: the profiled run holds the native kernels only)")

@@ -272,6 +272,9 @@ int mm_kernel_pool_multi_fwd(const void* const* q_list, int n_q, const void* con
  *   grad_alpha, grad_w [n_pairs, K]: per-pair contributions (sum over pairs on the host side:
  *   deterministic, no atomics). */
 size_t mm_kernel_pool_bwd_workspace_bytes(int64_t n_pairs, int Q, int D, int q_mask_kind, int d_mask_kind);
+/* ... plus the partial grad_q buffers of a small batch (<= 128 pairs: several workgroups share a pair's document blocks and a
+ * combine kernel finishes grad_q).  Optional: with the smaller workspace above each pair gets one workgroup. */
+size_t mm_kernel_pool_bwd_workspace_bytes2(int64_t n_pairs, int Q, int D, int E, int q_mask_kind, int d_mask_kind);
 
 int mm_kernel_pool_bwd(const void* q, const void* d,
                        const void* q_mask, int q_mask_kind,

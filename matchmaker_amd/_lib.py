@@ -49,6 +49,7 @@ SIGNATURES = {
     "mm_kernel_pool_multi_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _c.c_float, _vp, _i64, _i64,
                                       _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_bwd_workspace_bytes": (_sz, [_i64, _i, _i, _i, _i]),
+    "mm_kernel_pool_bwd_workspace_bytes2": (_sz, [_i64, _i, _i, _i, _i, _i]),
     "mm_kernel_pool_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                 _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_dot_topk_workspace_bytes": (_sz, [_i64, _i, _i]),

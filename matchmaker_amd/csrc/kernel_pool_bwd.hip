@@ -687,6 +687,14 @@ extern "C" size_t mm_kernel_pool_bwd_workspace_bytes(int64_t n_pairs, int Q, int
   return ((masks + 255) & ~(size_t)255) + kp_bwd_split_ws_bytes(n_pairs, Q, 16);
 }
 
+// ... + the partial grad_q buffers of a small batch, whose pairs are shared by several workgroups each (kp_bwd_split_launch;
+// 0 bytes from 129 pairs on).  A workspace of the size above still works: one workgroup per pair then.
+extern "C" size_t mm_kernel_pool_bwd_workspace_bytes2(int64_t n_pairs, int Q, int D, int E, int q_mask_kind, int d_mask_kind) {
+  const size_t base = mm_kernel_pool_bwd_workspace_bytes(n_pairs, Q, D, q_mask_kind, d_mask_kind);
+  const size_t part = (E > 0 && kp_bwd_split_supported(Q, E, 11)) ? kp_bwd_split_part_bytes(n_pairs, Q, D, E) : 0;
+  return ((base + 255) & ~(size_t)255) + (part ? part + 256 : 0);
+}
+
 extern "C" int mm_kernel_pool_ex_bwd2(const void* q, const void* d, const void* q_mask, int q_mask_kind, const void* d_mask,
                                       int d_mask_kind, const float* d_gate, const float* mu, const float* sigma,
                                       const float* alpha, const float* w, float clamp_min, const float* pooled,
@@ -712,8 +720,7 @@ extern "C" int mm_kernel_pool_ex_bwd2(const void* q, const void* d, const void* 
     a.gq = grad_q; a.gd = grad_d; a.galpha = grad_alpha; a.gw = grad_w; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E; a.K = K;
     char* ws = (char*)workspace;
     size_t left = workspace ? workspace_bytes : 0;
-    if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
-    if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+    if (int e = resolve_mask_pair(q_mask, q_mask_kind, n_pairs, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
     float* pkq_ws = nullptr;
     if (!pooled) {
       const size_t skip = (size_t)(-(intptr_t)ws) & 255, need = kp_bwd_split_ws_bytes(n_pairs, Q, K);
@@ -721,8 +728,12 @@ extern "C" int mm_kernel_pool_ex_bwd2(const void* q, const void* d, const void* 
         return set_error(MM_EINVAL, "kernel_pool_bwd: workspace too small for the pooled sums (%zu bytes left, %zu needed; "
                                     "mm_kernel_pool_bwd_workspace_bytes)", left, skip + need);
       pkq_ws = (float*)(ws + skip);
+      ws += skip + need;
+      left -= skip + need;
     }
-    return kp_bwd_split_launch(a, pooled, pkq_ws, stream);
+    const size_t pskip = (size_t)(-(intptr_t)ws) & 255;
+    float* part = left > pskip ? (float*)(ws + pskip) : nullptr;
+    return kp_bwd_split_launch(a, pooled, pkq_ws, part, part ? left - pskip : 0, stream);
   }
   // the exact-f32 tiled kernel whenever its tiles fit; the per-element kernel otherwise
   {
@@ -737,8 +748,7 @@ extern "C" int mm_kernel_pool_ex_bwd2(const void* q, const void* d, const void* 
       a.gq = grad_q; a.gd = grad_d; a.galpha = grad_alpha; a.gw = grad_w; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E; a.K = K;
       char* ws = (char*)workspace;
       size_t left = workspace ? workspace_bytes : 0;
-      if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
-      if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+      if (int e = resolve_mask_pair(q_mask, q_mask_kind, n_pairs, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
       auto go = [&](auto kern) {
         if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
         hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3((unsigned)nthr), tl, stream, a, Dpad);
@@ -771,8 +781,7 @@ extern "C" int mm_kernel_pool_ex_bwd2(const void* q, const void* d, const void* 
   a.gq = grad_q; a.gd = grad_d; a.galpha = grad_alpha; a.gw = grad_w; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E; a.K = K;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
-  if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
-  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (int e = resolve_mask_pair(q_mask, q_mask_kind, n_pairs, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kernel_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kernel_pool_bwd_kernel, dim3((unsigned)n_pairs), dim3(256), lds, stream, a, DT);

@@ -112,7 +112,10 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   const int tid = threadIdx.x;
   const int t = __builtin_amdgcn_readfirstlane(tid >> 6);     // wavefront = granule owner = row-quarter owner
   const int lane = tid & 63, r_ = lane & 31, h_ = lane >> 5;
-  const int64_t pair = blockIdx.x;
+  // small batches: S workgroups per pair, this one takes the blocks sp, sp + S, ... (S = 1: the whole pair)
+  const int S = MODE ? a.nsplit : 1;
+  const int64_t pair = S > 1 ? (int64_t)(blockIdx.x / (unsigned)S) : (int64_t)blockIdx.x;
+  const int sp = S > 1 ? (int)(blockIdx.x - (unsigned)pair * (unsigned)S) : 0;
   const int Q_ = a.Q, D = a.D, E_ = a.E;
   const int NG_ = (E_ + 15) >> 4;                             // 16-column granules of E; wavefront t owns t, t + 4, ...
   const int Q = Q_, E = E_, NG = NG_;
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   float ph[11] = {0};
   long long t_last = __builtin_readcyclecounter();
 #endif
-  if (nb > 0) issue_block(0, NG, E);
+  if (sp < nb) issue_block(sp, NG, E);
 
 
   // ---- per-lane validity of the 4-float windows it squares for the row norms (columns < E) -------------------------------------
@@ -278,11 +281,11 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
       lw[k] = qvalid ? __logf(fmaxf(rbf.alpha[k] * pk, a.clamp_min)) : 0.0f;
       la[k] = live ? rbf.w[k] / rbf.alpha[k] : 0.0f;
     }
-    if (t == 0) {
-      if (h_ == 0) {
+    if (t == 0 && h_ == 0) {
 #pragma unroll
-        for (int v = 0; v < 3; ++v) *(f32x4*)(AK + r_ * 12 + 4 * v) = f32x4{av[4 * v], av[4 * v + 1], av[4 * v + 2], av[4 * v + 3]};
-      }
+      for (int v = 0; v < 3; ++v) *(f32x4*)(AK + r_ * 12 + 4 * v) = f32x4{av[4 * v], av[4 * v + 1], av[4 * v + 2], av[4 * v + 3]};
+    }
+    if (t == 0 && sp == 0) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float sw = half_sum_last(lw[k]), sa = half_sum_last(la[k]);
@@ -303,7 +306,7 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   float* gd = a.gd + pair * D * (int64_t)E;
   const int Pq = 3 * 8 * 32;                                  // floats per quarter of P
 
-  for (int b = 0; b < nb; ++b) {
+  for (int b = sp; b < nb; b += S) {
     const int j0 = 32 * b;
     // lane coordinates behind an opaque copy: the per-lane LDS / global addresses derived from them are then computed inside the
     // block, not once before the loop and kept in (spilled) registers across it (the lesson of kernel_pool_bwd.hip / tkl_bwd.hip)
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
         for (int x = 0; x < 4; ++x) dst[x * 32] = acc[4 * tq + x];
       }
     }
-    if (MODE == 0 && b + 1 < nb) issue_block(b + 1, NG, E);          // pooling pass: the slice is consumed
+    if (MODE == 0 && b + S < nb) issue_block(b + S, NG, E);          // pooling pass: the slice is consumed
     KPS_PH(3);                                                // cosines + publish
     lds_barrier();                                            // barrier 1: partial tiles and norms are in LDS
     KPS_PH(4);                                                // barrier 1
@@ -551,8 +554,8 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
         // burst: 2.0 k cycles per block and wavefront, and the next block's rows requested a whole pass later).
         uint32_t o0 = 0, o1 = 0;
         int r0 = 0, r1 = 0;
-        const bool refill = b + 1 < nb;
-        if (refill) block_offsets(b + 1, E, o0, o1, r0, r1);
+        const bool refill = b + S < nb;
+        if (refill) block_offsets(b + S, E, o0, o1, r0, r1);
 #pragma unroll
         for (int v = 0; v < NGW; ++v) {
           if (v <= vlast) {
@@ -563,7 +566,7 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
             if (refill) {
               asm volatile("" : "+v"(bh), "+v"(bl));          // (the refill below is ordered behind the values' arrival)
               KPS_PH(7);
-              issue_granule(b + 1, v, NG, E, o0, o1, r0, r1);
+              issue_granule(b + S, v, NG, E, o0, o1, r0, r1);
               KPS_PH(10);                                     // LDS-DMA issue
             }
             accq[v][0] = mfma16(bh, gsh0, accq[v][0]);
@@ -603,7 +606,7 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   }
 
   // ---- rows past the last real block: zeros (every byte of grad_d is written by this launch) -------------------------------
-  {
+  if (sp == 0) {
     const int64_t z0 = (int64_t)nb * 32 * E, z1 = (int64_t)D * E;
     for (int64_t idx = z0 + 4 * tid; idx < z1; idx += 1024) *(f32x4*)(gd + idx) = f32x4{0, 0, 0, 0};
     if (GATE && a.gdw)
@@ -615,8 +618,28 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
     lds_barrier();                                            // (LDS only: the last block's gradient stores stay in flight)
     const float v = sqacc + __shfl_xor(sqacc, 32, 64);
     if (h == 0) R[t * 32 + r] = v;
-    // this lane's 16-byte pieces of q (unconditional, clamped): in flight across the two barriers
     const int e16 = lane & 15, kg = lane >> 4;
+    if (S > 1) {
+      // this workgroup's share of the pair: raw grad_q accumulators + its own-direction sums (+ the query norms once) -> `part`
+      float* pw = a.part + (pair * S + sp) * ((int64_t)Q * E + 96);
+#pragma unroll
+      for (int v2 = 0; v2 < NGW; ++v2) {
+        const int col = 16 * (t + 4 * v2) + 4 * kg;
+        if (t + 4 * v2 < NG && col < E) {
+          if (e16 < Q) *(f32x4*)(pw + (uint32_t)(e16 * E + col)) = accq[v2][0];
+          if (16 + e16 < Q) *(f32x4*)(pw + (uint32_t)((16 + e16) * E + col)) = accq[v2][1];
+        }
+      }
+      lds_barrier();
+      if (tid < 32) {
+        float* tail = pw + (int64_t)Q * E;
+        tail[tid] = ((R[tid] + R[32 + tid]) + R[64 + tid]) + R[96 + tid];
+        tail[32 + tid] = RQ[tid];
+        tail[64 + tid] = NQ[tid];
+      }
+      return;
+    }
+    // this lane's 16-byte pieces of q (unconditional, clamped): in flight across the two barriers
     f32x4 qv[NGW][2];
 #pragma unroll
     for (int v2 = 0; v2 < NGW; ++v2) {
@@ -651,29 +674,92 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
 #endif
 }
 
+// grad_q of a pair whose blocks were shared by S <= 8 workgroups: the partial accumulators and own-direction sums in workgroup
+// order (deterministic), then the norm's chain rule as in the one-workgroup epilogue.  One 16-byte piece of grad_q per lane,
+// every load of it issued before the first use (the launch is a latency chain otherwise: 10 us for 64 pairs).
+__global__ void __launch_bounds__(256) kp_bwd_combine_kernel(const KpBwdArgs a) {
+  const int Q = a.Q, E = a.E, S = a.nsplit, E4 = E >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.n_pairs * Q * E4) return;
+  const int64_t row = idx / E4;                                // pair * Q + i
+  const int c = 4 * (int)(idx - row * E4);
+  const int64_t pair = row / Q;
+  const int i = (int)(row - pair * Q);
+  const int64_t stride = (int64_t)Q * E + 96;
+  const float* pw = a.part + pair * S * stride;
+  f32x4 acc[8];
+  float sq[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float* ps = pw + (s < S ? s : 0) * stride;
+    acc[s] = *(const f32x4*)(ps + i * E + c);
+    sq[s] = ps[(int64_t)Q * E + i];
+  }
+  const float rq = pw[(int64_t)Q * E + 32 + i], nq = pw[(int64_t)Q * E + 64 + i];
+  const f32x4 qv = *(const f32x4*)(a.q + row * E + c);
+  f32x4 sum = acc[0];
+  float ssq = sq[0];
+#pragma unroll
+  for (int s = 1; s < 8; ++s)
+    if (s < S) {
+      sum += acc[s];
+      ssq += sq[s];
+    }
+  const float f2 = nq > 0.0f ? ssq * rq / nq : 0.0f;
+  *(f32x4*)(a.gq + row * E + c) = sum * rq - qv * f2;
+}
+
 bool kp_bwd_split_supported(int Q, int E, int K) { return Q >= 1 && Q <= 32 && K == 11 && E >= 4 && !(E & 3) && E <= 320; }
 
 size_t kp_bwd_split_ws_bytes(int64_t n_pairs, int Q, int K) { return (size_t)n_pairs * Q * K * sizeof(float); }
 
+// Small batches — batch_size_train 32 x 2 = 64 pairs is what the reference trains with (defaults.yaml:114) — leave most of the
+// 512 workgroup slots empty and a pair's seven blocks in ONE workgroup are a serial chain (66 us at 64 pairs): S workgroups
+// share a pair's blocks (MM_KP_BWD_NSPLIT forces S; 0 = by batch size), never more than it has blocks.
+// Measured (ragged MSMARCO lengths, D = 200; gradient launch + combine launch, us): 64 pairs 42.7 -> 22.3 + 4.8; 128 pairs
+// 44.3 -> 29.9 + 5.2 (S = 4); 192 / 256 pairs no gain with S = 2 (45.6 / 49 vs 45.6 / 48) -> one workgroup per pair from 129 on.
+int kp_bwd_split_nsplit(int64_t n_pairs, int D) {
+  const int nb = (D + 31) >> 5;
+  int S = env().kp_bwd_nsplit > 0 ? (env().kp_bwd_nsplit > 8 ? 8 : env().kp_bwd_nsplit) : (n_pairs <= 128 ? 4 : 1);
+  return S < nb ? S : (nb > 0 ? nb : 1);
+}
+
+size_t kp_bwd_split_part_bytes(int64_t n_pairs, int Q, int D, int E) {
+  const int S = kp_bwd_split_nsplit(n_pairs, D);
+  return S > 1 ? (size_t)n_pairs * S * ((size_t)Q * E + 96) * sizeof(float) : 0;
+}
+
 template <int NGW>
 static int launch_ngw(const KpBwdArgs& a, const float* pkq_in, float* pkq_ws, hipStream_t stream) {
   const size_t lds = BwdGeo<NGW>::LDS;
-  const dim3 grid((unsigned)a.n_pairs), block(256);
-  auto go = [&](auto kern, const float* pin, float* pout) {
+  const dim3 block(256);
+  auto go = [&](auto kern, const float* pin, float* pout, unsigned wgs) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, a, pin, pout);
+    hipLaunchKernelGGL(kern, dim3(wgs), block, lds, stream, a, pin, pout);
   };
+  const unsigned np = (unsigned)a.n_pairs;
   if (!pkq_in) {
-    a.dw ? go(kp_bwd_split_kernel<0, true, NGW>, nullptr, pkq_ws) : go(kp_bwd_split_kernel<0, false, NGW>, nullptr, pkq_ws);
+    a.dw ? go(kp_bwd_split_kernel<0, true, NGW>, nullptr, pkq_ws, np) : go(kp_bwd_split_kernel<0, false, NGW>, nullptr, pkq_ws, np);
     if (int e = check_launch("kp_bwd_split_kernel<pool>")) return e;
     pkq_in = pkq_ws;
   }
-  a.dw ? go(kp_bwd_split_kernel<1, true, NGW>, pkq_in, nullptr) : go(kp_bwd_split_kernel<1, false, NGW>, pkq_in, nullptr);
-  return check_launch("kp_bwd_split_kernel");
+  a.dw ? go(kp_bwd_split_kernel<1, true, NGW>, pkq_in, nullptr, np * (unsigned)a.nsplit)
+       : go(kp_bwd_split_kernel<1, false, NGW>, pkq_in, nullptr, np * (unsigned)a.nsplit);
+  if (int e = check_launch("kp_bwd_split_kernel")) return e;
+  if (a.nsplit > 1) {
+    const int64_t pieces = a.n_pairs * a.Q * (a.E >> 2);
+    hipLaunchKernelGGL(kp_bwd_combine_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, a);
+    return check_launch("kp_bwd_combine_kernel");
+  }
+  return MM_OK;
 }
 
-int kp_bwd_split_launch(const KpBwdArgs& a, const float* pkq_in, float* pkq_ws, hipStream_t stream) {
+int kp_bwd_split_launch(const KpBwdArgs& a0, const float* pkq_in, float* pkq_ws, float* part, size_t part_bytes, hipStream_t stream) {
   if (!pkq_in && !pkq_ws) return set_error(MM_EINVAL, "kernel_pool_bwd: no pooled sums and no workspace for them");
+  KpBwdArgs a = a0;
+  a.nsplit = kp_bwd_split_nsplit(a.n_pairs, a.D);
+  a.part = part;
+  if (a.nsplit > 1 && (!part || part_bytes < kp_bwd_split_part_bytes(a.n_pairs, a.Q, a.D, a.E))) a.nsplit = 1;   // (an old-size workspace: one workgroup per pair)
   const int NG = (a.E + 15) >> 4;
   if (NG <= 8) return launch_ngw<2>(a, pkq_in, pkq_ws, stream);
   return launch_ngw<5>(a, pkq_in, pkq_ws, stream);

@@ -25,6 +25,11 @@ struct KpBwdArgs {
   float* gw;      // [n_pairs, K]
   int64_t n_pairs;
   int Q, D, E, K;
+  // small batches (kernel_pool_bwd_split.hip): S > 1 workgroups per pair, workgroup s takes the blocks s, s + S, ... and leaves its
+  // share of grad_q (raw accumulators [Q][E]) + of the own-direction sums (+ workgroup 0: 1 / (|q| + tiny), |q|) in `part`:
+  // [n_pairs][S][Q * E + 96] floats; kp_bwd_combine_kernel finishes grad_q
+  int nsplit;
+  float* part;
 };
 
 __device__ __forceinline__ bool mask_bit(const PackedMask& m, int64_t row, int words, int pos, int L) {
@@ -40,6 +45,9 @@ __device__ __forceinline__ constexpr int mrow(int i) { return (i & 3) + 8 * (i >
 // (NULL: a pooling pre-pass of the same kernel writes them to pkq_ws first — the document then crosses HBM twice).
 bool kp_bwd_split_supported(int Q, int E, int K);
 size_t kp_bwd_split_ws_bytes(int64_t n_pairs, int Q, int K);
-int kp_bwd_split_launch(const KpBwdArgs& a, const float* pkq_in, float* pkq_ws, hipStream_t stream);
+// workgroups per pair the launch would use for n_pairs (1 from 129 pairs on), and the bytes of the partial buffer that needs
+int kp_bwd_split_nsplit(int64_t n_pairs, int D);
+size_t kp_bwd_split_part_bytes(int64_t n_pairs, int Q, int D, int E);
+int kp_bwd_split_launch(const KpBwdArgs& a, const float* pkq_in, float* pkq_ws, float* part, size_t part_bytes, hipStream_t stream);
 
 }  // namespace mm

@@ -1177,8 +1177,7 @@ extern "C" int mm_maxsim_bwd(const void* q, const void* d, const void* q_mask, i
   a.q = q; a.d = d; a.go = grad_out; a.gq = grad_q; a.gd = grad_d; a.n_pairs = n_pairs; a.Q = Q; a.D = D; a.E = E;
   char* ws = (char*)workspace;
   size_t left = workspace ? workspace_bytes : 0;
-  if (int e = resolve_mask(q_mask, q_mask_kind, n_pairs, Q, &ws, &left, stream, &a.qm)) return e;
-  if (int e = resolve_mask(d_mask, d_mask_kind, n_pairs, D, &ws, &left, stream, &a.dm)) return e;
+  if (int e = resolve_mask_pair(q_mask, q_mask_kind, n_pairs, Q, &a.qm, d_mask, d_mask_kind, n_pairs, D, &a.dm, &ws, &left, stream)) return e;
   if (((uintptr_t)grad_q | (uintptr_t)grad_d) & 15) return set_error(MM_EINVAL, "maxsim_bwd: gradients must be 16-byte aligned");
   const dim3 grid((unsigned)n_pairs), block(256);
   size_t lds = (size_t)Q * 4 + 2 * 128 * 4;

@@ -34,7 +34,7 @@ struct Api {
   decltype(&mm_kernel_pool_ex_fwd2) kp_fwd = nullptr;
   decltype(&mm_kernel_pool_ex_bwd2) kp_bwd = nullptr;
   decltype(&mm_kernel_pool_workspace_bytes) kp_fwd_ws = nullptr;
-  decltype(&mm_kernel_pool_bwd_workspace_bytes) kp_bwd_ws = nullptr;
+  decltype(&mm_kernel_pool_bwd_workspace_bytes2) kp_bwd_ws = nullptr;
   decltype(&mm_last_error) last_error = nullptr;
   decltype(&mm_abi_version) abi = nullptr;
 } api;
@@ -53,7 +53,7 @@ void init(const std::string& lib_path) {
   MM_SYM(kp_fwd, mm_kernel_pool_ex_fwd2);
   MM_SYM(kp_bwd, mm_kernel_pool_ex_bwd2);
   MM_SYM(kp_fwd_ws, mm_kernel_pool_workspace_bytes);
-  MM_SYM(kp_bwd_ws, mm_kernel_pool_bwd_workspace_bytes);
+  MM_SYM(kp_bwd_ws, mm_kernel_pool_bwd_workspace_bytes2);
   MM_SYM(last_error, mm_last_error);
   MM_SYM(abi, mm_abi_version);
 #undef MM_SYM
@@ -232,7 +232,8 @@ class KernelPool : public torch::autograd::Function<KernelPool> {
     const int qkind = (int)ctx->saved_data["qkind"].toInt(), dkind = (int)ctx->saved_data["dkind"].toInt();
     const int64_t B = d.size(0), Q = q.size(1), D = d.size(1), E = d.size(2), K = mu.numel();
     at::Tensor gq = at::empty_like(q), gd = at::empty_like(d);
-    at::Tensor ga = at::zeros({B, K}, q.options()), gw = at::zeros({B, K}, q.options());
+    at::Tensor gaw = at::zeros({2, B, K}, q.options());   // per-pair rows of grad_alpha, grad_w: one memset, one sum
+    at::Tensor ga = gaw.select(0, 0), gw = gaw.select(0, 1);
     at::Tensor gg = gate.defined() ? at::zeros({B, D}, q.options()) : at::Tensor();
     if (B > 0) {
       at::Tensor go = grads[0].reshape({-1});
@@ -241,7 +242,7 @@ class KernelPool : public torch::autograd::Function<KernelPool> {
       go = go.contiguous();
       TORCH_CHECK(go.numel() == B, "mm_autograd: grad_out has ", go.numel(), " elements for ", B, " pairs");
       const c10::DeviceGuard guard(q.device());
-      const size_t wsb = api.kp_bwd_ws(B, (int)Q, (int)D, qkind, dkind);
+      const size_t wsb = api.kp_bwd_ws(B, (int)Q, (int)D, (int)E, qkind, dkind);
       at::Tensor ws = wsb ? at::empty({(int64_t)wsb}, q.options().dtype(at::kByte)) : at::Tensor();
       void* stream = c10::hip::getCurrentHIPStream(q.device().index()).stream();
       check_rc(api.kp_bwd(q.data_ptr(), d.data_ptr(), qk.defined() ? qk.data_ptr() : nullptr, qkind, dk.defined() ? dk.data_ptr() : nullptr,
@@ -253,8 +254,9 @@ class KernelPool : public torch::autograd::Function<KernelPool> {
                "mm_kernel_pool_ex_bwd2");
     }
     // per-pair parameter rows -> one deterministic sum on the device, in the parameters' own shapes
-    at::Tensor gas = ga.sum(0).reshape(ctx->saved_data["alpha_shape"].toIntVector());
-    at::Tensor gws = gw.sum(0).reshape(ctx->saved_data["w_shape"].toIntVector());
+    const at::Tensor sums = gaw.sum(1);
+    at::Tensor gas = sums.select(0, 0).reshape(ctx->saved_data["alpha_shape"].toIntVector());
+    at::Tensor gws = sums.select(0, 1).reshape(ctx->saved_data["w_shape"].toIntVector());
     if (gg.defined()) gg = gg.reshape(ctx->saved_data["gate_shape"].toIntVector());
     return {gq, gd, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), gas, gws, gg, at::Tensor()};
   }

@@ -561,8 +561,8 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
     q, d, E = _pad_rows(q, d, 4)
     gq = torch.empty((B, Q, E), dtype=torch.float32, device=dev)
     gd = torch.empty((B, D, E), dtype=torch.float32, device=dev)
-    ga = torch.zeros((B, K), dtype=torch.float32, device=dev)
-    gw = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    gaw = torch.zeros((2, B, K), dtype=torch.float32, device=dev)    # per-pair rows of grad_alpha, grad_w: one memset, one sum
+    ga, gw = gaw[0], gaw[1]
     gate = _gate(d_gate, B, D)
     gg = torch.zeros((B, D), dtype=torch.float32, device=dev) if gate is not None else None
     if pooled is not None:
@@ -571,7 +571,7 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
         pooled = pooled.detach().contiguous()
     if B:
         with torch.cuda.device(dev):
-            wsb = L.mm_kernel_pool_bwd_workspace_bytes(B, Q, D, qk, dk)
+            wsb = L.mm_kernel_pool_bwd_workspace_bytes2(B, Q, D, E, qk, dk)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
             rc = L.mm_kernel_pool_ex_bwd2(q.data_ptr(), d.data_ptr(), qp, qk, dp, dk,
                                           gate.data_ptr() if gate is not None else None, mu.data_ptr(),
@@ -583,9 +583,10 @@ def kernel_pool_bwd(q: torch.Tensor, d: torch.Tensor, q_mask: Optional[torch.Ten
         _lib.check(rc, "mm_kernel_pool_ex_bwd2")
     if E != E0:
         gq, gd = gq[..., :E0].contiguous(), gd[..., :E0].contiguous()
+    gaw = gaw.sum(1)
     if gate is not None:
-        return gq, gd, ga.sum(0), gw.sum(0), gg
-    return gq, gd, ga.sum(0), gw.sum(0)
+        return gq, gd, gaw[0], gaw[1], gg
+    return gq, gd, gaw[0], gaw[1]
 
 
 def tkl_score(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor, chunk_slot: torch.Tensor,

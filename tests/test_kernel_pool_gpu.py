@@ -173,6 +173,63 @@ def test_kernel_pool_backward_matches_autograd_of_the_reference_ops(B, Q, D, E):
         np.testing.assert_allclose(got.cpu().numpy().astype(np.float64), want, atol=2e-4 * scale, rtol=2e-3, err_msg=name + " (pooled path)")
 
 
+@pytest.mark.parametrize("Q,D,E,gated", [(20, 200, 300, False), (30, 180, 128, True), (9, 40, 64, False), (20, 33, 300, True)])
+def test_small_batch_backward_shares_a_pair_between_workgroups_and_equals_the_large_batch_launch(Q, D, E, gated):
+    """kernel_pool_bwd_split.hip: up to 128 pairs (the reference trains 64, defaults.yaml:114) the document blocks of a pair are
+    shared by up to four workgroups and kp_bwd_combine_kernel finishes grad_q from their partial sums; from 129 pairs on one
+    workgroup walks the whole pair.  Same pairs, both launches: grad_d and the parameter gradients bit-equal (each block is one
+    workgroup's work either way), grad_q within summation-order rounding.  A caller with the older, smaller workspace
+    (mm_kernel_pool_bwd_workspace_bytes) gets the one-workgroup launch: bit-equal everywhere."""
+    from matchmaker_amd import _lib, ops
+    dev = torch.device("cuda", 0)
+    n, big = 50, 160
+    g = torch.Generator().manual_seed(Q * 1000 + D)
+    q, d = torch.randn(big, Q, E, generator=g).to(dev), torch.randn(big, D, E, generator=g).to(dev)
+    ql = torch.randint(1, Q + 1, (big,), generator=g).to(torch.int32).to(dev)
+    dl = torch.randint(0, D + 1, (big,), generator=g).to(torch.int32).to(dev)
+    dl[0], dl[1], dl[2] = D, 0, min(D, 31)
+    mu = torch.tensor([1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9], device=dev)
+    sigma = torch.tensor([1e-3] + [0.1] * 10, device=dev)
+    alpha, w = torch.rand(11, generator=g).to(dev) + 0.5, (torch.randn(11, generator=g) * 0.1).to(dev)
+    gate = torch.relu(torch.randn(big, D, generator=g)).to(dev) if gated else None
+    go = torch.randn(big, generator=g).to(dev)
+    _, pooled = ops.kernel_pool(q, d, ql, dl, mu, sigma, alpha, w, d_gate=gate, return_pooled=True)
+    ref = ops.kernel_pool_bwd(q, d, ql, dl, mu, sigma, alpha, w, go, d_gate=gate, pooled=pooled)
+    sl = lambda t: None if t is None else t[:n].contiguous()
+    got = ops.kernel_pool_bwd(sl(q), sl(d), sl(ql), sl(dl), mu, sigma, alpha, w, sl(go), d_gate=sl(gate), pooled=sl(pooled))
+    assert torch.equal(got[1], ref[1][:n]), "grad_d"
+    scale = float(ref[0][:n].abs().max())
+    assert float((got[0] - ref[0][:n]).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert not torch.isnan(got[0]).any()
+    if (D + 31) // 32 > 1:
+        assert not torch.equal(got[0], ref[0][:n]) or Q * E < 64, "the 50-pair launch was expected on the shared-pair path"
+    # the smaller workspace of ABI <= 4 callers: one workgroup per pair, bit-equal to the large launch
+    L = _lib.lib()
+    qs, ds, gos, ps = sl(q), sl(d), sl(go), sl(pooled)
+    _, qp, qk = ops._mask(sl(ql), n, Q, "q_mask")
+    _, dp, dk = ops._mask(sl(dl), n, D, "d_mask")
+    gs = sl(gate)
+    gq, gd = torch.empty_like(qs), torch.empty_like(ds)
+    ga, gw = torch.zeros(n, 11, device=dev), torch.zeros(n, 11, device=dev)
+    gg = torch.zeros(n, D, device=dev) if gated else None
+    wsb = L.mm_kernel_pool_bwd_workspace_bytes(n, Q, D, qk, dk)
+    assert wsb < L.mm_kernel_pool_bwd_workspace_bytes2(n, Q, D, E, qk, dk)
+    assert L.mm_kernel_pool_bwd_workspace_bytes2(big, Q, D, E, qk, dk) - L.mm_kernel_pool_bwd_workspace_bytes(big, Q, D, qk, dk) < 512
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    rc = L.mm_kernel_pool_ex_bwd2(qs.data_ptr(), ds.data_ptr(), qp, qk, dp, dk, gs.data_ptr() if gated else None, mu.data_ptr(),
+                                  sigma.data_ptr(), alpha.data_ptr(), w.data_ptr(), 1e-10, ps.data_ptr(), gos.data_ptr(),
+                                  gq.data_ptr(), gd.data_ptr(), gg.data_ptr() if gated else None, ga.data_ptr(), gw.data_ptr(),
+                                  n, Q, D, E, 11, ws.data_ptr(), wsb, ops._stream(dev))
+    assert rc == 0, L.mm_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(gq, ref[0][:n]) and torch.equal(gd, ref[1][:n])
+    # (per-pair rows equal either way; the operator sums them in one [2, n, K] reduction)
+    np.testing.assert_allclose(got[2].cpu().numpy(), ga.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg="grad_alpha")
+    np.testing.assert_allclose(got[3].cpu().numpy(), gw.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg="grad_w")
+    if gated:
+        assert torch.equal(got[4], gg), "grad_gate"
+
+
 @pytest.mark.parametrize("gated", [False, True])
 def test_cpp_autograd_node_of_the_pooling_block_equals_the_python_node(monkeypatch, gated):
     """tk.kernel_pool_train: the C++ torch::autograd::Function (csrc_host/mm_autograd.cpp KernelPool) and the Python
