@@ -42,14 +42,6 @@ constexpr int kShadowValu = 5;
 
 namespace mm {
 
-// TKL: the wavefront that processes packed chunk p publishes its slot-map entry (see KpArgs::slot2p)
-__device__ __forceinline__ void tkl_publish_slot(const KpArgs& a, int64_t p, int blocks, int lane) {
-  if (a.slot2p && lane == 0) {
-    const int sl = a.chunk_slot[p];
-    if (sl >= 0 && sl < a.n_slots) a.slot2p[sl] = (int32_t)((p << 2) | blocks);
-  }
-}
-
 
 // TKL epilogue of one block of a chunk's centre tokens (block t = rows 32t..32t+31 of the 40):
 // per position pair u the K summed activations (ecai-style RBF, masked: sigir20_tkl.py:192-194) and
@@ -1266,6 +1258,8 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   // No non-temporal hint on these K-sliced streams: the 400-B row pieces of neighbouring slices share cache
   // lines, and with `nt` the shared lines came from HBM twice (FETCH_SIZE 1.22 x the padded bytes, 1.08 x without).
   if constexpr (TKL) {  // grouped runs of chunks (tkl_stage1_run_kernel)
+    // the cosine hand-off streams whole rows since round 6 (tkl_stage1_rows.hip); MM_TKL_STAGE1_SLICES=1 keeps the K-sliced ring below for A/B runs
+    if (a.cos_out && !env().tkl_stage1_slices && tkl_stage1_rows_supported(a.Q, a.E)) return tkl_stage1_rows_launch(a, stream);
     if (a.cos_out) {
       if (a.E == 100)
         hipLaunchKernelGGL((tkl_stage1_run_kernel<1, K, NBUF, false, true>), grid, block, lds, stream, a);

@@ -474,6 +474,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// TKL: the wavefront that processes packed chunk p publishes its slot-map entry (see KpArgs::slot2p)
+__device__ __forceinline__ void tkl_publish_slot(const KpArgs& a, int64_t p, int blocks, int lane) {
+  if (a.slot2p && lane == 0) {
+    const int sl = a.chunk_slot[p];
+    if (sl >= 0 && sl < a.n_slots) a.slot2p[sl] = (int32_t)((p << 2) | blocks);
+  }
+}
+
+// tkl_stage1_rows.hip: TKL stage 1 with the cosine hand-off, whole chunk rows streamed (E = 100 / 200 / 300, Q <= 32)
+bool tkl_stage1_rows_supported(int Q, int E);
+int tkl_stage1_rows_launch(const KpArgs& a, hipStream_t stream);
+
 // kernel_pool128.hip: streaming kernels for E = 64n <= 384 (Q <= 32)
 bool kp128_supported(int Q, int D, int E, bool gated);
 int kp128_launch(const KpArgs& a, hipStream_t stream);
