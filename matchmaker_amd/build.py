@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libmm_native.so")
-SOURCES = ["common.hip", "maxsim.hip", "maxsim_pair.hip", "kernel_pool.hip", "kernel_pool128.hip", "kernel_pool_bwd.hip", "kernel_pool_bwd_split.hip", "tkl.hip", "tkl_stage1_rows.hip", "tkl_bwd.hip", "dot_topk.hip"]
+SOURCES = ["common.hip", "maxsim.hip", "maxsim_pair.hip", "kernel_pool.hip", "kernel_pool128.hip", "kernel_pool_bwd.hip", "kernel_pool_bwd_split.hip", "tkl.hip", "tkl_stage1_rows.hip", "tkl_stage1_ksplit.hip", "tkl_bwd.hip", "dot_topk.hip"]
 HEADERS = [os.path.join(CSRC, "mm_internal.h"), os.path.join(CSRC, "kp_device.h"), os.path.join(CSRC, "maxsim_device.h"), os.path.join(CSRC, "kp_bwd.h"), os.path.join(HERE, "..", "include", "mm_native.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 

@@ -1258,7 +1258,9 @@ static int launch_stream(const KpArgs& a0, hipStream_t stream) {
   // No non-temporal hint on these K-sliced streams: the 400-B row pieces of neighbouring slices share cache
   // lines, and with `nt` the shared lines came from HBM twice (FETCH_SIZE 1.22 x the padded bytes, 1.08 x without).
   if constexpr (TKL) {  // grouped runs of chunks (tkl_stage1_run_kernel)
-    // the cosine hand-off streams whole rows since round 6 (tkl_stage1_rows.hip); MM_TKL_STAGE1_SLICES=1 keeps the K-sliced ring below for A/B runs
+    // the cosine hand-off streams whole rows since round 6 (tkl_stage1_rows.hip).  A/B: MM_TKL_STAGE1_KSPLIT=1 = two K-splitting wavefronts per
+    // workgroup (tkl_stage1_ksplit.hip: correct, not faster), MM_TKL_STAGE1_SLICES=1 = the K-sliced ring of rounds 2-5 below
+    if (a.cos_out && env().tkl_stage1_ksplit && tkl_stage1_ksplit_supported(a.Q, a.E)) return tkl_stage1_ksplit_launch(a, stream);
     if (a.cos_out && !env().tkl_stage1_slices && tkl_stage1_rows_supported(a.Q, a.E)) return tkl_stage1_rows_launch(a, stream);
     if (a.cos_out) {
       if (a.E == 100)

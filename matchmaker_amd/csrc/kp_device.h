@@ -485,6 +485,9 @@ __device__ __forceinline__ void tkl_publish_slot(const KpArgs& a, int64_t p, int
 // tkl_stage1_rows.hip: TKL stage 1 with the cosine hand-off, whole chunk rows streamed (E = 100 / 200 / 300, Q <= 32)
 bool tkl_stage1_rows_supported(int Q, int E);
 int tkl_stage1_rows_launch(const KpArgs& a, hipStream_t stream);
+// tkl_stage1_ksplit.hip: the same with two wavefronts per workgroup sharing every tile along K (two wavefronts per SIMD)
+bool tkl_stage1_ksplit_supported(int Q, int E);
+int tkl_stage1_ksplit_launch(const KpArgs& a, hipStream_t stream);
 
 // kernel_pool128.hip: streaming kernels for E = 64n <= 384 (Q <= 32)
 bool kp128_supported(int Q, int D, int E, bool gated);

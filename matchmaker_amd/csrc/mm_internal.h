@@ -38,6 +38,7 @@ struct EnvCfg {
   int dot_no_spread = 0;    // MM_DOT_NO_SPREAD: dot top-k filter issues a block's LDS-DMA all at once after the barrier (A/B runs)
   int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
   int kp_bwd_threads = 1024; // MM_KP_BWD_THREADS: 1024 (when its LDS fits) | 512 threads per pair in kernel_pool_bwd_tiled_kernel (A/B runs)
+  int tkl_stage1_ksplit = 0;  // MM_TKL_STAGE1_KSPLIT=1: TKL stage 1 on the two-wavefront K-split kernel (tkl_stage1_ksplit.hip) instead of the row-streaming one (A/B runs)
   int tkl_stage1_slices = 0;  // MM_TKL_STAGE1_SLICES=1: TKL stage 1 (cosine hand-off) on the K-sliced ring of rounds 2-5 instead of the row-streaming kernel (A/B runs)
   int kp_bwd_nsplit = 0;    // MM_KP_BWD_NSPLIT=n: workgroups per pair of the split backward (0: by batch size — 4 up to 128 pairs, else 1)
   int kp_bwd_f32 = 0;       // MM_KP_BWD_F32=1: pooling backward on the exact-f32 tiled kernel of rounds 4-5 instead of the split-bf16 streaming kernel (parity twin, A/B runs)

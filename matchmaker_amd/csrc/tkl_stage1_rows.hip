@@ -25,6 +25,20 @@ namespace {
 constexpr int kRing = 4;       // ring slots = units of 8 chunk rows in flight per wavefront
 constexpr int kUnitRows = 8;
 
+// sum over the four k-groups of a row (lanes l, l ^ 16, l ^ 32, l ^ 48), in every lane: two gfx950 lane swaps + two adds on the
+// VALU (two ds_bpermute round trips before: ~200 cycles each with nothing else resident on the SIMD)
+__device__ __forceinline__ float kgroup_sum(float v) {
+  // v_permlane16_swap x, y: rows 1, 3 of x <-> rows 0, 2 of y; v_permlane32_swap: the upper half of x <-> the lower half of y.
+  // (Inline assembly: __builtin_amdgcn_permlane16_swap(u, u) came back with the same value in both results on ROCm 7.2 —
+  // tools/scratch/swap.hip.)
+  float x = v, y;
+  asm volatile("v_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "=&v"(y) : "v"(v));
+  const float s = x + y;                                       // rows 0, 1: r0 + r1; rows 2, 3: r2 + r3
+  float x2 = s, y2;
+  asm volatile("v_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x2), "=&v"(y2) : "v"(s));
+  return x2 + y2;
+}
+
 __device__ __forceinline__ f32x4 mfma16x32(const bf16x8& a, const bf16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -96,6 +110,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
   const uint32_t RB = (uint32_t)E * 4u, UB = kUnitRows * RB;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   float* rdbuf = (float*)(smem + kRing * UB + 128);           // (128 B behind the ring: the last row's reads past E stay inside)
+  float* timg = rdbuf + 16;                                   // [16 rows][qlim <= 32] image of a tile's cosines
   const int tail_lanes = (E & 31) ? 2 * (E & 31) : 64;         // lanes of a unit's last LDS-DMA instruction
   const uint32_t vlane = (uint32_t)lane * 16u;
 
@@ -129,8 +144,17 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
   const long long t_begin = t_last;
 #endif
   auto wait_oldest = [&](int n_units) __attribute__((always_inline)) {    // the n_units oldest units in flight have landed
-    int n = (int)((young >> (8 * (inflight - n_units))) & 0xffu);
-    wait_vm(n < 62 ? n : 62);
+    // (vmcnt takes an immediate: the count is floored to a unit boundary — at most one store or two short of exact, i.e. a few
+    // hundred bytes of the next unit awaited with it — instead of a 63-way jump table, 340 cycles per tile)
+    const int n = (int)((young >> (8 * (inflight - n_units))) & 0xffu);
+    if (n >= 3 * NSTEP)
+      wait_vm(3 * NSTEP);
+    else if (n >= 2 * NSTEP)
+      wait_vm(2 * NSTEP);
+    else if (n >= NSTEP)
+      wait_vm(NSTEP);
+    else
+      wait_vm(0);
   };
   // ---- chunk metadata, 64 chunks at a time: lane l holds the slot and the 40 validity bits of chunk mbase + l, fetched by ONE
   // round of loads BEFORE the stream starts and read per chunk with v_readlane.  (Per chunk: three dependent scalar loads and —
@@ -200,7 +224,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
     f32x4 hh[2], lh[2], hl[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) hh[t] = lh[t] = hl[t] = f32x4{0, 0, 0, 0};
-    f32x2 ss2 = {0.0f, 0.0f};
+    f32x2 ssa[4] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
     // (the choice between one and two N-tiles OUTSIDE the k-loop: a branch per step made the register allocator shuffle the
     // accumulators through v_accvgpr moves at every step)
     auto products = [&](auto nt) __attribute__((always_inline)) {
@@ -218,10 +242,10 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
         {
           const f32x2 a0 = {x[s][0][0], x[s][0][1]}, a1 = {x[s][0][2], x[s][0][3]};
           const f32x2 b0 = {x[s][1][0], x[s][1][1]}, b1 = {x[s][1][2], x[s][1][3]};
-          ss2 += a0 * a0;
-          ss2 += a1 * a1;
-          ss2 += b0 * b0;
-          ss2 += b1 * b1;
+          ssa[0] += a0 * a0;                                    // (four chains: one accumulator was 40 dependent v_pk_fma per tile,
+          ssa[1] += a1 * a1;                                    //  ~13 cycles each with nothing else resident on the SIMD)
+          ssa[2] += b0 * b0;
+          ssa[3] += b1 * b1;
         }
 #endif
 #if MM_S1_CUT == 1
@@ -236,38 +260,55 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
 #endif
       }
     };
+    S1_PH(0);
     if (ntile == 2)
       products(std::integral_constant<int, 2>());
     else
       products(std::integral_constant<int, 1>());
-    float ss = ss2[0] + ss2[1];
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    S1_PH(6);                                                  // k-loop: split, norms, products
+    const f32x2 ss2 = (ssa[0] + ssa[1]) + (ssa[2] + ssa[3]);
+    const float ss = kgroup_sum(ss2[0] + ss2[1]);
     if (kg == 0) rdbuf[m] = 1.0f / (sqrtf(ss) + 1e-13f);       // row m of the tile
     const f32x4 rd = *(const f32x4*)(rdbuf + 4 * kg);          // rows 4 kg + 0..3 (same wavefront: program order)
     const int row0 = 16 * tau + 4 * kg;
     const bool rows_exist = row0 < 40;                         // tau = 2: k-groups 0 and 1
+    S1_PH(7);                                                  // norm reduction + redistribution
     const uint32_t bits = (uint32_t)(vb >> (row0 < 40 ? row0 : 0)) & 0xfu;
+    // The tile's cosines leave as ONE contiguous run: rows 16 tau .. of the chunk x qlim tokens are nrows x qlim consecutive
+    // floats of the hand-off buffer.  From the accumulator layout (lane = token, four rows 4 apart in position) that was 4 store
+    // instructions per N-tile of <= 16 x 4 B pieces; through a wavefront-private LDS image of the tile it is one 16-byte store
+    // per lane (a second instruction only past 256 floats): the vector-memory queue is what this wavefront waits on.
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (t < ntile) {
         const int tok = 16 * t + m;
         if (tok < qlim && rows_exist) {
-          float* dst = cbase + (int64_t)row0 * qlim + tok;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float c = ((hh[t][i] + (lh[t][i] + hl[t][i])) * rq[t]) * rd[i];
-#if MM_S1_PROBE == 3
-            asm volatile("" ::"v"(c), "v"(dst));
-#else
-            dst[i * qlim] = ((bits >> i) & 1u) ? c : 1.0e5f;
-#endif
+            timg[(4 * kg + i) * qlim + tok] = ((bits >> i) & 1u) ? c : 1.0e5f;
           }
         }
       }
     }
+    const int nfl = (tau < 2 ? 16 : 8) * qlim;                 // floats of the run (a multiple of 4)
+    float* run = cbase + (int64_t)(16 * tau) * qlim;
 #if MM_S1_PROBE == 0
-    young += 0x01010101u * (uint32_t)(4 * ntile);              // the stores above are in the vmcnt queue too
+    if (4 * lane < nfl) {
+      const f32x4 v = *(const f32x4*)(timg + 4 * lane);
+      float* d = run + 4 * lane;
+      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(d), "v"(v) : "memory");
+    }
+    if (nfl > 256) {
+      if (4 * lane + 256 < nfl) {
+        const f32x4 v = *(const f32x4*)(timg + 256 + 4 * lane);
+        float* d = run + 256 + 4 * lane;
+        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(d), "v"(v) : "memory");
+      }
+    }
+#endif
+#if MM_S1_PROBE == 0
+    young += 0x01010101u * (nfl > 256 ? 2u : 1u);              // the stores above are in the vmcnt queue too
 #endif
 #endif
   };
@@ -316,9 +357,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
           qhi[t][s] = to_agpr(qhi[t][s]);
           qlo[t][s] = to_agpr(qlo[t][s]);
         }
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        rq[t] = 1.0f / (sqrtf(ss) + 1e-13f);
+        rq[t] = 1.0f / (sqrtf(kgroup_sum(ss)) + 1e-13f);
       }
 #endif
     }
@@ -329,23 +368,18 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
     cbase = a.cos_out + qi * ((int64_t)a.C * 40 * Q) + (int64_t)cpos * 40 * qlim;
   };
 
-  // One copy of the loop body (the six-fold unrolled form — two register images alternating over a chunk's three tiles — was
-  // 13 k instructions for E = 300, more than the instruction cache holds: 84 us).  xn: the tile fetched ahead, xc: the one multiplied.
-  f32x4 xn[NSTEP][2], xc[NSTEP][2];
-  read_tile(xn, 0);
+  // Two tiles per loop trip, the register images alternating (xa multiplied while xb is fetched, then the reverse): no copy, two
+  // copies of the body.  (The six-fold unrolled form — a chunk pair's six tiles — was 13 k instructions for E = 300, more than the
+  // instruction cache holds: 84 us; one copy with a 40-register move per tile: ~200 cycles of a tile's 5.7 k.)
+  f32x4 xa[NSTEP][2], xb[NSTEP][2];
   int64_t p = p0;
   int tau = 0;
-#pragma unroll 1
-  for (;;) {
+  bool done = false;
+  auto step = [&](f32x4 (&xc)[NSTEP][2], f32x4 (&xn)[NSTEP][2]) __attribute__((always_inline)) {
     if (tau == 0) {
       S1_PH(0);
       chunk_head(p);
       S1_PH(5);                                                // chunk head (query tile when the document changes)
-    }
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-      xc[s][0] = xn[s][0];
-      xc[s][1] = xn[s][1];
     }
     const bool last = p + 1 >= p1 && tau == 2;
     if (!last) read_tile(xn, tau == 2 ? 0 : tau + 1);
@@ -354,17 +388,25 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
     for (int s = 0; s < NSTEP; ++s) asm volatile("" ::"v"(xc[s][0]), "v"(xc[s][1]));
 #endif
     compute_tile(xc, tau);
-    if (last) break;
+    done = last;
     if (++tau == 3) {
       tau = 0;
       ++p;
     }
+  };
+  read_tile(xa, 0);
+#pragma unroll 1
+  for (;;) {
+    step(xa, xb);
+    if (done) break;
+    step(xb, xa);
+    if (done) break;
   }
 #if MM_S1_PHASES
   S1_PH(0);
   if ((blockIdx.x % 37 == 0 || blockIdx.x == gridDim.x / 2) && lane == 0)
-    printf("S1PH wave %4d chunks %d | arithmetic+stores %lld | top-up before wait %lld | wait units %lld | LDS reads issue %lld | reads back + DMA issue %lld | chunk head %lld | total %lld\n",
-           (int)blockIdx.x, (int)(p1 - p0), ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], t_last - t_begin);
+    printf("S1PH wave %4d chunks %d | copy+stores+loop %lld | top-up before wait %lld | wait units %lld | LDS reads issue %lld | reads back + DMA issue %lld | chunk head %lld | k-loop %lld | norm %lld | total %lld\n",
+           (int)blockIdx.x, (int)(p1 - p0), ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], t_last - t_begin);
 #endif
 }
 
@@ -377,7 +419,7 @@ int tkl_stage1_rows_launch(const KpArgs& a0, hipStream_t stream) {
   if (waves <= 0) return MM_OK;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
   waves = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-  const int lds = kRing * kUnitRows * a.E * 4 + 128 + 64;
+  const int lds = kRing * kUnitRows * a.E * 4 + 128 + 64 + 16 * 32 * 4;
   const dim3 grid((unsigned)waves), block(64);
   if (a.E == 100)
     hipLaunchKernelGGL((tkl_stage1_rows_kernel<4>), grid, block, lds, stream, a);

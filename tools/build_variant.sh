@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../matchmaker_amd/csrc"
 name=$1; tu=$2; shift 2
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment "$@" -c -o build/${tu}_${name}.o ${tu}.hip
 objs=""
-for o in common maxsim maxsim_pair kernel_pool kernel_pool128 kernel_pool_bwd kernel_pool_bwd_split tkl tkl_stage1_rows tkl_bwd dot_topk; do
+for o in common maxsim maxsim_pair kernel_pool kernel_pool128 kernel_pool_bwd kernel_pool_bwd_split tkl tkl_stage1_rows tkl_stage1_ksplit tkl_bwd dot_topk; do
   if [ "$o" = "$tu" ]; then objs="$objs build/${tu}_${name}.o"; else objs="$objs build/$o.o"; fi
 done
 mkdir -p ../../variants
