@@ -441,7 +441,7 @@ def extra_tkl(steps, cpu_budget):
            "dtype": "fp32 (split-bf16 operands: x = hi + lo, 3 bf16 MFMAs hi.hi + lo.hi + hi.lo, fp32 accumulation)", "ms": ms, "docs_per_s": B / (ms * 1e-3), "algorithmic_bytes": by,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "needed_bytes": by_needed, "frac_needed_bytes": by_needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "kernel": "tkl_prep_kernel + tkl_stage1_run_kernel<cos> + tkl_window_kernel<cos> + tkl_region_kernel: the whole mm_tkl_fwd call",
+           "kernel": "tkl_prep_kernel + tkl_stage1_rows_kernel + tkl_window_kernel<cos> + tkl_region_kernel: the whole mm_tkl_fwd call",
            "profile": "profiles/r06_tkl_pmc.json, profiles/r06_tkl_trace.json (full documents: profiles/r06_tklfull_pmc.json)"}
     try:
         if not LEAN:

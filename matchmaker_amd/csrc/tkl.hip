@@ -57,24 +57,11 @@ __global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slo
   if (blk < n_fill) {
     const int64_t i = (int64_t)blk * 256 + threadIdx.x;
     if (i < BC) slot2p[i] = -1;
-    // Per document (the first B threads of this role): the live window tiles and the arrival counter of the window kernel's
-    // last-workgroup epilogue.  The LAST kept chunk c of a document bounds its live tiles (windows w <= 20 c + 19 touch
-    // chunk c); it is found by a binary search for the first slot past the document in the ascending chunk_slot list, so a
-    // document without kept chunks gets 0 — every entry is written on every call.
+    // Per document (the first B threads of this role): the arrival counter of the window kernel's last-workgroup epilogue; the
+    // live window tiles come from the chunk role below (without packed chunks: 0 for every document, here).
     if (i < B) {
-      int64_t lo = 0, hi = P;
-      const int64_t past = (i + 1) * (int64_t)C;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)chunk_slot[mid] < past) lo = mid + 1; else hi = mid;
-      }
-      int nt = 0;
-      if (lo > 0) {
-        const int sl = chunk_slot[lo - 1];
-        if ((int64_t)sl >= i * (int64_t)C) nt = (kU * (sl % C) + kU - 1) / kWT + 1;
-      }
-      ntile[i] = nt;
       done_cnt[i] = 0;
+      if (P == 0) ntile[i] = 0;
     }
     return;
   }
@@ -118,6 +105,27 @@ __global__ void __launch_bounds__(256) tkl_prep_kernel(int32_t* __restrict__ slo
     clen_out[p] = bal ? 64 - __builtin_clzll(bal) : 0;
     cbits_out[p * 2] = (uint32_t)bal;
     cbits_out[p * 2 + 1] = (uint32_t)(bal >> 32);
+    // Live window tiles per document: the LAST kept chunk c of a document bounds them (windows w <= 20 c + 19 touch chunk c).
+    // chunk_slot is ascending, so the wavefront of the last chunk of a document sees the next document in chunk_slot[p + 1] and
+    // writes the entry — and zeros for the documents without chunks between the two (and in front of the first, behind the last
+    // chunk): every entry is written on every call, by exactly one wavefront.  (A binary search per document in the fill role,
+    // thirteen dependent loads, was this launch's critical path: 5.7 us.)
+    const int64_t nb = B;
+    int64_t sl = chunk_slot[p];
+    sl = sl < 0 ? 0 : (sl >= nb * C ? nb * C - 1 : sl);
+    const int64_t b = sl / C;
+    int64_t bn = nb;                                           // document of the next chunk (B behind the last)
+    if (p + 1 < P) {
+      int64_t sn = chunk_slot[p + 1];
+      sn = sn < 0 ? 0 : (sn >= nb * C ? nb * C - 1 : sn);
+      bn = sn / C;
+    }
+    if (p == 0)
+      for (int64_t d = 0; d < b; ++d) ntile[d] = 0;
+    if (bn != b) {
+      ntile[b] = (kU * (int)(sl - b * C) + kU - 1) / kWT + 1;
+      for (int64_t d = b + 1; d < bn; ++d) ntile[d] = 0;
+    }
   }
 }
 
@@ -182,10 +190,12 @@ __device__ __forceinline__ void window_items(const float* tile, float* red, cons
         const float x0 = emb[i], x1 = len;                             // :224-225
         const float mean = (x0 + x1) * 0.5f;                           // LayerNorm(2) :228
         const float d0 = x0 - mean, d1 = x1 - mean;
-        const float rstd = 1.0f / sqrtf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
+        // v_rsq_f32 / v_rcp_f32 (1 ulp) instead of the IEEE sqrt + two IEEE divisions (~35 instructions per window in a
+        // VALU-bound kernel): 1e-7 relative on s1 .. s3, two orders below the window error of the fp32 evaluation itself
+        const float rstd = __builtin_amdgcn_rsqf((d0 * d0 + d1 * d1) * 0.5f + 1e-5f);
         const float n0 = d0 * rstd * sp[9] + sp[11], n1 = d1 * rstd * sp[10] + sp[12];
         const float s1 = n0 * sp[0] + n1 * sp[1] + sp[2];              // :230
-        const float s2 = 1.0f / (n0 * sp[3] + n1 * sp[4] + sp[5]);      // :231
+        const float s2 = __builtin_amdgcn_rcpf(n0 * sp[3] + n1 * sp[4] + sp[5]);   // :231
         const float s3 = n0 * sp[6] + n1 * sp[7] + sp[8];              // :232
 #pragma unroll
         for (int k = 0; k < kK; ++k) {
@@ -196,15 +206,18 @@ __device__ __forceinline__ void window_items(const float* tile, float* red, cons
           // (folding this to factor (s1 sum_k w_k x_k^s2 - s3 sum_k w_k) saves two operations per kernel and was tried:
           // with the reference's biases of 100 in s1 and s3 the two sums cancel to ~1 % of their size, and the window
           // error against fp64 grew from 9e-7 to 7e-6 — more than the reference's own fp32 evaluation makes)
-          val += prm[TklParams::dense() + k] * (sat * factor);
+          val += prm[TklParams::dense() + k] * sat;
         }
       } else {
 #pragma unroll
         for (int k = 0; k < kK; ++k) {
           const float sat = logf(fmaxf(pk[k] * prm[TklParams::kmult() + k], 1e-10f));   // :246
-          val += prm[TklParams::dense() + k] * (sat * factor);
+          val += prm[TklParams::dense() + k] * sat;
         }
       }
+      // :248 the query mask and the empty-window factor once per window instead of once per kernel: factor is 0 or 1 for the
+      // reference's {0, 1} masks, and x * 1 is exact (eleven multiplies less per window)
+      val *= factor;
       red[(wl + which) * (ql | 1) + i] = (w0 + wl + which < W) ? val : 0.0f;
     }
     if (ONCE) break;      // the caller knows the 512 threads cover the items in one pass (no loop-carried registers)
@@ -454,20 +467,25 @@ __global__ void __launch_bounds__(kWThreads, 4) tkl_window_kernel(const float* _
             for (int kp = 0; kp < kKC / 2; ++kp) o2[kp] = f32x2{0.0f, 0.0f};
             float cnt = 0.0f;
             if (cl[s] >= 0 && cinfo[cl[s]] >= 0) {
+              // eleven kernels = five packed pairs + one alone (the dummy twelfth of the packed form was two v_exp per item
+              // for an exact 0); the first position ASSIGNS its activations (0 + e = e exactly), the second adds
 #pragma unroll
               for (int half = 0; half < 2; ++half) {
                 const float c = half ? cb[s] : ca[s];
                 const f32x2 cc = {c, c};
                 f32x2 any2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int kp = 0; kp < kKC / 2; ++kp) {
+                for (int kp = 0; kp < kK / 2; ++kp) {
                   const f32x2 sv = cc * sq2[kp] - msq2[kp];
                   const f32x2 av = -(sv * sv);
                   const f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
-                  o2[kp] += e;
+                  o2[kp] = half ? o2[kp] + e : e;
                   any2 += e;
                 }
-                cnt += (any2[0] + any2[1]) != 0.0f ? 1.0f : 0.0f;        // (:210)
+                const float sv = c * sq2[kK / 2][0] - msq2[kK / 2][0];
+                const float e = __builtin_amdgcn_exp2f(-(sv * sv));
+                o2[kK / 2][0] = half ? o2[kK / 2][0] + e : e;
+                cnt += ((any2[0] + any2[1]) + e) != 0.0f ? 1.0f : 0.0f;  // (:210)
               }
             }
             f32x4* dst = (f32x4*)(tile + (size_t)idx * kKC);             // idx = j * ql + i: row j, token i
@@ -616,16 +634,35 @@ __global__ void __launch_bounds__(kRThreads) tkl_region_kernel(const float* part
     np = np < n_planes ? np : n_planes;
   }
   const int live_w = ntile[b] * kWT;
-  for (int w = tid; w < Wp; w += kRThreads) {
-    float s = 0.0f;
-    if (w < W) {
-      if (w < live_w)
-        for (int g = 0; g < np; ++g) s += part[g * plane + (int64_t)b * W + w];
-      win[(int64_t)b * W + w] = s;
+  // Four windows per thread at a time, every plane's value requested before the first store: `win` may be the plane buffer
+  // itself (one token group), so with a store per window the compiler kept each window's loads behind the previous window's
+  // store — four dependent memory round trips per document in a launch that is nothing but latency (9.8 us for 256 workgroups).
+  constexpr int kIt = 4;
+  for (int w0 = tid; w0 < Wp; w0 += kIt * kRThreads) {
+    float s[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) s[it] = 0.0f;
+    for (int g = 0; g < np; ++g) {
+      float v[kIt];
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int w = w0 + it * kRThreads;
+        v[it] = (w < W && w < live_w) ? part[g * plane + (int64_t)b * W + w] : 0.0f;
+      }
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) s[it] += v[it];                   // (planes in order, as before: 0 + v0 + v1 ...)
     }
-    if (s == 0.0f) s = -9900.0f;                                       // :257
-    orig[w] = s;
-    work[w] = s;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int w = w0 + it * kRThreads;
+      if (w < Wp) {
+        float sv = s[it];
+        if (w < W) win[(int64_t)b * W + w] = sv;
+        if (sv == 0.0f) sv = -9900.0f;                                   // :257
+        orig[w] = sv;
+        work[w] = sv;
+      }
+    }
   }
   __syncthreads();
   region_topk(orig, work, rv, ri, Wp, prm, out + b, peaks ? peaks + 3 * (int64_t)b : nullptr, tid);

@@ -208,8 +208,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
     cslot = (cslot + nun) & (kRing - 1);
     inflight -= nun;
     S1_PH(3);                                                  // LDS reads issued
-    top_up();                                                  // (waits for the reads above, then refills the slots)
-    S1_PH(4);                                                  // reads returned + LDS-DMA issue
+    // (the freed slots are refilled from inside the k-loop of the tile multiplied next: compute_tile)
   };
 
   // per-chunk state of the tile being multiplied
@@ -227,10 +226,53 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
     f32x2 ssa[4] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
     // (the choice between one and two N-tiles OUTSIDE the k-loop: a branch per step made the register allocator shuffle the
     // accumulators through v_accvgpr moves at every step)
+    // The refill of the slots the pre-read just freed is issued from INSIDE the k-loop, two LDS-DMA instructions per k-step.
+    // Issuing is the transfer (the queue to the memory system is shallow: an instruction is accepted at the CU's share of the
+    // HBM stream, ~80 cycles per KiB) and four wavefronts share that path: with a 20-instruction burst per tile each was in its
+    // issue phase ~30 % of the time and the path idle whenever all four computed at once ((1 - 0.3)^4 = 24 %: the measured 74 % of
+    // the stream-only rate).  Interleaved, every wavefront offers the path work throughout its tile.
+    bool act = false;
+    const char* ug = nullptr;
+    uint32_t ud = 0;
+    auto dma_step = [&](int s) __attribute__((always_inline)) {          // (s: a constant after unrolling)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int i0 = (2 * s) % NSTEP;
+        const bool paired = i0 + 1 < NSTEP - 1;                // instructions i0, i0 + 1: both full-width, one M0 / base pair
+        if (jj == 1 && paired) continue;
+        const int i = (2 * s + jj) % NSTEP;
+        if (i == 0) {
+          act = pp < p1 && inflight < kRing;
+          if (act) {
+            ug = dbase + (pp * 50 + 5 + kUnitRows * pu) * (int64_t)RB;
+            ud = lds0 + (uint32_t)pslot * UB;
+          }
+        }
+        if (act) {
+          if (i < NSTEP - 1) {
+            if (jj == 0 && paired)
+              glds_group<2>(ug + 1024 * i, vlane, ud + 1024u * i);
+            else
+              glds_group<1>(ug + 1024 * i, vlane, ud + 1024u * i);
+          } else {
+            if (lane < tail_lanes) glds_group<1>(ug + 1024 * i, vlane, ud + 1024u * i);
+            young = (young + 0x01010101u * NSTEP) << 8;
+            pslot = (pslot + 1) & (kRing - 1);
+            ++inflight;
+            if (++pu == 5) {
+              pu = 0;
+              ++pp;
+            }
+          }
+        }
+      }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the pre-read of the next tile has returned: its slots may be overwritten
     auto products = [&](auto nt) __attribute__((always_inline)) {
       constexpr int NT = decltype(nt)::value;
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
+        dma_step(s);
         bf16x8 ah, al;
 #if MM_S1_CUT == 2
         ah = __builtin_bit_cast(bf16x8, x[s][0]);
@@ -388,6 +430,9 @@ __global__ void __launch_bounds__(64) tkl_stage1_rows_kernel(const KpArgs a) {
     for (int s = 0; s < NSTEP; ++s) asm volatile("" ::"v"(xc[s][0]), "v"(xc[s][1]));
 #endif
     compute_tile(xc, tau);
+    S1_PH(0);
+    top_up();                                                  // (whatever the k-loop did not issue: a skipped tile, the ramp)
+    S1_PH(4);
     done = last;
     if (++tau == 3) {
       tau = 0;

@@ -10,8 +10,8 @@ import sys
 
 MODELS = {
     "colbert": ("colbert_fp16_autocast_q32_d180_e128", ("maxsim_bwd_kernel", "maxsim_pair_kernel", "pack_mask_kernel<long>")),
-    "tk": ("tk_pooling_q20_d200_e300", ("kernel_pool_bwd_tiled_kernel", "kernel_pool_split_kernel", "pack_mask2_kernel", "pack_mask_kernel<float>")),
-    "tkl": ("tkl_scoring_d2048_e300", ("tkl_bwd_tiled_kernel", "tkl_bwd_fill_kernel", "tkl_bwd_slot_kernel", "tkl_stage1_run_kernel",
+    "tk": ("tk_pooling_q20_d200_e300", ("kernel_pool_bwd_tiled_kernel", "kp_bwd_split_kernel", "kp_bwd_combine_kernel", "kernel_pool_split_kernel", "pack_mask2_kernel", "pack_mask_kernel<float>")),
+    "tkl": ("tkl_scoring_d2048_e300", ("tkl_bwd_tiled_kernel", "tkl_bwd_fill_kernel", "tkl_bwd_slot_kernel", "tkl_stage1_run_kernel", "tkl_stage1_rows_kernel",
                                          "tkl_window_kernel", "tkl_prep_kernel")),
 }
 
