@@ -469,6 +469,35 @@ def test_folded_region_epilogue_is_bit_equal_to_the_standalone_region_kernel(tmp
     assert (alone["config3_1024.peaks"][:, 0] != alone["config3_1024.peaks"][:, 1]).all()
 
 
+@pytest.mark.parametrize("switch", ["MM_TKL_STAGE1_SLICES", "MM_TKL_STAGE1_KSPLIT"])
+def test_stage1_kernels_agree_with_the_row_streaming_default(tmp_path, switch):
+    """Stage 1 ships as tkl_stage1_rows.hip (whole chunk rows through the LDS ring, round 6).  Its two A/B twins — the K-sliced ring
+    of rounds 2-5 (MM_TKL_STAGE1_SLICES=1) and the two-wavefront K-split kernel (MM_TKL_STAGE1_KSPLIT=1) — compute the same split-bf16
+    cosines in another summation order: every window of the five epilogue cases (config 3 at 1,024 documents, one / three token
+    groups, log saturation at E = 64 -> generic fallback, short documents) within 4e-5 of the default's, the document scores
+    within 1e-3 except where a region arg-max sits on a tie (at most 1 %; tests/util.py states the tie policy)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "twin.npz")
+    r = subprocess.run([sys.executable, "-c", f"from tests.test_tkl_gpu import _epilogue_run_all; _epilogue_run_all({path!r})"], cwd=root,
+                       env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert not os.environ.get(switch), "this process must run the default stage 1"
+    twin = np.load(path)
+    ours = _epilogue_run_all()
+    assert set(twin.files) == set(ours)
+    for k in sorted(ours):
+        if k.endswith(".win"):
+            a, b = ours[k].astype(np.float64), twin[k].astype(np.float64)
+            assert np.isfinite(a).all() and np.isfinite(b).all()
+            err = np.abs(a - b) / np.maximum(1.0, np.abs(a))
+            assert err.max() <= 4e-5, f"{k}: windows differ by {err.max():.2e}"
+        elif k.endswith(".score"):
+            a, b = ours[k].astype(np.float64), twin[k].astype(np.float64)
+            off = np.abs(a - b) > 1e-3 * np.maximum(1.0, np.abs(a))
+            assert off.mean() <= 0.01, f"{k}: {int(off.sum())} of {off.size} document scores differ (region ties are rarer than that)"
+
+
 def _stability_run():
     """200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI, poisoned workspace, racing side stream; see the test."""
 
