@@ -841,7 +841,7 @@ def extra_train_step(steps, cpu_budget):
     from matchmaker_amd import ops, synth
     from matchmaker_amd.colbert import ColBERT
     from matchmaker_amd.tk import kernel_pool_train
-    from matchmaker_amd.tkl import TKL_sigir20, _TKLScoreFn, chunk_documents
+    from matchmaker_amd.tkl import TKL_sigir20, chunk_documents, tkl_score_train
     dev = torch.device("cuda", torch.cuda.current_device())
     res = {}
 
@@ -1008,7 +1008,7 @@ def extra_train_step(steps, cpu_budget):
 
         def l_native():
             zero()
-            _TKLScoreFn.apply(q_ctx, chunks, cmask, slot, qm, (B, C, 11, "embedding", packed, sizes), *scoring)[0].backward(go)
+            tkl_score_train(q_ctx, chunks, cmask, slot, qm, packed, B, C, 11, "embedding", scoring, sizes)[0].backward(go)      # (the C++ node when the host extension is built)
 
         prm = {"mu": m.mu, "sigma": m.sigma, "dense_w": m.dense.weight, "sat_w1": m.saturation_linear.weight,
                "sat_b1": m.saturation_linear.bias, "sat_w2": m.saturation_linear2.weight, "sat_b2": m.saturation_linear2.bias,

@@ -19,7 +19,9 @@
 #include <c10/hip/HIPStream.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "mm_native.h"
 
@@ -35,6 +37,10 @@ struct Api {
   decltype(&mm_kernel_pool_ex_bwd2) kp_bwd = nullptr;
   decltype(&mm_kernel_pool_workspace_bytes) kp_fwd_ws = nullptr;
   decltype(&mm_kernel_pool_bwd_workspace_bytes2) kp_bwd_ws = nullptr;
+  decltype(&mm_tkl_fwd) tkl_fwd = nullptr;
+  decltype(&mm_tkl_bwd) tkl_bwd = nullptr;
+  decltype(&mm_tkl_workspace_bytes) tkl_fwd_ws = nullptr;
+  decltype(&mm_tkl_bwd_workspace_bytes) tkl_bwd_ws = nullptr;
   decltype(&mm_last_error) last_error = nullptr;
   decltype(&mm_abi_version) abi = nullptr;
 } api;
@@ -54,6 +60,10 @@ void init(const std::string& lib_path) {
   MM_SYM(kp_bwd, mm_kernel_pool_ex_bwd2);
   MM_SYM(kp_fwd_ws, mm_kernel_pool_workspace_bytes);
   MM_SYM(kp_bwd_ws, mm_kernel_pool_bwd_workspace_bytes2);
+  MM_SYM(tkl_fwd, mm_tkl_fwd);
+  MM_SYM(tkl_bwd, mm_tkl_bwd);
+  MM_SYM(tkl_fwd_ws, mm_tkl_workspace_bytes);
+  MM_SYM(tkl_bwd_ws, mm_tkl_bwd_workspace_bytes);
   MM_SYM(last_error, mm_last_error);
   MM_SYM(abi, mm_abi_version);
 #undef MM_SYM
@@ -268,6 +278,127 @@ at::Tensor kernel_pool(const at::Tensor& q, const at::Tensor& d, const c10::opti
   return KernelPool::apply(q, d, q_mask, d_mask, mu, sigma, alpha, w, gate, clamp_min);
 }
 
+// TKL scoring (sigir20_tkl.py:180-286 through mm_tkl_fwd / mm_tkl_bwd): the training step's node
+// without Python in its backward.  `scoring`: the parameter tensors of the packed vector in pack order; lo / cnt / full: where each
+// sits in the packed gradient, how many of its elements the kernels read, its own numel (lo < 0: a parameter the active saturation
+// never reads — its gradient stays undefined, as in the reference and in the Python node tkl._TKLScoreFn).
+class TklScore : public torch::autograd::Function<TklScore> {
+ public:
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& q_in, const at::Tensor& c_in,
+                                                const at::Tensor& chunk_mask, const at::Tensor& chunk_slot, const at::Tensor& q_mask,
+                                                const at::Tensor& packed_in, int64_t B, int64_t C, int64_t K, int64_t saturation,
+                                                at::TensorList scoring, const at::Tensor& layout) {
+    // layout: int64 [3, n] on the host = (lo, cnt, full) per scoring tensor (ONE argument: every element of an integer list would
+    // count as an input of the node)
+    TORCH_CHECK(layout.device().is_cpu() && layout.scalar_type() == at::kLong && layout.dim() == 2 && layout.size(0) == 3 &&
+                    layout.size(1) == (int64_t)scoring.size(), "mm_autograd: layout must be a host int64 [3, ", scoring.size(), "] tensor");
+    const at::Tensor lay = layout.contiguous();
+    const int64_t n_sc = lay.size(1);
+    std::vector<int64_t> lo(lay.data_ptr<int64_t>(), lay.data_ptr<int64_t>() + n_sc), cnt(lay.data_ptr<int64_t>() + n_sc, lay.data_ptr<int64_t>() + 2 * n_sc),
+        full(lay.data_ptr<int64_t>() + 2 * n_sc, lay.data_ptr<int64_t>() + 3 * n_sc);
+    TORCH_CHECK(api.handle, "mm_autograd: init(lib_path) was not called");
+    TORCH_CHECK(q_in.is_cuda() && q_in.dim() == 3 && c_in.dim() == 3 && q_in.scalar_type() == at::kFloat && c_in.scalar_type() == at::kFloat,
+                "mm_autograd: TKL scoring takes float32 q_ctx [B, Q, E] and chunks [P, 50, E] (tkl.yaml use_fp16: False)");
+    const at::Device dev = q_in.device();
+    for (const at::Tensor* t : {&c_in, &chunk_mask, &chunk_slot, &q_mask, &packed_in})
+      TORCH_CHECK(t->device() == dev, "mm_autograd: every TKL operand must be on ", dev, ", got ", t->device());
+    TORCH_CHECK(scoring.size() == lo.size() && lo.size() == cnt.size() && cnt.size() == full.size(), "mm_autograd: scoring layout lists differ in length");
+    const at::Tensor q = q_in.contiguous(), c = c_in.contiguous();
+    const int64_t Q = q.size(1), E = q.size(2), P = c.size(0);
+    TORCH_CHECK(q.size(0) == B && (P == 0 || (c.size(1) == 50 && c.size(2) == E)) && E % 4 == 0, "mm_autograd: bad TKL shapes q_ctx ", q.sizes(),
+                " chunks ", c.sizes());
+    const at::Tensor cm = chunk_mask.to(at::kFloat).contiguous(), cs = chunk_slot.to(at::kInt).contiguous(),
+                     qm = q_mask.to(at::kFloat).contiguous(), packed = packed_in.detach().to(at::kFloat).contiguous();
+    TORCH_CHECK(packed.numel() == MM_TKL_NPARAMS(K, E), "mm_autograd: packed parameters have ", packed.numel(), " elements");
+    const int64_t W = (std::max<int64_t>(C * 40, 30) - 30) / 2 + 1;
+    at::Tensor out = at::empty({B}, q.options()), win = at::empty({B, W}, q.options());
+    if (B > 0) {
+      const c10::DeviceGuard guard(dev);
+      const size_t wsb = api.tkl_fwd_ws(B, P, (int)C, (int)Q, (int)K);
+      at::Tensor ws = wsb ? at::empty({(int64_t)wsb}, q.options().dtype(at::kByte)) : at::Tensor();
+      void* stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+      check_rc(api.tkl_fwd(q.data_ptr(), P ? c.data_ptr() : nullptr, P ? cm.data_ptr<float>() : nullptr, P ? cs.data_ptr<int32_t>() : nullptr,
+                           qm.data_ptr<float>(), packed.data_ptr<float>(), win.data_ptr<float>(), out.data_ptr<float>(), B, P, (int)C, (int)Q,
+                           (int)E, (int)K, (int)saturation, wsb ? ws.data_ptr() : nullptr, wsb, stream),
+               "mm_tkl_fwd");
+    }
+    ctx->save_for_backward({q, c, cm, cs, qm, packed, win});
+    ctx->saved_data["C"] = C;
+    ctx->saved_data["K"] = K;
+    ctx->saved_data["sat"] = saturation;
+    ctx->saved_data["lo"] = lo;
+    ctx->saved_data["cnt"] = cnt;
+    ctx->saved_data["full"] = full;
+    std::vector<std::vector<int64_t>> shapes;
+    std::vector<int64_t> dtypes;
+    for (const at::Tensor& t : scoring) {
+      shapes.push_back(t.sizes().vec());
+      dtypes.push_back((int64_t)t.scalar_type());
+    }
+    ctx->saved_data["shapes"] = shapes;
+    ctx->saved_data["dtypes"] = dtypes;
+    ctx->saved_data["q_dtype"] = (int64_t)q_in.scalar_type();
+    ctx->mark_non_differentiable({win});
+    return {out, win};
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &q = saved[0], &c = saved[1], &cm = saved[2], &cs = saved[3], &qm = saved[4], &packed = saved[5], &win = saved[6];
+    const int64_t B = q.size(0), Q = q.size(1), E = q.size(2), P = c.size(0);
+    const int64_t C = ctx->saved_data["C"].toInt(), K = ctx->saved_data["K"].toInt(), sat = ctx->saved_data["sat"].toInt();
+    const auto lo = ctx->saved_data["lo"].toIntVector(), cnt = ctx->saved_data["cnt"].toIntVector(), full = ctx->saved_data["full"].toIntVector();
+    const int64_t NP = packed.numel();
+    at::Tensor gq = at::empty_like(q), gc = P ? at::empty_like(c) : at::zeros_like(c), gp;
+    if (B > 0) {
+      at::Tensor go = grads[0].reshape({-1});
+      TORCH_CHECK(go.device() == q.device(), "mm_autograd: grad_out on ", go.device(), ", the embeddings on ", q.device());
+      if (go.scalar_type() != at::kFloat) go = go.to(at::kFloat);
+      go = go.contiguous();
+      TORCH_CHECK(go.numel() == B, "mm_autograd: grad_out has ", go.numel(), " elements for ", B, " documents");
+      at::Tensor gpd = at::empty({B, NP}, q.options());
+      const c10::DeviceGuard guard(q.device());
+      const size_t wsb = api.tkl_bwd_ws(B, (int)C);
+      at::Tensor ws = at::empty({(int64_t)(wsb ? wsb : 16)}, q.options().dtype(at::kByte));
+      void* stream = c10::hip::getCurrentHIPStream(q.device().index()).stream();
+      check_rc(api.tkl_bwd(q.data_ptr(), P ? c.data_ptr() : nullptr, P ? cm.data_ptr<float>() : nullptr, P ? cs.data_ptr<int32_t>() : nullptr,
+                           qm.data_ptr<float>(), packed.data_ptr<float>(), win.data_ptr<float>(), go.data_ptr<float>(), gq.data_ptr<float>(),
+                           P ? gc.data_ptr<float>() : nullptr, gpd.data_ptr<float>(), B, P, (int)C, (int)Q, (int)E, (int)K, (int)sat,
+                           ws.data_ptr(), wsb, stream),
+               "mm_tkl_bwd");
+      gp = gpd.sum(0);                      // per-document rows -> one deterministic sum on the device
+    } else {
+      gp = at::zeros({NP}, q.options());
+    }
+    torch::autograd::variable_list out = {gq, gc, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                                          at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    const auto shapes = ctx->saved_data["shapes"].toList();
+    const auto dtypes = ctx->saved_data["dtypes"].toIntVector();
+    for (size_t i = 0; i < lo.size(); ++i) {
+      if (lo[i] < 0) {
+        out.push_back(at::Tensor());
+        continue;
+      }
+      at::Tensor g = gp.narrow(0, lo[i], cnt[i]);
+      if (full[i] != cnt[i]) {              // kernel_mult [4, 1, 1, 1, K]: only row 0 is read (:246)
+        at::Tensor z = at::zeros({full[i]}, gp.options());
+        z.narrow(0, 0, cnt[i]).copy_(g);
+        g = z;
+      }
+      const auto shape = shapes.get(i).toIntVector();
+      out.push_back(g.reshape(shape).to((at::ScalarType)dtypes[i]));
+    }
+    out.push_back(at::Tensor());            // layout
+    return out;
+  }
+};
+
+std::vector<at::Tensor> tkl_score(const at::Tensor& q_ctx, const at::Tensor& chunks, const at::Tensor& chunk_mask, const at::Tensor& chunk_slot,
+                                  const at::Tensor& q_mask, const at::Tensor& packed, int64_t B, int64_t C, int64_t K, int64_t saturation,
+                                  std::vector<at::Tensor> scoring, const at::Tensor& layout) {
+  return TklScore::apply(q_ctx, chunks, chunk_mask, chunk_slot, q_mask, packed, B, C, K, saturation, at::TensorList(scoring), layout);   // (a TensorList: every element an input of the node)
+}
+
 // the torch this file was compiled against: _fast.module() refuses the extension under another one (an artefact that
 // dlopens against an ABI-incompatible torch would crash the hot path instead of leaving it to the Python node)
 std::string built_torch_version() { return TORCH_VERSION; }
@@ -281,6 +412,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("kernel_pool", &kernel_pool, "TK kernel pooling (pair-per-row) with a native autograd node", py::arg("q"), py::arg("d"),
         py::arg("q_mask"), py::arg("d_mask"), py::arg("mu"), py::arg("sigma"), py::arg("alpha"), py::arg("w"), py::arg("gate"),
         py::arg("clamp_min"));
+  m.def("tkl_score", &tkl_score, "TKL scoring (score, window scores) with a native autograd node", py::arg("q_ctx"), py::arg("chunks"),
+        py::arg("chunk_mask"), py::arg("chunk_slot"), py::arg("q_mask"), py::arg("packed"), py::arg("B"), py::arg("C"), py::arg("K"),
+        py::arg("saturation"), py::arg("scoring"), py::arg("layout"));
   m.def("maxsim_paired", &maxsim_paired, "paired MaxSim with a native autograd node", py::arg("q"), py::arg("d"), py::arg("q_mask"),
         py::arg("d_mask"), py::arg("flags"));
 }

@@ -14,12 +14,13 @@ to 2,000 — and differentiates them: gradients w.r.t. the contextualised query,
 every scoring parameter).  (The same computation in differentiable torch ops, the reference the native backward is tested
 against, lives with the tests: tests/tkl_window_reference.py.)
 """
+import os
 from typing import List
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _fast, ops
 from ._lib import NativeError
 from .tk import sinusoid_positions
 
@@ -110,6 +111,26 @@ class _TKLScoreFn(torch.autograd.Function):
         return (gq.to(q_ctx.dtype), gc.to(chunks_ctx.dtype), None, None, None, None, *grads)
 
 
+def tkl_score_train(q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, packed, B, C, K, saturation, scoring, sizes, layout=None):
+    """(score, window scores) of mm_tkl_fwd with mm_tkl_bwd behind autograd: the C++ node of csrc_host/mm_autograd.cpp (TklScore)
+    when the host extension is built, the Python autograd.Function above otherwise (MM_TKL_PY_AUTOGRAD=1 forces it: A/B runs, tests).
+    `layout`: the cached host tensor of _layout_tensor(sizes)."""
+    fast = None if os.environ.get("MM_TKL_PY_AUTOGRAD", "0") not in ("", "0") else _fast.module()
+    if fast is not None and hasattr(fast, "tkl_score") and q_ctx.shape[-1] % 4 == 0:
+        if layout is None:
+            layout = _layout_tensor(sizes)
+        return fast.tkl_score(q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, packed, B, C, K,
+                              0 if saturation == "embedding" else 1, list(scoring), layout)
+    return _TKLScoreFn.apply(q_ctx, chunks_ctx, chunk_mask, chunk_slot, q_mask, (B, C, K, saturation, packed, sizes), *scoring)
+
+
+def _layout_tensor(sizes):
+    """(offset in the packed gradient, elements the kernels read, numel) per scoring tensor as ONE host int64 [3, n] tensor
+    (offset -1: the active saturation never reads the tensor — no gradient)."""
+    return torch.tensor([[-1 if n is None else n[0] for n in sizes], [0 if n is None else n[1] for n in sizes],
+                         [0 if n is None else n[2] for n in sizes]], dtype=torch.int64)
+
+
 class TKL_sigir20(nn.Module):
     """TKL: TK for long documents (https://arxiv.org/abs/2005.04908)."""
 
@@ -181,6 +202,7 @@ class TKL_sigir20(nn.Module):
         self.dense = nn.Linear(n_kernels, 1, bias=False)
         torch.nn.init.uniform_(self.dense.weight, -0.014, 0.014)
         self._packed = None
+        self._layout, self._layout_key = None, None      # (lo, cnt, full) of the scoring tensors for the C++ node
 
     # ------------------------------------------------------------------ native parameter vector
     def pack_params(self) -> torch.Tensor:
@@ -227,8 +249,10 @@ class TKL_sigir20(nn.Module):
         if torch.is_grad_enabled() and (query_ctx.requires_grad or chunks_ctx.requires_grad or
                                         any(p.requires_grad for p in self._scoring_parameters())):
             scoring, sizes = self._pack_layout()
-            score, win = _TKLScoreFn.apply(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
-                                           (B, C, K, saturation, self.pack_params(), sizes), *scoring)
+            if self._layout_key != tuple(sizes):
+                self._layout, self._layout_key = _layout_tensor(sizes), tuple(sizes)
+            score, win = tkl_score_train(query_ctx.float(), chunks_ctx.float(), chunk_mask, chunk_slot, query_pad_oov_mask,
+                                         self.pack_params(), B, C, K, saturation, scoring, sizes, self._layout)
             peaks = region_peaks(win.detach()) if output_secondary_output else None
         else:
             with torch.no_grad():

@@ -245,6 +245,44 @@ def test_tkl_training_gradients_match_the_real_class(sat):
     assert torch.equal(plain, score.detach())
 
 
+@pytest.mark.parametrize("sat", ["embedding", "log"])
+def test_cpp_autograd_node_of_tkl_equals_the_python_node(monkeypatch, sat):
+    """TKL_sigir20.forward in train mode routes the scoring through csrc_host/mm_autograd.cpp TklScore when the host extension is
+    built (MM_TKL_PY_AUTOGRAD=1: the Python autograd.Function).  Both issue mm_tkl_fwd / mm_tkl_bwd: scores and every gradient —
+    inputs and each scoring parameter, None where the active saturation never reads a parameter — bit-equal."""
+    from matchmaker_amd import _fast
+    if _fast.module() is None or not hasattr(_fast.module(), "tkl_score"):
+        pytest.skip("host extension not built (python -m matchmaker_amd.build)")
+    dev = util.require_gpu()
+    torch.manual_seed(5)
+    m = make_model(64, sat, dev).train()
+    B, Q, D = 5, 12, 900
+    q = torch.randn(B, Q, 64, device=dev)
+    d = torch.randn(B, D, 64, device=dev)
+    qm = (torch.arange(Q, device=dev)[None] < torch.tensor([12, 3, 7, 1, 9], device=dev)[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < torch.tensor([900, 130, 41, 512, 77], device=dev)[:, None]).float()
+    go = torch.randn(B, device=dev)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        qq, dd = q.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        s = m.forward(qq, dd, qm, dm)
+        (s * go).sum().backward()
+        return s.detach(), qq.grad, dd.grad, {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}
+
+    s_c, gq_c, gd_c, gp_c = run()
+    monkeypatch.setenv("MM_TKL_PY_AUTOGRAD", "1")
+    s_p, gq_p, gd_p, gp_p = run()
+    assert torch.equal(s_c, s_p) and torch.equal(gq_c, gq_p) and torch.equal(gd_c, gd_p)
+    assert gp_c.keys() == gp_p.keys()
+    for n in gp_c:
+        assert (gp_c[n] is None) == (gp_p[n] is None), n
+        if gp_c[n] is not None:
+            assert torch.equal(gp_c[n], gp_p[n]), n
+    assert gq_c.abs().sum() > 0 and torch.isfinite(gq_c).all() and torch.isfinite(gd_c).all()
+
+
 def test_tkl_full_model_trains_end_to_end():
     """The whole drop-in (Transformer contextualiser included) takes an optimiser step in train mode."""
     dev = util.require_gpu()
