@@ -453,10 +453,12 @@ print("ACCEPTED")
 
 def _epilogue_cases(dev):
     """(label, B, Q, D, E, sat, seed): config 3 at 1,024 documents; Q <= 10 (ONE token group: the window output buffer is
-    also the plane the finalizer reads — win == win_final inside the kernel); Q = 30 (three groups); short documents."""
+    also the plane the finalizer reads — win == win_final inside the kernel); Q = 30 (three groups); short documents; E = 100 / 200."""
     return [("config3_1024", 1024, 20, 2048, 300, "embedding", 11), ("one_group_q7", 96, 7, 2048, 300, "embedding", 12),
             ("one_group_q10_log", 64, 10, 700, 64, "log", 13), ("three_groups_q30", 64, 30, 2048, 300, "embedding", 14),
-            ("short_docs", 200, 20, 90, 128, "embedding", 15)]
+            ("short_docs", 200, 20, 90, 128, "embedding", 15),
+            # the other two widths of the streaming stage-1 kernels (4 and 7 k-steps of 32; uneven K halves in the K-split twin)
+            ("e100_q12", 40, 12, 700, 100, "embedding", 16), ("e200_q20_log", 32, 20, 500, 200, "log", 17)]
 
 
 def _epilogue_inputs(dev, B, Q, D, E, sat, seed):
