@@ -370,6 +370,9 @@ int mm_tkl_fwd_peaks(const void* q_ctx, const void* chunks, const float* chunk_m
  *   sum over the documents on the host side (deterministic, no atomics).  Q <= 32.
  * Workspace: mm_tkl_bwd_workspace_bytes(B, C). */
 size_t mm_tkl_bwd_workspace_bytes(int64_t B, int C);
+/* ... plus the per-region shares of grad_q and of the parameter rows of a small batch (3 B <= 256: three workgroups per document,
+ * one per arg-max region).  Optional: with the smaller workspace above every document gets one workgroup. */
+size_t mm_tkl_bwd_workspace_bytes2(int64_t B, int C, int Q, int E);
 int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
                const float* q_mask, const float* params, const float* win_scores, const float* grad_out,
                float* grad_q, float* grad_chunks, float* grad_params,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mm_kernel_pool_ex_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _c.c_float, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_tkl_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "mm_tkl_bwd_workspace_bytes2": (_sz, [_i64, _i, _i, _i]),
     "mm_tkl_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mm_kernel_pool_multi_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i, _i, _i]),
     "mm_kernel_pool_multi_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _c.c_float, _vp, _i64, _i64,

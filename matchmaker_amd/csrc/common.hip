@@ -39,6 +39,7 @@ const EnvCfg& env() {
     c.dot_no_spread = env_int("MM_DOT_NO_SPREAD", 0);
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
     c.tkl_fold_regions = env_int("MM_TKL_FOLD_REGIONS", 0);
+    c.tkl_bwd_nosplit = env_int("MM_TKL_BWD_NOSPLIT", 0);
     c.kp128_occ = env_int("MM_KP128_OCC", 0);
     c.kp_multi_2d = env_int("MM_KP_MULTI_2D", 0);
     c.kp_multi_wg = env_int("MM_KP_MULTI_WG", 0);

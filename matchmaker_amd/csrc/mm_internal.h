@@ -51,6 +51,7 @@ struct EnvCfg {
                               // 47.3 — but 9.68 vs 8.65 ms: one wavefront per SIMD cannot hide the RBF epilogue that bounds the launch; A/B runs)
   int kp_multi_2d = 0;        // MM_KP_MULTI_2D=1: Conv-KNRM's multi launch on the 2-D grid of rounds 1-4 instead of the flat XCD-grouped order (A/B runs)
   int kp128_occ = 0;          // MM_KP128_OCC: 0 = choose by shape, 1 / 2 = wavefronts per SIMD of the 64n-wide pooling kernel (A/B runs)
+  int tkl_bwd_nosplit = 0;    // MM_TKL_BWD_NOSPLIT=1: TKL's backward with one workgroup per document at every batch size (A/B runs)
   int tkl_fold_regions = 0;   // MM_TKL_FOLD_REGIONS=1: TKL's region top-k in the last window workgroup of each document (round 4's default) instead of
                               // its own launch (A/B runs: the hand-off written to the memory model costs +50 us per 256-document call, see tkl.hip)
   int tkl_pairsums = 0;     // MM_TKL_PAIRSUMS: TKL stage 1 emits pair sums (round-2 data path) instead of cosines (A/B runs)

@@ -42,6 +42,12 @@ struct TklBwdArgs {
   float* gchunks;           // [P, 50, E] (zero-initialised by the caller)
   float* gprm;              // [B, NP]
   int C, Q, E, W, NP, sat;
+  // small batches (tkl_bwd_tiled_kernel): nsplit = 3 workgroups per document, one per arg-max region; each leaves its share of
+  // grad_q in part_gq [B, 3, Q, E] and of the parameter row in part_gp [B, 3, NP]; tkl_bwd_combine_kernel adds them in region order
+  int nsplit;
+  float* part_gq;
+  float* part_gp;
+  int32_t* flags;           // [B, 3] zero before the launch: region r of document b has written its chunk rows
 };
 
 __global__ void __launch_bounds__(kBwdThreads) tkl_bwd_kernel(const TklBwdArgs a) {
@@ -415,7 +421,21 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
   constexpr int TPW = 16 / NW;           // 32-column tiles of E per wavefront (E <= 512)
   constexpr int PP = NTHR / 256;         // threads per (token, kernel) in the pooling phase: 2 x 15 positions, or 4 x 8
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  // Small batches (the reference trains 32 x 2 = 64 documents, defaults.yaml:114: 64 workgroups on 256 CUs, each walking its
+  // document's three regions one after the other — 91 % of a document's 515 k cycles are per-region work): three workgroups per
+  // document, workgroup r0 takes arg-max region r0.  Everything a region adds to — grad_q, the parameter row — is linear in the
+  // regions' sums, so each workgroup writes its share and tkl_bwd_combine_kernel adds the three in region order.  The chunk rows
+  // of regions may overlap by a few positions (peaks 15 .. 18 windows apart, or a document of < 40 windows: a few per cent of the
+  // documents).  The region order of the one-workgroup launch is kept for those rows: a workgroup whose region touches an earlier
+  // region's rows waits for the earlier workgroups' flags (raised after their last row store, behind an agent-scope release)
+  // before its read-add-write — same sums in the same order, bit for bit, and no atomics.  Workgroups are dispatched in index
+  // order and a region-0 workgroup never waits, so the wait cannot deadlock.  (Tried first: workgroup 0 walking all three regions
+  // of such a document — one such document in the batch and the launch is as long as before; float atomics onto the zero-filled
+  // rows — a document of < 40 windows has three addends per row and the bits changed from run to run.)
+  const int S = a.nsplit;
+  const int b = S > 1 ? (int)(blockIdx.x / 3u) : (int)blockIdx.x;
+  const int r0 = S > 1 ? (int)(blockIdx.x - 3u * (unsigned)b) : 0;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = tid & 31, lh = (tid >> 5) & 1;          // MFMA lane coordinates within the wavefront
   const int C = a.C, Q = a.Q, E = a.E, W = a.W;
@@ -462,7 +482,7 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
   __shared__ int top_s[3];
 
   const float* qb = a.q_ctx + (int64_t)b * Q * E;
-  float* gq = a.gq + (int64_t)b * Q * E;
+  float* gq = S > 1 ? a.part_gq + ((int64_t)b * 3 + r0) * Q * E : a.gq + (int64_t)b * Q * E;
   const float g = a.go[b];
 #if MM_TKL_BWD_PHASE_TIMES
   float ph[16] = {0};
@@ -601,12 +621,18 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
       // does region r touch positions of an earlier region?  (peaks are >= 15 windows = 30 positions apart and a region
       // spans <= 38: rarely) — only then must its chunk rows be read before they are added to
       const int p0 = hi >= 0 ? 2 * lo : 0, p1 = hi >= 0 ? 2 * hi + kBwdT : 0;
-      int ov = 0;
-      for (int o = 0; o < 2; ++o) {
+      int ov = 0, ova = 0;
+      for (int o = 0; o < 3; ++o) {
         const int q0 = __shfl(p0, o, 64), q1 = __shfl(p1, o, 64);
-        if (o < lane && q1 > q0 && p1 > p0 && q0 < p1 && p0 < q1) ov = 1;
+        const bool hit = o != lane && q1 > q0 && p1 > p0 && q0 < p1 && p0 < q1;
+        if (hit && o < lane) ov = 1;
+        if (hit) ova = 1;
       }
       rinf[8 + lane] = ov;
+      // ... or of ANY other region (bit r of rinf[3]): with one workgroup per region (a.nsplit = 3) such a workgroup publishes its
+      // rows with a release before it raises its flag (below)
+      const unsigned long long am = __ballot(ova != 0);
+      if (lane == 0) rinf[3] = (int)(am & 7ull);
     }
   }
   __syncthreads();
@@ -694,6 +720,7 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
   for (int n = 0; n < nv; ++n) {
     const int j = wlist[n];
     const int r = j % 3;
+    if (S > 1 && r != r0) continue;                                 // (wave-uniform) one workgroup per region
     const bool first = n == 0 || wlist[n - 1] % 3 != r;            // (wave-uniform: LDS values)
     const bool last = n + 1 == nv || wlist[n + 1] % 3 != r;
     const int* prow = prowA + j * 32;
@@ -879,6 +906,14 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
     if (!last) continue;                                          // (wave-uniform)
 
     // ---- the region's gradient products: its <= 38 positions as two blocks of 32 rows -------------------------------------
+    if (S > 1 && rinf[8 + r] != 0) {                               // (wave-uniform) the earlier regions' rows first: see the top
+      if (tid == 0) {
+        for (int e2 = 0; e2 < r0; ++e2)
+          while (__hip_atomic_load(a.flags + (int64_t)b * 3 + e2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
     for (int hb = 0; hb < 2; ++hb) {
       if (32 * hb >= rinf[4 + r]) break;
       const int* ptab = prowR + r * 64 + 32 * hb;
@@ -1020,6 +1055,13 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
     }
   }
 
+  if (S > 1) {                                                     // this region's chunk rows are written (the block loop ends with a barrier)
+    __syncthreads();
+    if (tid == 0) {
+      if ((rinf[3] >> r0) & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // another region's workgroup reads them
+      __hip_atomic_store(a.flags + (int64_t)b * 3 + r0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // ---- grad_q = rq (sum_w sum_t G dh - (sum G c) q / |q|) + dev emb_w; parameter rows of this document -----------------
   const bool emb_sat = a.sat == MM_TKL_SAT_EMBEDDING;
 #pragma unroll
@@ -1041,7 +1083,7 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
         if (mrow(i) + 4 * lh < Q) gq[(uint32_t)((mrow(i) + 4 * lh) * E + col)] = ov[i];
     }
   }
-  float* gp = a.gprm + (int64_t)b * a.NP;
+  float* gp = S > 1 ? a.part_gp + ((int64_t)b * 3 + r0) * a.NP : a.gprm + (int64_t)b * a.NP;
   if (emb_sat) {
     for (int e = tid; e < E; e += NTHR) {
       float s = 0.0f;
@@ -1068,9 +1110,10 @@ __global__ void __launch_bounds__(NTHR) tkl_bwd_tiled_kernel(const TklBwdArgs a)
 }
 
 // slot2p for the backward (the forward's preparation kernels live in tkl.hip)
-__global__ void __launch_bounds__(256) tkl_bwd_fill_kernel(int32_t* slot2p, int64_t n) {
+__global__ void __launch_bounds__(256) tkl_bwd_fill_kernel(int32_t* slot2p, int64_t n, int32_t* flags, int64_t nflags) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) slot2p[i] = -1;
+  if (i < nflags) flags[i] = 0;                            // (region flags of the three-workgroup launch; nflags <= 3 * 85 < n's grid)
 }
 __global__ void __launch_bounds__(256) tkl_bwd_slot_kernel(const int32_t* __restrict__ chunk_slot, int64_t P, int64_t BC,
                                                            int32_t* __restrict__ slot2p) {
@@ -1085,7 +1128,29 @@ __global__ void __launch_bounds__(256) tkl_bwd_slot_kernel(const int32_t* __rest
 
 using namespace mm;
 
+// grad_q and the parameter row of a document whose three regions went to three workgroups: the shares added in region order
+__global__ void __launch_bounds__(256) tkl_bwd_combine_kernel(const float* __restrict__ part_gq, const float* __restrict__ part_gp,
+                                                              float* __restrict__ gq, float* __restrict__ gp, int QE, int NP) {
+  const int64_t b = blockIdx.x;
+  const float* pq = part_gq + b * 3 * QE;
+  for (int i = 4 * threadIdx.x; i < QE; i += 1024) {
+    const f32x4 x0 = *(const f32x4*)(pq + i), x1 = *(const f32x4*)(pq + QE + i), x2 = *(const f32x4*)(pq + 2 * QE + i);
+    *(f32x4*)(gq + b * QE + i) = (x0 + x1) + x2;
+  }
+  const float* pp = part_gp + b * 3 * NP;
+  for (int i = threadIdx.x; i < NP; i += 256) gp[b * NP + i] = (pp[i] + pp[NP + i]) + pp[2 * NP + i];
+}
+
 extern "C" size_t mm_tkl_bwd_workspace_bytes(int64_t B, int C) { return ((size_t)B * C * 4 + 255) & ~(size_t)255; }
+
+// ... + the per-region shares of grad_q and of the parameter rows when the batch is small enough for three workgroups per document
+// (3 B <= 256 CUs).  Optional: with the smaller workspace above every document gets one workgroup.
+static bool tkl_bwd_splits(int64_t B) { return 3 * B <= kCUs && !env().tkl_bwd_nosplit; }
+extern "C" size_t mm_tkl_bwd_workspace_bytes2(int64_t B, int C, int Q, int E) {
+  const size_t base = mm_tkl_bwd_workspace_bytes(B, C);
+  if (B <= 0 || !tkl_bwd_splits(B) || Q <= 0 || E <= 0) return base;
+  return base + (((size_t)B * 3 * ((size_t)Q * E + MM_TKL_NPARAMS(kK, E)) * 4 + 255) & ~(size_t)255) + (((size_t)B * 3 * 4 + 255) & ~(size_t)255);
+}
 
 extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* chunk_mask, const int32_t* chunk_slot,
                           const float* q_mask, const float* params, const float* win_scores, const float* grad_out,
@@ -1107,7 +1172,16 @@ extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* ch
   const int W = ((C * 40 > 30 ? C * 40 : 30) - 30) / 2 + 1;
   const int Wp = W < 3 ? 3 : W;
   int32_t* slot2p = (int32_t*)workspace;
-  hipLaunchKernelGGL(tkl_bwd_fill_kernel, dim3((unsigned)((B * (int64_t)C + 255) / 256)), dim3(256), 0, stream, slot2p, B * (int64_t)C);
+  // (the flags of the three-workgroups-per-document launch sit behind the per-region shares; zeroed here whenever the workspace has them)
+  const size_t ws_base = mm_tkl_bwd_workspace_bytes(B, C);
+  const size_t ws_shares = (size_t)B * 3 * ((size_t)Q * E + MM_TKL_NPARAMS(K, E)) * 4, ws_flags = ((size_t)B * 3 * 4 + 255) & ~(size_t)255;
+  const bool can_split = tkl_bwd_splits(B) && !(E & 3) && workspace_bytes >= ws_base + ws_shares + ws_flags;
+  int32_t* flags = can_split ? (int32_t*)((char*)workspace + ws_base + ws_shares) : nullptr;
+  {
+    const int64_t nfill = B * (int64_t)C > 3 * B ? B * (int64_t)C : 3 * B;
+    hipLaunchKernelGGL(tkl_bwd_fill_kernel, dim3((unsigned)((nfill + 255) / 256)), dim3(256), 0, stream, slot2p, B * (int64_t)C, flags,
+                       flags ? 3 * B : (int64_t)0);
+  }
   if (P > 0) {
     hipLaunchKernelGGL(tkl_bwd_slot_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, chunk_slot, P, B * (int64_t)C, slot2p);
     if (hipMemsetAsync(grad_chunks, 0, (size_t)P * 50 * E * sizeof(float), stream) != hipSuccess)
@@ -1124,13 +1198,27 @@ extern "C" int mm_tkl_bwd(const void* q_ctx, const void* chunks, const float* ch
     const size_t tl = tkl_bwd_tiled_lds_bytes(Wp, Q, E, nthr);
     if (!(E & 3) && E <= 512 && tl <= 150 * 1024 && !env().kp_bwd_untiled &&
         !(((uintptr_t)q_ctx | (uintptr_t)chunks | (uintptr_t)grad_q | (uintptr_t)grad_chunks | (uintptr_t)params) & 15)) {
+      // three workgroups per document when the batch leaves CUs idle and the caller sized the workspace for the shares
+      a.nsplit = 1;
+      if (can_split) {
+        a.nsplit = 3;
+        a.part_gq = (float*)((char*)workspace + ws_base);
+        a.part_gp = a.part_gq + (size_t)B * 3 * Q * E;
+        a.flags = flags;
+      }
       auto go = [&](auto kern) {
         if (tl > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3((unsigned)nthr), tl, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * a.nsplit)), dim3((unsigned)nthr), tl, stream, a);
       };
       // a thread's share of a block of rows in 16-byte chunks: five (E <= 320) or eight
       E <= 320 ? go(tkl_bwd_tiled_kernel<5, 512>) : go(tkl_bwd_tiled_kernel<8, 512>);
-      return check_launch("tkl_bwd_tiled_kernel");
+      if (int e = check_launch("tkl_bwd_tiled_kernel")) return e;
+      if (a.nsplit > 1) {
+        hipLaunchKernelGGL(tkl_bwd_combine_kernel, dim3((unsigned)B), dim3(256), 0, stream, (const float*)a.part_gq, (const float*)a.part_gp,
+                           grad_q, grad_params, Q * E, a.NP);
+        return check_launch("tkl_bwd_combine_kernel");
+      }
+      return MM_OK;
     }
   }
   const size_t lds = ((size_t)2 * Wp + 2 * kBwdQ * kBwdT + 2 * kBwdQ * kK + kBwdQ * 40 + 7 * kBwdQ + 4 * (kBwdT + 2) + 16 + kBwdT + 2) * 4;

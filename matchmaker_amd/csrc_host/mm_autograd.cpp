@@ -40,7 +40,7 @@ struct Api {
   decltype(&mm_tkl_fwd) tkl_fwd = nullptr;
   decltype(&mm_tkl_bwd) tkl_bwd = nullptr;
   decltype(&mm_tkl_workspace_bytes) tkl_fwd_ws = nullptr;
-  decltype(&mm_tkl_bwd_workspace_bytes) tkl_bwd_ws = nullptr;
+  decltype(&mm_tkl_bwd_workspace_bytes2) tkl_bwd_ws = nullptr;
   decltype(&mm_last_error) last_error = nullptr;
   decltype(&mm_abi_version) abi = nullptr;
 } api;
@@ -63,7 +63,7 @@ void init(const std::string& lib_path) {
   MM_SYM(tkl_fwd, mm_tkl_fwd);
   MM_SYM(tkl_bwd, mm_tkl_bwd);
   MM_SYM(tkl_fwd_ws, mm_tkl_workspace_bytes);
-  MM_SYM(tkl_bwd_ws, mm_tkl_bwd_workspace_bytes);
+  MM_SYM(tkl_bwd_ws, mm_tkl_bwd_workspace_bytes2);
   MM_SYM(last_error, mm_last_error);
   MM_SYM(abi, mm_abi_version);
 #undef MM_SYM
@@ -358,7 +358,7 @@ class TklScore : public torch::autograd::Function<TklScore> {
       TORCH_CHECK(go.numel() == B, "mm_autograd: grad_out has ", go.numel(), " elements for ", B, " documents");
       at::Tensor gpd = at::empty({B, NP}, q.options());
       const c10::DeviceGuard guard(q.device());
-      const size_t wsb = api.tkl_bwd_ws(B, (int)C);
+      const size_t wsb = api.tkl_bwd_ws(B, (int)C, (int)Q, (int)E);
       at::Tensor ws = at::empty({(int64_t)(wsb ? wsb : 16)}, q.options().dtype(at::kByte));
       void* stream = c10::hip::getCurrentHIPStream(q.device().index()).stream();
       check_rc(api.tkl_bwd(q.data_ptr(), P ? c.data_ptr() : nullptr, P ? cm.data_ptr<float>() : nullptr, P ? cs.data_ptr<int32_t>() : nullptr,

@@ -668,7 +668,7 @@ def tkl_bwd(q_ctx: torch.Tensor, chunks: torch.Tensor, chunk_mask: torch.Tensor,
         return gq, gc.zero_(), torch.zeros(NP, dtype=torch.float32, device=dev)
     L = _lib.lib()
     with torch.cuda.device(dev):
-        wsb = L.mm_tkl_bwd_workspace_bytes(B, C)
+        wsb = L.mm_tkl_bwd_workspace_bytes2(B, C, Q, E)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         rc = L.mm_tkl_bwd(q_ctx.data_ptr(), chunks.data_ptr() if P else None, chunk_mask.data_ptr() if P else None,
                           chunk_slot.data_ptr() if P else None, q_mask.data_ptr(), params.data_ptr(), win.data_ptr(), go.data_ptr(),

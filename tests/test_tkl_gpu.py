@@ -283,6 +283,48 @@ def test_cpp_autograd_node_of_tkl_equals_the_python_node(monkeypatch, sat):
     assert gq_c.abs().sum() > 0 and torch.isfinite(gq_c).all() and torch.isfinite(gd_c).all()
 
 
+def test_backward_with_three_workgroups_per_document_equals_the_one_workgroup_launch():
+    """mm_tkl_bwd: up to 85 documents (3 B <= 256 CUs; the reference trains 64) every document's three arg-max regions go to three
+    workgroups whose shares tkl_bwd_combine_kernel adds in region order; larger batches walk the regions in one workgroup.  The same
+    documents through both launches (90 documents at once vs the first 30 alone): chunk-row gradients bit-equal (a region's rows
+    are one workgroup's work either way), grad_q and the parameter rows within summation-order rounding.  A caller with the older,
+    smaller workspace (mm_tkl_bwd_workspace_bytes) gets the one-workgroup launch."""
+    from matchmaker_amd import ops, _lib
+    dev = util.require_gpu()
+    big, n = 90, 30
+    q_ctx, chunks, cmask, slot, qm, params, B, C, sat = _epilogue_inputs(dev, big, 20, 1500, 300, "embedding", 31)
+    s, win = ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, sat, return_windows=True)
+    go = torch.randn(big, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    gq1, gc1, gp1 = ops.tkl_bwd(q_ctx, chunks, cmask, slot, qm, params, win, go, big, C, 11, sat)          # one workgroup per document
+    keep = slot < n * C
+    Pn = int(keep.sum())
+    gq3, gc3, gp3 = ops.tkl_bwd(q_ctx[:n].contiguous(), chunks[:Pn].contiguous(), cmask[:Pn].contiguous(), slot[:Pn].contiguous(),
+                                qm[:n].contiguous(), params, win[:n].contiguous(), go[:n].contiguous(), n, C, 11, sat)
+    assert torch.equal(gc3, gc1[:Pn]), "chunk-row gradients"
+    scale = float(gq1[:n].abs().max())
+    assert float((gq3 - gq1[:n]).abs().max()) <= 2e-6 * max(scale, 1.0)
+    assert torch.isfinite(gq3).all() and torch.isfinite(gp3).all() and gq3.abs().sum() > 0
+    # parameter rows are summed over the documents by the operator: compare against the per-document rows of the large launch
+    L = _lib.lib()
+    P, Q, E = chunks.shape[0], q_ctx.shape[1], q_ctx.shape[2]
+    NP = params.numel()
+    assert L.mm_tkl_bwd_workspace_bytes2(n, C, Q, E) > L.mm_tkl_bwd_workspace_bytes(n, C)
+    assert L.mm_tkl_bwd_workspace_bytes2(big, C, Q, E) == L.mm_tkl_bwd_workspace_bytes(big, C)
+    wsb = L.mm_tkl_bwd_workspace_bytes(n, C)                                                           # the smaller workspace
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    gq0 = torch.empty(n, Q, E, device=dev)
+    gc0 = torch.empty(Pn, 50, E, device=dev)
+    gp0 = torch.empty(n, NP, device=dev)
+    a = [t.contiguous() for t in (q_ctx[:n], chunks[:Pn], cmask[:Pn].float(), slot[:Pn].to(torch.int32), qm[:n].float(), params, win[:n], go[:n])]
+    rc = L.mm_tkl_bwd(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(), a[5].data_ptr(), a[6].data_ptr(),
+                      a[7].data_ptr(), gq0.data_ptr(), gc0.data_ptr(), gp0.data_ptr(), n, Pn, C, Q, E, 11, 0, ws.data_ptr(), wsb,
+                      torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0, L.mm_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(gq0, gq1[:n]) and torch.equal(gc0, gc1[:Pn])
+    np.testing.assert_allclose(gp3.cpu().numpy(), gp0.sum(0).cpu().numpy(), rtol=2e-5, atol=1e-5 * float(gp0.sum(0).abs().max()))
+
+
 def test_tkl_full_model_trains_end_to_end():
     """The whole drop-in (Transformer contextualiser included) takes an optimiser step in train mode."""
     dev = util.require_gpu()

@@ -45,7 +45,7 @@ def main():
     gp = torch.empty(B, NP, device=dev)
     cm = cmask.to(torch.float32).contiguous()
     sl = slot.to(torch.int32).contiguous()
-    wsb = L.mm_tkl_bwd_workspace_bytes(B, C)
+    wsb = L.mm_tkl_bwd_workspace_bytes2(B, C, Qt, Et)       # (with the per-region shares when the batch is small: three workgroups per document)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     for it in range(4):
