@@ -1144,8 +1144,22 @@ __global__ void __launch_bounds__(256) tkl_bwd_combine_kernel(const float* __res
 extern "C" size_t mm_tkl_bwd_workspace_bytes(int64_t B, int C) { return ((size_t)B * C * 4 + 255) & ~(size_t)255; }
 
 // ... + the per-region shares of grad_q and of the parameter rows when the batch is small enough for three workgroups per document
-// (3 B <= 256 CUs).  Optional: with the smaller workspace above every document gets one workgroup.
-static bool tkl_bwd_splits(int64_t B) { return 3 * B <= kCUs && !env().tkl_bwd_nosplit; }
+// (3 B <= the device's CUs).  Optional: with the smaller workspace above every document gets one workgroup.
+// The region workgroups of a document wait for each other's flags, so all 3 B workgroups must be able to be resident at once (one
+// per CU: ~100 KB of LDS each): the device's CU count is asked from the runtime (a partitioned MI355X shows fewer than 256), never
+// assumed.
+static int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+    cus[dev] = n;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+static bool tkl_bwd_splits(int64_t B) { return 3 * B <= device_cus() && !env().tkl_bwd_nosplit; }
 extern "C" size_t mm_tkl_bwd_workspace_bytes2(int64_t B, int C, int Q, int E) {
   const size_t base = mm_tkl_bwd_workspace_bytes(B, C);
   if (B <= 0 || !tkl_bwd_splits(B) || Q <= 0 || E <= 0) return base;
