@@ -580,6 +580,40 @@ def test_stage1_kernels_agree_with_the_row_streaming_default(tmp_path, switch):
             assert off.mean() <= 0.01, f"{k}: {int(off.sum())} of {off.size} document scores differ (region ties are rarer than that)"
 
 
+def test_scores_do_not_depend_on_the_batch_and_wavefronts_with_more_than_64_chunks_reload_their_metadata():
+    """tkl_stage1_rows_kernel gives every wavefront a run of consecutive packed chunks and prefetches the chunks' metadata 64 at a
+    time (one lane each); past 65,536 chunks a wavefront owns more than 64 and reloads.  3,200 documents of 1,600-2,048 tokens
+    = ~120 k chunks: the scores and window scores of documents at both ends of the batch are bit-equal to the same documents
+    scored in a batch of their own (a chunk's cosines do not depend on which wavefront computes them)."""
+    from matchmaker_amd import ops
+    from matchmaker_amd.tkl import chunk_documents
+    dev = util.require_gpu()
+    B, Q, D, E = 3200, 20, 2048, 300
+    gen = torch.Generator(device=dev).manual_seed(77)
+    m = make_model(E, "embedding", dev, seed=77)
+    params = m.pack_params()
+    q = torch.randn(B, Q, E, generator=gen, device=dev)
+    q_len = torch.randint(1, Q + 1, (B,), generator=gen, device=dev)
+    d_len = torch.randint(1600, D + 1, (B,), generator=gen, device=dev)
+    qm = (torch.arange(Q, device=dev)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D, device=dev)[None] < d_len[:, None]).float()
+    q_ctx = q * qm.unsqueeze(-1)
+    d = torch.randn(B, D, E, generator=gen, device=dev, dtype=torch.float32)
+    d *= dm.unsqueeze(-1)
+    chunks, cmask, slot, C = chunk_documents(d, dm)
+    assert chunks.shape[0] > 65536 + 1024
+    s_all, w_all = ops.tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, "embedding", return_windows=True)
+    del chunks, cmask, slot
+    torch.cuda.empty_cache()
+    pick = torch.cat([torch.arange(0, 6, device=dev), torch.arange(B // 2, B // 2 + 6, device=dev), torch.arange(B - 6, B, device=dev)])
+    ch2, cm2, sl2, C2 = chunk_documents(d[pick].contiguous(), dm[pick].contiguous())
+    assert C2 == C
+    s_sub, w_sub = ops.tkl_score(q_ctx[pick].contiguous(), ch2, cm2, sl2, qm[pick].contiguous(), params, pick.numel(), C2, 11, "embedding",
+                                 return_windows=True)
+    assert torch.isfinite(s_all).all()
+    assert torch.equal(w_sub, w_all[pick]) and torch.equal(s_sub, s_all[pick])
+
+
 def _stability_run():
     """200 calls of mm_tkl_fwd_peaks on ONE input through the C ABI, poisoned workspace, racing side stream; see the test."""
 
