@@ -42,7 +42,8 @@ constexpr int kDotSample = 16384;  // sample size (documents) of phase 1 when th
 constexpr int kSortMax = 16384;    // rows of sort_rows_kernel are padded to a power of two <= this
 
 enum { DOT_SAMPLE = 0, DOT_FILTER = 1 };
-constexpr int kStageW = 192;        // LDS staging entries (score, document, query) per wavefront
+constexpr int kStageW = 256;        // LDS staging entries (score, code: 8 bytes) per wavefront
+constexpr int64_t kStageRel = (1 << 21) - 1;  // a staged code counts blocks from b_base in 21 bits
 
 struct DotArgs {
   const void* q;      // [nq, E]
@@ -62,7 +63,9 @@ struct DotArgs {
   int32_t* cand_idx;  // [nq, cap] document index inside the shard
   int cap;
   int spread;         // LDS-DMA of block b + 1 spread over block b's K loop (default; MM_DOT_NO_SPREAD=1: all at once)
-  unsigned long long* prof;  // optional [grid * 4 wavefronts][6] cycle counters (MM_DOT_PROF=1, tools only)
+  int flush_every;    // FILTER: blocks between the workgroup's common staging flushes (launch_dot: from `expect`)
+  double expect;      // FILTER: expected fraction of a query's scores above its threshold
+  unsigned long long* prof;  // optional [grid * 4 wavefronts][8] cycle counters (MM_DOT_PROF=1, tools only)
 };
 
 template <int DT>
@@ -186,21 +189,30 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   // area: positions come from the ballot of the compare (popcount + mbcnt), the fill level lives in a
   // scalar register — no atomics, no waits.  A wavefront flushes its own area to the per-query
   // candidate lists when it runs full; only that flush uses returning global atomics (which force
-  // vmcnt(0), i.e. drain this wavefront's LDS-DMA prefetch: once every ~40 blocks instead of on
-  // nearly every block).
-  float* st_score = (float*)(smem + NBUF * BLK) + w * kStageW;            // [4][kStageW]
-  int* st_doc = (int*)(smem + NBUF * BLK + 4 * kStageW * 4) + w * kStageW;  // [4][kStageW]
-  int* st_q = (int*)(smem + NBUF * BLK + 8 * kStageW * 4) + w * kStageW;    // [4][kStageW]
+  // vmcnt(0), i.e. drain this wavefront's LDS-DMA prefetch: once every ~25 blocks instead of on
+  // nearly every block).  An entry is 8 bytes: the score and a CODE (block - b_base) << 11 | element << 6 | lane;
+  // query and document are decoded by the flush, 64 entries per instruction, instead of being selected and
+  // multiplied per survivor in the filing loop, which one wavefront walks serially (round 6: that loop was
+  // 1.2 k of a block's 5.9 k cycles, MM_DOT_PROF).
+  uint2* st = (uint2*)(smem + NBUF * BLK) + w * kStageW;   // [4][kStageW] {score bits, code}
+  // one slot per lane that takes the store of a lane without a survivor (the in-loop filing round below is branch-free)
+  uint2* trash = (uint2*)(smem + NBUF * BLK + 4 * kStageW * 8) + w * 64 + lane;
   // accumulator parking: [element e = 16 n + i][lane] floats = NQT x 4 KiB per wavefront (FILTER epilogue)
-  char* park = smem + NBUF * BLK + 12 * kStageW * 4 + w * (NQT * 4096);
+  char* park = smem + NBUF * BLK + 4 * kStageW * 8 + 4 * 64 * 8 + w * (NQT * 4096);
   int scnt = 0;  // wave-uniform fill level
+  int64_t b_base = b_lo;   // block the staged codes count from (moved by the per-block flush: codes stay below 2^21 blocks)
   auto flush_wave = [&]() {
     for (int i = lane; i < scnt; i += 64) {
-      const int qq = st_q[i];
+      const uint2 ent = st[i];
+      const uint32_t code = ent.y;
+      const int ls = (int)(code & 63u), e = (int)((code >> 6) & 31u);
+      const int qq = q0 + 32 * (e >> 4) + (ls & 31);
+      if (qq >= a.nq) continue;   // (a query past the end has tau = +inf: only an infinite score gets here)
+      const int doc = (int32_t)(((b_base + (int64_t)(code >> 11)) * 32 + 4 * (ls >> 5) + drowof(e & 15)) * a.stride);
       const int slot = atomicAdd(a.count + qq, 1);
       if ((unsigned)slot < (unsigned)a.cap) {
-        a.cand_score[(int64_t)qq * a.cap + slot] = st_score[i];
-        a.cand_idx[(int64_t)qq * a.cap + slot] = st_doc[i];
+        a.cand_score[(int64_t)qq * a.cap + slot] = __uint_as_float(ent.x);
+        a.cand_idx[(int64_t)qq * a.cap + slot] = doc;
       }
     }
     scnt = 0;
@@ -245,12 +257,16 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       dot_issue<NSL>(gb, voff, lds0 + (uint32_t)(slot * BLK + (w + 4 * u) * 1024));
     }
   };
+  // the per-lane source offsets of a whole block (every block but a partial last one), for the in-loop issue
+  uint32_t nvo_full[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) nvo_full[u] = (uint32_t)(lrow[u] * rowstep) + lslot[u];
   // A-fragment read offsets inside a slice: chunk (2kk + h) of row r at slot chunk ^ (r & 15)
   uint32_t lo[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
 
-  unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto now = [&]() -> unsigned long long {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -258,6 +274,34 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   };
   int slot_i = 0;  // ring slot of block `b`
   if (b_lo < b_hi) issue(b_lo, 0);
+  // FILTER, software-pipelined over the blocks: block b's accumulators are tested and parked after its K loop (pmask_prev: bit
+  // e = 16 n + i set <=> element e passed); the FIRST filing round of those survivors (every lane stages its lowest pending
+  // element: all there is for 85 % of the blocks) runs as ~20 branch-free instructions in the shadow of block b + 1's MFMAs;
+  // what is left after that round is filed by the loop behind the K loop.  (The whole filing used to run between the K loops:
+  // a serial chain of ~300 cycles per round in a kernel with one wavefront per SIMD, plus the barrier wait its uneven round
+  // counts caused: 1.2 k of a block's 5.9 k cycles, by removal, MM_DOT_CUT.)
+  uint32_t pmask_prev = 0;
+  // every pending element of the parked block, round after round (wave-uniform flush when a round would not fit)
+  auto file_rounds = [&](uint32_t& pm, uint32_t c0) {
+    while (true) {
+      const bool pend = pm != 0;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(pend);
+      if (bal == 0) break;
+      const int cnt = __builtin_popcountll(bal);
+      if (scnt + cnt > kStageW) flush_wave();
+#ifdef MM_DOT_PROF_ROUNDS   // (counting build: "wait_vm" becomes leftover rounds per block x 1000, "barrier" their entries x 1000)
+      if (PROF) { tp[0] += 1000; tp[1] += 1000 * cnt; }
+#endif
+      if (pend) {
+        const int e = (int)__builtin_ctz(pm);
+        const float val = *(const float*)(park + (e * 64 + lane) * 4);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, (uint32_t)scnt));
+        st[pos] = uint2{__float_as_uint(val), c0 | ((uint32_t)e << 6)};
+      }
+      scnt += cnt;
+      pm &= pm - 1;
+    }
+  };
 
   for (int64_t b = b_lo; b < b_hi; ++b) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -270,16 +314,18 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     const bool more = b + 1 < b_hi;
     const bool spread = more && a.spread;
     const char* gbn = (const char*)a.c;
-    uint32_t nvo[2] = {0, 0};
+    uint32_t nvo[2] = {nvo_full[0], nvo_full[1]};
     const uint32_t ndst = lds0 + (uint32_t)((slot_i ^ 1) * BLK + w * 1024);
     if (spread) {
       const int64_t left = a.ndocs - (b + 1) * 32;
       gbn = (const char*)a.c + (b + 1) * 32 * rowstep;
+      if (left < 32) {   // the shard's last block only: rows past the end are redirected (64-bit multiplies: ~300 cycles)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        int row = lrow[u];
-        if (left < 32 && row >= left) row = (int)left - 1;
-        nvo[u] = (uint32_t)(row * rowstep) + lslot[u];
+        for (int u = 0; u < 2; ++u) {
+          int row = lrow[u];
+          if (row >= left) row = (int)left - 1;
+          nvo[u] = (uint32_t)(row * rowstep) + lslot[u];
+        }
       }
     } else if (more) {
       issue(b + 1, slot_i ^ 1);
@@ -294,6 +340,15 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     // nothing else hides the ~100-cycle LDS latency); the group barriers pin the order
     // {1 LDS read, NQT MFMAs} so the compiler does not fold the reads back next to their uses
     constexpr int STEPS = NSL * 8, AHEAD = 3;
+    // in-loop filing rounds: round rd reads its parked values at K step kFileStep + 8 rd and stores four steps later
+    constexpr int kFileStep = 1, kFileRounds = STEPS >= 16 ? 2 : 1;
+    static_assert(kFileStep + 8 * (kFileRounds - 1) + 4 < STEPS, "the in-loop filing rounds do not fit the K loop");
+    bool f_pend = false;
+    unsigned long long f_bal = 0;
+    uint32_t f_e = 0;
+    float f_val = 0.0f;
+    // the code of block b - 1's entries: blocks since b_base, lane (b_base only moves in the flush below, behind the rounds)
+    const uint32_t code_prev = ((uint32_t)(b - 1 - b_base) << 11) | (uint32_t)lane;
     short8 av[AHEAD + 1];
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) av[s] = *(const short8*)(buf + (s >> 3) * 8192 + lo[s & 7]);
@@ -309,6 +364,30 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
         const int u = (s >> 1) / NSL, sl = (s >> 1) % NSL;
         if (spread) dot_issue_one(gbn, nvo[u] + (uint32_t)(sl * 256), ndst + (uint32_t)(u * 4096 + sl * 0x2000));
       }
+      if constexpr (MODE == DOT_FILTER) {
+        // filing rounds of block b - 1 (pmask_prev = 0 before the first block: every lane stores to its trash slot).
+        // No branch: a lane without a pending element reads element 31's slot and stores to its trash slot.
+#pragma unroll
+        for (int rd = 0; rd < kFileRounds; ++rd) {
+          if (s == kFileStep + 8 * rd) {
+            f_pend = pmask_prev != 0;
+            f_bal = __builtin_amdgcn_ballot_w64(f_pend);
+            f_e = (uint32_t)__builtin_ctz(pmask_prev | 0x80000000u);     // 31 for an empty mask
+            f_val = *(const float*)(park + (f_e * 64 + lane) * 4);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // (the parked value's read)
+          }
+          if (s == kFileStep + 8 * rd + 4) {
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(f_bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)f_bal, (uint32_t)scnt));
+            uint2* dst = f_pend ? st + pos : trash;
+            *dst = uint2{__float_as_uint(f_val), code_prev | (f_e << 6)};
+            scnt += __builtin_popcountll(f_bal);
+            pmask_prev &= pmask_prev - 1;
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+      }
     }
     slot_i ^= 1;
     if (PROF) {
@@ -318,7 +397,10 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       for (int n = 0; n < NQT; ++n) sink += acc[n][0];
       asm volatile("" ::"v"(sink));
       t4 = now();
-      tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += t3 - t2; tp[3] += t4 - t3;
+#ifndef MM_DOT_PROF_ROUNDS
+      tp[0] += t1 - t0; tp[1] += t2 - t1;
+#endif
+      tp[2] += t3 - t2; tp[3] += t4 - t3;
     }
 
     // ---- epilogue: acc[n][i] = <document b*32 + drowof(i) + 4h, query qid[n]> ----------------------
@@ -343,57 +425,76 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       // the working threshold) are filed by a loop in which every lane takes its lowest pending element per round — one
       // round for 85 % of the blocks.  (One flush opportunity per block; a full private area falls back to the direct
       // global append: exact, only slow.)
-      if (scnt > kStageW / 2) flush_wave();
-      const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
-      uint32_t pmask = 0;
-#pragma unroll
-      for (int e = 16 * NQT - 1; e >= 0; --e) {   // highest element first: its bit is shifted up by the ones after it
-        const float v = acc[e >> 4][e & 15];
-        *(float*)(park + (e * 64 + lane) * 4) = v;
-        // pmask = 2 pmask + (v >= tau): the compare's lane bit enters as the carry — two instructions per element
-        asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pmask) : "v"(v), "v"(tau[e >> 4]) : "vcc");
+      // what the in-loop round left of block b - 1 (a lane with two survivors: 15 % of the blocks)
+#if !defined(MM_DOT_CUT) || MM_DOT_CUT != 4
+      file_rounds(pmask_prev, code_prev);
+#endif
+      // The flush: on a schedule the four wavefronts of the workgroup share (every a.flush_every blocks, ~96 staged entries each at
+      // the expected survivor rate), so that they pay its two returning-atomic round trips (~2.3 k cycles) in the SAME block —
+      // flushing whenever the own area was half full put one of the four into a flush in every fifth block and the other three
+      // at the barrier (440 cycles per block).  The fill-level test stays as the guard: the in-loop rounds need room for 128.
+#if defined(MM_DOT_CUT) && MM_DOT_CUT == 5
+      if (scnt > kStageW / 2) {
+#else
+      if (b - b_base >= a.flush_every || scnt > kStageW / 2) {
+#endif
+        unsigned long long tf = 0;
+        if (PROF) tf = now();
+        flush_wave();
+        b_base = b;
+        if (PROF) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          tp[6] += now() - tf;
+        }
       }
+      unsigned long long tq = 0;
+      if (PROF) tq = now();
+      const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
+      // pm[n] = 2 pm[n] + (v >= tau): the compare's lane mask enters a per-lane 16-bit mask as the carry — two instructions per
+      // element; one chain per query tile, each with its own scalar pair for the carry (through VCC the tiles' chains
+      // serialised on the one register)
+      uint32_t pm[NQT];
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) pm[n] = 0;
+#pragma unroll
+      for (int i = 15; i >= 0; --i) {   // highest element first: its bit is shifted up by the ones after it
+#pragma unroll
+        for (int n = 0; n < NQT; ++n) *(float*)(park + ((16 * n + i) * 64 + lane) * 4) = acc[n][i];
+        if constexpr (NQT == 2) {
+          unsigned long long cy0, cy1;   // both compares first: the add of one tile does not wait behind its own compare
+          asm("v_cmp_ge_f32_e64 %2, %4, %5\n\tv_cmp_ge_f32_e64 %3, %6, %7\n\t"
+              "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\tv_addc_co_u32_e64 %1, %3, %1, %1, %3"
+              : "+v"(pm[0]), "+v"(pm[1]), "=&s"(cy0), "=&s"(cy1)
+              : "v"(acc[0][i]), "v"(tau[0]), "v"(acc[1][i]), "v"(tau[1]));
+        } else {
+          unsigned long long cy;
+          asm("v_cmp_ge_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(pm[0]), "=&s"(cy) : "v"(acc[0][i]), "v"(tau[0]));
+        }
+      }
+      uint32_t pmask = pm[0];
+      if constexpr (NQT == 2) pmask |= pm[1] << 16;
       if (!whole) {   // wave-uniform, the shard's last block only: documents past the end do not exist
         uint32_t exist = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) exist |= (d0 + drowof(i) < a.ndocs) ? (0x00010001u << i) : 0u;
         pmask &= exist;
       }
-      while (true) {
-        const bool pend = pmask != 0;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pend);
-        if (bal == 0) break;
-        const int e = pend ? (int)__builtin_ctz(pmask) : 0;
-        const float val = *(const float*)(park + (e * 64 + lane) * 4);
-        int qsel = qid[0];
-#pragma unroll
-        for (int n = 1; n < NQT; ++n) qsel = (e >> 4) == n ? qid[n] : qsel;
-        if (pend) {
-          const int pos = scnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          const int doc = (int32_t)((d0 + drowof(e & 15)) * a.stride);
-          if (pos < kStageW) {
-            st_score[pos] = val;
-            st_doc[pos] = doc;
-            st_q[pos] = qsel;
-          } else {
-            const int slot = atomicAdd(a.count + qsel, 1);
-            if ((unsigned)slot < (unsigned)a.cap) {
-              a.cand_score[(int64_t)qsel * a.cap + slot] = val;
-              a.cand_idx[(int64_t)qsel * a.cap + slot] = doc;
-            }
-          }
-        }
-        const int np = scnt + __builtin_popcountll(bal);
-        scnt = np < kStageW ? np : kStageW;
-        pmask &= pmask - 1;
-      }
+#if defined(MM_DOT_CUT) && MM_DOT_CUT == 1   // by-removal timing builds (tools/build_variant.sh; results are wrong)
+      pmask = 0;
+#endif
+      pmask_prev = pmask;
+      if (PROF) tp[7] += now() - tq;   // park + test (now() waits for the LDS stores)
     }
     if (PROF) tp[4] += now() - t4;
   }
-  if (MODE == DOT_FILTER) flush_wave();
+  if (MODE == DOT_FILTER) {   // the last block has no K loop behind it
+    file_rounds(pmask_prev, ((uint32_t)(b_hi - 1 - b_base) << 11) | (uint32_t)lane);
+    flush_wave();
+  }
   if (PROF && lane == 0) {
-    unsigned long long* o = a.prof + ((int64_t)blockIdx.x * 4 + w) * 6;
+    unsigned long long* o = a.prof + ((int64_t)blockIdx.x * 4 + w) * 8;
     o[0] = tp[0]; o[1] = tp[1]; o[2] = tp[2]; o[3] = tp[3]; o[4] = tp[4]; o[5] = (unsigned long long)(b_hi - b_lo);
+    o[6] = tp[6]; o[7] = tp[7];
   }
 }
 
@@ -733,12 +834,17 @@ template <int DT, int NSL, int NQT, int MODE>
 static int launch_dot(const DotArgs& a0, int nq_launch, int T, hipStream_t stream) {
   DotArgs a = a0;
   constexpr int QPW = 128 * NQT;  // queries per workgroup
-  const int lds = 2 * 32 * NSL * 256 + 4 * kStageW * 12 + 4 * NQT * 4096;
+  const int lds = 2 * 32 * NSL * 256 + 4 * kStageW * 8 + 4 * 64 * 8 + 4 * NQT * 4096;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dot_stream_kernel<DT, NSL, NQT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (31.0 * (double)a.stride * (NSL * 256) >= 4294967296.0)
     return set_error(MM_EUNSUPPORTED, "dot_topk: sample stride too large for 32-bit row offsets");
   a.T = T;
+  {  // ~96 staged entries per wavefront between two common flushes (32 NQT queries x 32 documents per wavefront-block)
+    const double rate = a.expect * 32.0 * (32 * NQT);
+    const double n = rate > 0.0 ? 96.0 / rate : (double)kStageRel;
+    a.flush_every = n < 1.0 ? 1 : (n > (double)kStageRel ? (int)kStageRel : (int)n);
+  }
   for (int qb = 0; qb < nq_launch; qb += 32 * QPW) {  // at most 32 query groups (one per CU of an XCD) per launch
     const int nq_here = nq_launch - qb < 32 * QPW ? nq_launch - qb : 32 * QPW;
     a.G = (nq_here + QPW - 1) / QPW;
@@ -841,11 +947,12 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   // phase 2: full product + threshold filter
   if (hipMemsetAsync(count, 0, (size_t)nq * 4, stream) != hipSuccess) return set_error(MM_ELAUNCH, "dot_topk: memset failed");
   a.ndocs = n_docs; a.stride = 1;
+  a.expect = small ? 1.0 : 2.5 * k * m_scale / (double)n_docs;
   if (env().dot_prof) {  // MM_DOT_PROF=1: per-wavefront phase cycle counters (single-GPU profiling runs only:
                          // the buffer lives on the device that was current at the first call)
     static unsigned long long* const prof_buf = [] {
       void* p = nullptr;
-      if (hipMalloc(&p, 8 * 32 * 32 * 4 * 6 * 8) != hipSuccess) p = nullptr;
+      if (hipMalloc(&p, 8 * 32 * 32 * 4 * 8 * 8) != hipSuccess) p = nullptr;
       return (unsigned long long*)p;
     }();
     a.prof = prof_buf;
@@ -862,20 +969,21 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
                      n_docs, out_scores, out_idx, status);
   if (int e = check_launch("topk_rows_kernel")) return e;
   if (a.prof) {  // tools only: synchronous dump of the phase counters
-    static unsigned long long host[8 * 32 * 32 * 4 * 6];
+    static unsigned long long host[8 * 32 * 32 * 4 * 8];
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(host, a.prof, sizeof(host), hipMemcpyDeviceToHost);
     const int nw = 8 * 32 * 4;  // first launch's workgroups x 4 wavefronts at most
-    double sum[6] = {0, 0, 0, 0, 0, 0};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cntw = 0;
     for (int i = 0; i < nw; ++i) {
-      if (host[i * 6 + 5] == 0) continue;
-      for (int j = 0; j < 5; ++j) sum[j] += (double)host[i * 6 + j] / (double)host[i * 6 + 5];
+      if (host[i * 8 + 5] == 0) continue;
+      for (int j = 0; j < 8; ++j)
+        if (j != 5) sum[j] += (double)host[i * 8 + j] / (double)host[i * 8 + 5];
       ++cntw;
     }
     if (cntw)
-      fprintf(stderr, "[MM_DOT_PROF] cycles per block (avg over %d wavefronts): wait_vm %.0f | barrier %.0f | flush+issue %.0f | mfma loop %.0f | epilogue %.0f\n",
-              cntw, sum[0] / cntw, sum[1] / cntw, sum[2] / cntw, sum[3] / cntw, sum[4] / cntw);
+      fprintf(stderr, "[MM_DOT_PROF] cycles per block (avg over %d wavefronts): wait_vm %.0f | barrier %.0f | flush+issue %.0f | mfma loop %.0f | epilogue %.0f (of which: staging flush %.0f, park + test %.0f)\n",
+              cntw, sum[0] / cntw, sum[1] / cntw, sum[2] / cntw, sum[3] / cntw, sum[4] / cntw, sum[6] / cntw, sum[7] / cntw);
   }
   return MM_OK;
 }
