@@ -36,7 +36,6 @@ const EnvCfg& env() {
     c.kp_generic = env_int("MM_KP_GENERIC", 0);
     c.kp_f32mfma = env_int("MM_KP_F32MFMA", 0);
     c.dot_prof = env_int("MM_DOT_PROF", 0);
-    c.dot_no_spread = env_int("MM_DOT_NO_SPREAD", 0);
     c.tkl_pairsums = env_int("MM_TKL_PAIRSUMS", 0);
     c.tkl_fold_regions = env_int("MM_TKL_FOLD_REGIONS", 0);
     c.tkl_bwd_nosplit = env_int("MM_TKL_BWD_NOSPLIT", 0);

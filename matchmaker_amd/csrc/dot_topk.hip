@@ -62,7 +62,6 @@ struct DotArgs {
   float* cand_score;  // [nq, cap]
   int32_t* cand_idx;  // [nq, cap] document index inside the shard
   int cap;
-  int spread;         // LDS-DMA of block b + 1 spread over block b's K loop (default; MM_DOT_NO_SPREAD=1: all at once)
   int flush_every;    // FILTER: blocks between the workgroup's common staging flushes (launch_dot: from `expect`)
   double expect;      // FILTER: expected fraction of a query's scores above its threshold
   unsigned long long* prof;  // optional [grid * 4 wavefronts][8] cycle counters (MM_DOT_PROF=1, tools only)
@@ -310,15 +309,16 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     if (PROF) t1 = now();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
     if (PROF) t2 = now();
-    // block b + 1 goes into the slot block b - 1 used: all at once here, or (a.spread) one instruction every second K step
+    // Block b + 1 goes into the slot block b - 1 used, one LDS-DMA instruction every second K step (dot_issue_one).  The last
+    // block of the range requests ITS OWN rows again (valid addresses, an idle slot, one block of ~540): the K loop carries no
+    // branch, so it is one scheduling region.  (Until round 6 a run-time switch, MM_DOT_NO_SPREAD, kept the burst form for A/B.)
     const bool more = b + 1 < b_hi;
-    const bool spread = more && a.spread;
-    const char* gbn = (const char*)a.c;
+    const int64_t bn = more ? b + 1 : b;
+    const char* gbn = (const char*)a.c + bn * 32 * rowstep;
     uint32_t nvo[2] = {nvo_full[0], nvo_full[1]};
     const uint32_t ndst = lds0 + (uint32_t)((slot_i ^ 1) * BLK + w * 1024);
-    if (spread) {
-      const int64_t left = a.ndocs - (b + 1) * 32;
-      gbn = (const char*)a.c + (b + 1) * 32 * rowstep;
+    {
+      const int64_t left = a.ndocs - bn * 32;
       if (left < 32) {   // the shard's last block only: rows past the end are redirected (64-bit multiplies: ~300 cycles)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -327,8 +327,6 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
           nvo[u] = (uint32_t)(row * rowstep) + lslot[u];
         }
       }
-    } else if (more) {
-      issue(b + 1, slot_i ^ 1);
     }
 
     if (PROF) t3 = now();
@@ -362,7 +360,10 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
       if ((s & 1) == 0 && (s >> 1) < 2 * NSL) {
         const int u = (s >> 1) / NSL, sl = (s >> 1) % NSL;
-        if (spread) dot_issue_one(gbn, nvo[u] + (uint32_t)(sl * 256), ndst + (uint32_t)(u * 4096 + sl * 0x2000));
+        // (fenced: without the two barriers the scheduler gathers the twelve requests at the head of the loop)
+        __builtin_amdgcn_sched_barrier(0);
+        dot_issue_one(gbn, nvo[u] + (uint32_t)(sl * 256), ndst + (uint32_t)(u * 4096 + sl * 0x2000));
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (MODE == DOT_FILTER) {
         // filing rounds of block b - 1 (pmask_prev = 0 before the first block: every lane stores to its trash slot).
@@ -487,6 +488,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     }
     if (PROF) tp[4] += now() - t4;
   }
+  dot_wait<0>();   // the last block's redundant request has landed before the workgroup's LDS can go to another one
   if (MODE == DOT_FILTER) {   // the last block has no K loop behind it
     file_rounds(pmask_prev, ((uint32_t)(b_hi - 1 - b_base) << 11) | (uint32_t)lane);
     flush_wave();
@@ -923,7 +925,6 @@ extern "C" int mm_dot_topk_fwd(const void* queries, const void* corpus, int64_t 
   int32_t* cand_idx = (int32_t*)ws;
 
   DotArgs a{};
-  a.spread = env().dot_no_spread ? 0 : 1;
   a.q = queries; a.c = corpus; a.nq = nq; a.E = E; a.q_base = 0;
   a.tau = tau; a.count = count; a.cand_score = cand_score; a.cand_idx = cand_idx; a.cap = cap;
 

@@ -35,7 +35,6 @@ struct EnvCfg {
   int maxsim_f32_terms = 3; // MM_MAXSIM_F32_TERMS: 2 = two-term split for fp32 MaxSim (A/B), default three terms
   int kp_generic = 0;       // MM_KP_GENERIC: force the generic pooling kernel
   int kp_f32mfma = 0;       // MM_KP_F32MFMA: exact-f32 MFMA pooling kernel instead of split-bf16
-  int dot_no_spread = 0;    // MM_DOT_NO_SPREAD: dot top-k filter issues a block's LDS-DMA all at once after the barrier (A/B runs)
   int dot_prof = 0;         // MM_DOT_PROF: in-kernel phase counters of the dot top-k kernel
   int kp_bwd_threads = 1024; // MM_KP_BWD_THREADS: 1024 (when its LDS fits) | 512 threads per pair in kernel_pool_bwd_tiled_kernel (A/B runs)
   int tkl_stage1_ksplit = 0;  // MM_TKL_STAGE1_KSPLIT=1: TKL stage 1 on the two-wavefront K-split kernel (tkl_stage1_ksplit.hip) instead of the row-streaming one (A/B runs)
