@@ -161,6 +161,9 @@ __device__ __forceinline__ void dot_wait() {
   else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifndef MM_DOT_AHEAD
+#define MM_DOT_AHEAD 4   // A fragments in flight ahead of the MFMAs that use them (A/B builds: -DMM_DOT_AHEAD=n)
+#endif
 template <int DT, int NSL, int NQT, int MODE, bool PROF = false>
 __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   // Ring of TWO blocks (measured: 15.20 ms against 15.33 ms with three — block b + 1 has the whole of block b's MFMA
@@ -234,6 +237,10 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   float tau[NQT];
 #pragma unroll
   for (int n = 0; n < NQT; ++n) tau[n] = (MODE == DOT_FILTER && qid[n] >= 0) ? a.tau[qid[n]] : __builtin_huge_valf();
+  // The thresholds are in their registers HERE: left to the first use — the in-loop test of the DEEP form — the compiler's wait
+  // for this load is an s_waitcnt vmcnt(0) inside the K loop, behind the first LDS-DMA request of every block.
+#pragma unroll
+  for (int n = 0; n < NQT; ++n) asm volatile("" : "+v"(tau[n]));
 
   // ---- LDS-DMA: this wavefront moves rows 4k..4k+3 (k = w, w + 4) of every slice of a block --------
   const int64_t rowstep = a.stride * RB;  // bytes between consecutive visited documents
@@ -260,10 +267,16 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
   uint32_t nvo_full[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) nvo_full[u] = (uint32_t)(lrow[u] * rowstep) + lslot[u];
-  // A-fragment read offsets inside a slice: chunk (2kk + h) of row r at slot chunk ^ (r & 15)
-  uint32_t lo[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) lo[kk] = (uint32_t)(r * 256 + ((((2 * kk) | h) ^ (r & 15)) << 4));
+  // A-fragment read offsets inside a slice: chunk (2kk + h) of row r at slot chunk ^ (r & 15) — = lo0 ^ (32 kk): the XOR with
+  // 2 kk only reaches bits 5..7 of the byte offset.  One register and one v_xor per read (in the shadow of the MFMAs) instead
+  // of eight offsets + eight per-block addresses held through the K loop: the DEEP form needs those registers for its second
+  // accumulator set.  (lds0 and the slot bases are multiples of 256: the XOR commutes with adding them.)
+  const uint32_t lo0 = (uint32_t)(r * 256 + ((h ^ (r & 15)) << 4));
+  auto a_frag = [&](uint32_t base, int s) -> short8 {
+    asm("" : "+v"(base));   // a fresh value per read: keeps the compiler from holding the eight XORs in registers
+    const uint32_t off = base ^ (uint32_t)(32 * (s & 7));
+    return *(const short8*)((const __attribute__((address_space(3))) char*)(uintptr_t)off + (s >> 3) * 8192);
+  };
 
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto now = [&]() -> unsigned long long {
@@ -302,10 +315,65 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     }
   };
 
-  for (int64_t b = b_lo; b < b_hi; ++b) {
+  // DEEP (FILTER, 64 queries per wavefront, >= 40 K steps: the dim-640 / 768 instantiations): TWO accumulator sets.  Block b
+  // accumulates into one while the other — block b - 1's finished scores — is tested, parked and filed in the shadow of block
+  // b's MFMAs: one element pair per K step for the test (4 VALU + one 8-byte-per-lane LDS store), then the two filing rounds.
+  // Nothing of the threshold test is left between the K loops (it was ~0.75 k of a block's 5.3 k cycles, a serial stretch
+  // that one wavefront per SIMD cannot hide); the last block of the range is tested behind the loop (tail).  The other
+  // instantiations keep one set and test behind each K loop.
+  // (The MM_DOT_PROF instantiation keeps the one-set form: with the stamps' registers the two-set form spills.)
+  constexpr bool DEEP = MODE == DOT_FILTER && NQT == 2 && NSL >= 5 && !PROF;
+  constexpr int STEPS = NSL * 8, AHEAD = MM_DOT_AHEAD;
+  // in-loop filing rounds: round rd reads its parked values at K step kFileStep + 8 rd and stores four steps later
+  constexpr int kFileStep = DEEP ? 17 : 1, kFileRounds = STEPS >= 16 ? 2 : 1;
+  static_assert(kFileStep + 8 * (kFileRounds - 1) + 4 < STEPS, "the in-loop filing rounds do not fit the K loop");
+
+  // test + park of a finished accumulator set behind a K loop (every block of the other instantiations; DEEP: the tail)
+  auto test_park = [&](const f32x16 (&acc)[NQT], int64_t b) -> uint32_t {
+    const int64_t d0 = b * 32 + 4 * h;
+    const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
+    // pm[n] = 2 pm[n] + (v >= tau): the compare's lane mask enters a per-lane 16-bit mask as the carry — two instructions per
+    // element; one chain per query tile, each with its own scalar pair for the carry (through VCC the tiles' chains
+    // serialised on the one register)
+    uint32_t pm[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) pm[n] = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {   // highest element first: its bit is shifted up by the ones after it
+#pragma unroll
+      for (int n = 0; n < NQT; ++n) *(float*)(park + ((16 * n + i) * 64 + lane) * 4) = acc[n][i];
+      if constexpr (NQT == 2) {
+        unsigned long long cy0, cy1;   // both compares first: the add of one tile does not wait behind its own compare
+        asm("v_cmp_ge_f32_e64 %2, %4, %5\n\tv_cmp_ge_f32_e64 %3, %6, %7\n\t"
+            "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\tv_addc_co_u32_e64 %1, %3, %1, %1, %3"
+            : "+v"(pm[0]), "+v"(pm[1]), "=&s"(cy0), "=&s"(cy1)
+            : "v"(acc[0][i]), "v"(tau[0]), "v"(acc[1][i]), "v"(tau[1]));
+      } else {
+        unsigned long long cy;
+        asm("v_cmp_ge_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(pm[0]), "=&s"(cy) : "v"(acc[0][i]), "v"(tau[0]));
+      }
+    }
+    uint32_t pmask = pm[0];
+    if constexpr (NQT == 2) pmask |= pm[1] << 16;
+    if (!whole) {   // wave-uniform, the shard's last block only: documents past the end do not exist
+      uint32_t exist = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) exist |= (d0 + drowof(i) < a.ndocs) ? (0x00010001u << i) : 0u;
+      pmask &= exist;
+    }
+#if defined(MM_DOT_CUT) && MM_DOT_CUT == 1   // by-removal timing builds (tools/build_variant.sh; results are wrong)
+    pmask = 0;
+#endif
+    return pmask;
+  };
+
+  // one block: acc = this block's accumulators; prv (DEEP) = block b - 1's, complete
+  auto run_block = [&](const int64_t b, f32x16 (&acc)[NQT], f32x16 (&prv)[NQT]) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if (PROF) t0 = now();
-    dot_wait<0>();  // this wavefront's part of block b has landed
+    // This wavefront's part of block b has landed: FILTER waited for it behind the previous K loop, in front of the flush — a
+    // wait here would also wait for that flush's stores to be acknowledged (~1 k cycles in every flush block).
+    if (MODE != DOT_FILTER || b == b_lo) dot_wait<0>();
     if (PROF) t1 = now();
     __syncthreads();  // every part of block b landed; every wavefront is done with block b - 1
     if (PROF) t2 = now();
@@ -330,40 +398,68 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     }
 
     if (PROF) t3 = now();
-    f32x16 acc[NQT];
 #pragma unroll
     for (int n = 0; n < NQT; ++n) acc[n] = f32x16{0};
-    const char* buf = smem + slot_i * BLK;
+    const uint32_t abase = lds0 + (uint32_t)(slot_i * BLK) + lo0;
     // A fragments are fetched AHEAD steps ahead of the MFMAs that use them (one wavefront per SIMD:
     // nothing else hides the ~100-cycle LDS latency); the group barriers pin the order
     // {1 LDS read, NQT MFMAs} so the compiler does not fold the reads back next to their uses
-    constexpr int STEPS = NSL * 8, AHEAD = 3;
-    // in-loop filing rounds: round rd reads its parked values at K step kFileStep + 8 rd and stores four steps later
-    constexpr int kFileStep = 1, kFileRounds = STEPS >= 16 ? 2 : 1;
-    static_assert(kFileStep + 8 * (kFileRounds - 1) + 4 < STEPS, "the in-loop filing rounds do not fit the K loop");
     bool f_pend = false;
     unsigned long long f_bal = 0;
     uint32_t f_e = 0;
     float f_val = 0.0f;
+    uint32_t dpm[2] = {0, 0};   // DEEP: the per-tile pass masks of block b - 1 as they are built
     // the code of block b - 1's entries: blocks since b_base, lane (b_base only moves in the flush below, behind the rounds)
     const uint32_t code_prev = ((uint32_t)(b - 1 - b_base) << 11) | (uint32_t)lane;
     short8 av[AHEAD + 1];
 #pragma unroll
-    for (int s = 0; s < AHEAD; ++s) av[s] = *(const short8*)(buf + (s >> 3) * 8192 + lo[s & 7]);
+    for (int s = 0; s < AHEAD; ++s) av[s] = a_frag(abase, s);
     __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);  // the first AHEAD reads go out together
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if (s + AHEAD < STEPS) av[(s + AHEAD) % (AHEAD + 1)] = *(const short8*)(buf + ((s + AHEAD) >> 3) * 8192 + lo[(s + AHEAD) & 7]);
+      if (s + AHEAD < STEPS) av[(s + AHEAD) % (AHEAD + 1)] = a_frag(abase, s + AHEAD);
 #pragma unroll
+#if defined(MM_DOT_CUT) && MM_DOT_CUT == 7   // no matrix work: every fourth step keeps the operands alive
+      for (int n = 0; n < NQT; ++n) if ((s & 3) == 0) acc[n] = DotMfma<DT>::run(av[s % (AHEAD + 1)], qf[n][s >> 3][s & 7], acc[n]); else asm volatile("" :: "v"(av[s % (AHEAD + 1)]), "v"(qf[n][s >> 3][s & 7]));
+#else
       for (int n = 0; n < NQT; ++n) acc[n] = DotMfma<DT>::run(av[s % (AHEAD + 1)], qf[n][s >> 3][s & 7], acc[n]);
+#endif
       __builtin_amdgcn_sched_group_barrier(0x008, NQT, 0);  // NQT MFMAs of step s
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // then the read for step s + AHEAD
       if ((s & 1) == 0 && (s >> 1) < 2 * NSL) {
         const int u = (s >> 1) / NSL, sl = (s >> 1) % NSL;
         // (fenced: without the two barriers the scheduler gathers the twelve requests at the head of the loop)
         __builtin_amdgcn_sched_barrier(0);
+#if !defined(MM_DOT_CUT) || MM_DOT_CUT != 8
         dot_issue_one(gbn, nvo[u] + (uint32_t)(sl * 256), ndst + (uint32_t)(u * 4096 + sl * 0x2000));
+#endif
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (DEEP) {
+        // test + park of block b - 1, element pair i = 15 - s (highest first: its bit is shifted up by the ones after it)
+#if !defined(MM_DOT_CUT) || MM_DOT_CUT != 6
+        if (s < 16) {
+          const int i = 15 - s;
+          // [e = 16 n + i][lane]: the two tiles' slots are 16 x 256 B apart — one ds_write2st64_b32.  (Tried: the store and the
+          // compare fed straight from the accumulator registers through "a" operands, so that the finished set need not be
+          // copied out behind the K loop — the allocator answered with 600 v_accvgpr moves and scratch.)
+          *(float*)(park + (i * 64 + lane) * 4) = prv[0][i];
+          *(float*)(park + ((16 + i) * 64 + lane) * 4) = prv[1][i];
+          unsigned long long cy0, cy1;
+          asm("v_cmp_ge_f32_e64 %2, %4, %5\n\tv_cmp_ge_f32_e64 %3, %6, %7\n\t"
+              "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\tv_addc_co_u32_e64 %1, %3, %1, %1, %3"
+              : "+v"(dpm[0]), "+v"(dpm[1]), "=&s"(cy0), "=&s"(cy1)
+              : "v"(prv[0][i]), "v"(tau[0]), "v"(prv[1][i]), "v"(tau[1]));
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#endif
+        if (s == 16) {
+          pmask_prev = dpm[0] | (dpm[1] << 16);
+          if (b == b_lo) pmask_prev = 0;   // (no block behind the first one: the other set holds zeros)
+#if defined(MM_DOT_CUT) && MM_DOT_CUT == 1
+          pmask_prev = 0;
+#endif
+        }
       }
       if constexpr (MODE == DOT_FILTER) {
         // filing rounds of block b - 1 (pmask_prev = 0 before the first block: every lane stores to its trash slot).
@@ -423,10 +519,9 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     } else {
       // Threshold test without a scalar branch per element: every lane collects the elements that pass in a bit mask
       // (bit e = 16 n + i), the accumulators are parked in LDS ([e][lane]), and the survivors (~5 per wavefront-block at
-      // the working threshold) are filed by a loop in which every lane takes its lowest pending element per round — one
-      // round for 85 % of the blocks.  (One flush opportunity per block; a full private area falls back to the direct
-      // global append: exact, only slow.)
-      // what the in-loop round left of block b - 1 (a lane with two survivors: 15 % of the blocks)
+      // the working threshold) are filed from there: every lane takes its lowest pending element per round.
+      dot_wait<0>();   // block b + 1's rows (requested in the first half of the K loop) — and nothing else is in flight here
+      // What the in-loop rounds left of block b - 1 (a lane with three survivors):
 #if !defined(MM_DOT_CUT) || MM_DOT_CUT != 4
       file_rounds(pmask_prev, code_prev);
 #endif
@@ -448,50 +543,41 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
           tp[6] += now() - tf;
         }
       }
-      unsigned long long tq = 0;
-      if (PROF) tq = now();
-      const bool whole = b * 32 + 32 <= a.ndocs;  // only the last block of the shard can be partial
-      // pm[n] = 2 pm[n] + (v >= tau): the compare's lane mask enters a per-lane 16-bit mask as the carry — two instructions per
-      // element; one chain per query tile, each with its own scalar pair for the carry (through VCC the tiles' chains
-      // serialised on the one register)
-      uint32_t pm[NQT];
-#pragma unroll
-      for (int n = 0; n < NQT; ++n) pm[n] = 0;
-#pragma unroll
-      for (int i = 15; i >= 0; --i) {   // highest element first: its bit is shifted up by the ones after it
-#pragma unroll
-        for (int n = 0; n < NQT; ++n) *(float*)(park + ((16 * n + i) * 64 + lane) * 4) = acc[n][i];
-        if constexpr (NQT == 2) {
-          unsigned long long cy0, cy1;   // both compares first: the add of one tile does not wait behind its own compare
-          asm("v_cmp_ge_f32_e64 %2, %4, %5\n\tv_cmp_ge_f32_e64 %3, %6, %7\n\t"
-              "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\tv_addc_co_u32_e64 %1, %3, %1, %1, %3"
-              : "+v"(pm[0]), "+v"(pm[1]), "=&s"(cy0), "=&s"(cy1)
-              : "v"(acc[0][i]), "v"(tau[0]), "v"(acc[1][i]), "v"(tau[1]));
-        } else {
-          unsigned long long cy;
-          asm("v_cmp_ge_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(pm[0]), "=&s"(cy) : "v"(acc[0][i]), "v"(tau[0]));
-        }
+      if constexpr (!DEEP) {
+        unsigned long long tq = 0;
+        if (PROF) tq = now();
+        pmask_prev = test_park(acc, b);
+        if (PROF) tp[7] += now() - tq;   // park + test (now() waits for the LDS stores)
       }
-      uint32_t pmask = pm[0];
-      if constexpr (NQT == 2) pmask |= pm[1] << 16;
-      if (!whole) {   // wave-uniform, the shard's last block only: documents past the end do not exist
-        uint32_t exist = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) exist |= (d0 + drowof(i) < a.ndocs) ? (0x00010001u << i) : 0u;
-        pmask &= exist;
-      }
-#if defined(MM_DOT_CUT) && MM_DOT_CUT == 1   // by-removal timing builds (tools/build_variant.sh; results are wrong)
-      pmask = 0;
-#endif
-      pmask_prev = pmask;
-      if (PROF) tp[7] += now() - tq;   // park + test (now() waits for the LDS stores)
     }
     if (PROF) tp[4] += now() - t4;
-  }
-  dot_wait<0>();   // the last block's redundant request has landed before the workgroup's LDS can go to another one
-  if (MODE == DOT_FILTER) {   // the last block has no K loop behind it
-    file_rounds(pmask_prev, ((uint32_t)(b_hi - 1 - b_base) << 11) | (uint32_t)lane);
+  };
+
+  f32x16 accA[NQT];
+  if constexpr (DEEP) {
+    f32x16 accB[NQT];
+#pragma unroll
+    for (int n = 0; n < NQT; ++n) accB[n] = f32x16{0};
+    int64_t b = b_lo;
+    bool last_in_a;
+    while (true) {
+      run_block(b, accA, accB);
+      if (++b == b_hi) { last_in_a = true; break; }
+      run_block(b, accB, accA);
+      if (++b == b_hi) { last_in_a = false; break; }
+    }
+    dot_wait<0>();   // the last block's redundant request has landed before the workgroup's LDS can go to another one
+    // tail: the last block of the range has no K loop behind it
+    uint32_t pm = last_in_a ? test_park(accA, b_hi - 1) : test_park(accB, b_hi - 1);
+    file_rounds(pm, ((uint32_t)(b_hi - 1 - b_base) << 11) | (uint32_t)lane);
     flush_wave();
+  } else {
+    for (int64_t b = b_lo; b < b_hi; ++b) run_block(b, accA, accA);
+    dot_wait<0>();   // the last block's redundant request has landed before the workgroup's LDS can go to another one
+    if (MODE == DOT_FILTER) {   // the last block has no K loop behind it
+      file_rounds(pmask_prev, ((uint32_t)(b_hi - 1 - b_base) << 11) | (uint32_t)lane);
+      flush_wave();
+    }
   }
   if (PROF && lane == 0) {
     unsigned long long* o = a.prof + ((int64_t)blockIdx.x * 4 + w) * 8;
