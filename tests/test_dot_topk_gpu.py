@@ -57,6 +57,24 @@ def test_dot_topk_matches_flat_index_semantics(dtype, nq, N, E, k):
     assert idx[0, 0].item() == 0 and idx[0, 1].item() == 1
 
 
+@pytest.mark.parametrize("nq,N,k", [(200, 3000, 1000),    # no sampling (N <= 4096): every score passes, partial last block
+                                    (150, 5000, 1000),    # sampled threshold near 0: half of all scores pass (on-demand flushes)
+                                    (200, 40, 10), (200, 31, 5),   # two blocks / one partial block per range
+                                    (260, 70001, 100)])   # two query groups, partial last block, sub-slices
+def test_dot_topk_two_tile_dim768_form_edges(nq, N, k):
+    """The dim-768 / > 128-query instantiation tests block b - 1 inside block b's K loop (two accumulator sets: csrc/dot_topk.hip
+    DEEP): first block of a range (the other set holds zeros — which pass a threshold <= 0), last block tested behind the
+    loop, survivor rates far above the staging area's schedule."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(nq + N)
+    E = 768
+    c = torch.randn(N, E, generator=g).half()
+    q = torch.randn(nq, E, generator=g).half()
+    s, idx = ops.dot_topk(q.to(dev), c.to(dev), k)
+    _check(q.float().numpy(), c.float().numpy(), k, s.cpu().numpy(), idx.cpu().numpy(), tol=5e-2)
+
+
 def test_dot_topk_skewed_scores_need_threshold_reruns():
     """A collection whose strided sample misses the dense head: the sampled threshold lets too few /
     too many candidates through and the host-side bisection must still deliver the exact top-k."""
