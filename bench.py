@@ -805,7 +805,7 @@ def extra_dot_topk(steps, cpu_budget):
            "roofline": {"bound": "mfma", "achieved": flop / t / 1e12, "peak": MFMA_PEAK_16BIT / 1e12, "unit": "TFLOP/s",
                         "frac": flop / t / MFMA_PEAK_16BIT},
            "kernel": "dot_stream_kernel (sample + filter) + sample_tau_kernel + topk_rows_kernel (whole mm_dot_topk_fwd call, wall clock)",
-           "profile": "profiles/r06_dot_topk_trace.json (counters: profiles/r03_dot_topk_pmc.json, kernel unchanged; power / clock: profiles/r06_experiments/dot_topk_power_trace.txt)"}
+           "profile": "profiles/r06_dot_topk_trace.json (counters: profiles/r06_dot_topk_pmc.json — the filter launch keeps the matrix pipe busy for 0.64 of its cycles at a 1.70 GHz delivered clock; by-removal and phase history: profiles/r06_experiments/dot_topk_filing_history.txt)"}
     if not LEAN:
         # what the vendor GEMM reaches on THIS box: the same product (one 262,144-passage slice, fp16 scores written, no
         # top-k) and a square 8192^3 — the matrix rate the board's power budget allows, next to the 2.5 PFLOP/s nominal peak

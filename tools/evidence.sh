@@ -34,6 +34,22 @@ for t in "abc":
         out["pmc"].setdefault(k, {}).update(v)
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 P
+# the dot top-k call alone: three counter passes (matrix-pipe busy cycles, LDS, waits) + the in-kernel phase clocks of the one-set form
+bash tools/prof_cmd.sh dot python tools/bench_dot_topk.py --steps 2 > gpurun_out/dot_$R.log 2>&1
+python - "$O/${R}_dot_topk_pmc.json" <<'P'
+import json, sys
+out = {"command": "python tools/bench_dot_topk.py --steps 2 (tools/prof_cmd.sh: three counter passes)", "pmc": {}}
+for t in "abc":
+    try:
+        j = json.load(open(f"gpurun_out/pmc_dot_{t}/summary.json"))
+    except OSError:
+        continue
+    for k, v in j.get("pmc", {}).items():
+        if "dot_stream" in k or "topk_rows" in k or "sample_tau" in k:
+            out["pmc"].setdefault(k, {}).update(v)
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+P
+MM_DOT_PROF=1 python tools/bench_dot_topk.py --steps 1 2>&1 | grep MM_DOT_PROF | tail -1 > $O/${R}_dot_topk_phases.txt
 if [ -f variants/libmm_native_phases.so ]; then
   MM_NATIVE_LIB=variants/libmm_native_phases.so python tools/bench_kp_bwd.py --child --phases --pairs 2048,32768 2>&1 | grep PHASES > $O/${R}_tk_bwd_phases.txt
 fi
