@@ -627,43 +627,14 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-__global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restrict__ all, int64_t ld, int n, int m,
-                                                          float* __restrict__ tau) {
-  // Radix select, one byte per pass (round 2 built the answer bit by bit: 32 count + barrier rounds, 36 us per row): the
-  // 16 keys of a thread stay in registers, a pass counts the keys that match the prefix found so far into a 256-bin LDS
-  // histogram, wavefront 0 scans it from the top.  Bytes on which all keys agree are skipped.
-  __shared__ int hist[256];
-  __shared__ int misc[8];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  uint32_t key[16];
-  uint32_t kmax = 0u, kmin = 0xffffffffu;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = tid + 1024 * e;
-    key[e] = i < n ? f2ord(all[(int64_t)row * ld + i]) : 0u;  // 0 sorts below every real value (incl. -inf)
-    kmax = key[e] > kmax ? key[e] : kmax;
-    kmin = key[e] < kmin ? key[e] : kmin;
-  }
-  if (tid < 8) misc[tid] = tid == 1 ? -1 : 0;                 // [0] max key, [1] min key (unsigned order)
-  __syncthreads();
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t a = (uint32_t)__shfl_xor((int)kmax, o, 64), b2 = (uint32_t)__shfl_xor((int)kmin, o, 64);
-    kmax = a > kmax ? a : kmax;
-    kmin = b2 < kmin ? b2 : kmin;
-  }
-  if (lane == 0) {
-    atomicMax((unsigned int*)&misc[0], kmax);
-    atomicMin((unsigned int*)&misc[1], kmin);
-  }
-  __syncthreads();
-  kmax = (uint32_t)misc[0];
-  kmin = (uint32_t)misc[1];
-  if (m > n) m = n;
-  if (m < 1) m = 1;
+// The m-th largest of NK keys per thread x 1,024 threads, one byte per pass: a pass counts the keys that match the prefix found
+// so far into a 256-bin LDS histogram, wavefront 0 scans it from the top.  Bytes on which all keys agree (kmax / kmin: bounds
+// of the key set in unsigned order) are skipped.  hist[256] / misc[8]: LDS scratch; every thread returns the same key.
+template <int NK>
+__device__ __forceinline__ uint32_t radix_mth_largest(const uint32_t (&key)[NK], int need, uint32_t kmax, uint32_t kmin, int* hist,
+                                                      int* misc, int tid, int lane) {
   const int common = kmax == kmin ? 32 : __builtin_clz(kmax ^ kmin);
   uint32_t prefix = common >= 32 ? kmax : (common == 0 ? 0u : (kmax & ~(0xffffffffu >> common)));
-  int need = m;
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (common >= 32 - shift) {                               // every key has the same byte here
       prefix = (prefix & ~(0xffu << shift)) | (kmax & (0xffu << shift));
@@ -673,7 +644,7 @@ __global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restric
     __syncthreads();
     const uint32_t hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int e = 0; e < NK; ++e)
       if ((key[e] & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key[e] >> shift) & 0xffu], 1);
     __syncthreads();
     if (tid < 64) {                                           // suffix scan: lane l owns bins 4l .. 4l + 3
@@ -702,6 +673,74 @@ __global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restric
     need -= misc[4];
     __syncthreads();
   }
+  return prefix;
+}
+
+__global__ void __launch_bounds__(1024) sample_tau_kernel(const float* __restrict__ all, int64_t ld, int n, int m,
+                                                          float* __restrict__ tau) {
+  // Radix select (round 2 built the answer bit by bit: 32 count + barrier rounds, 36 us per row): the 16 keys of a thread stay
+  // in registers.  Round 6: the working point asks for the m = 37th largest of 16,384 — the select first runs over the 1,024
+  // per-thread MAXIMA (one key per thread: a sixteenth of the histogram atomics, which all land in the few bins of the score
+  // distribution's top bytes).  Its answer T0 is a lower bound of the true m-th largest (m distinct positions are >= T0), the
+  // keys >= T0 — m plus the few threads that hold two of them — are gathered into LDS and ranked there: the same threshold, bit for
+  // bit, as the full select, which stays as the path for m > 256 and for tie-heavy rows (more than 1,024 keys >= T0).
+  __shared__ int hist[256];
+  __shared__ int misc[8];
+  __shared__ uint32_t cand[1024];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  uint32_t key[16];
+  uint32_t kmax = 0u, kmin = 0xffffffffu;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = tid + 1024 * e;
+    key[e] = i < n ? f2ord(all[(int64_t)row * ld + i]) : 0u;  // 0 sorts below every real value (incl. -inf)
+    kmax = key[e] > kmax ? key[e] : kmax;
+    kmin = key[e] < kmin ? key[e] : kmin;
+  }
+  const uint32_t tmax = kmax;                                 // this thread's largest key
+  if (tid < 8) misc[tid] = tid == 1 ? -1 : 0;                 // [0] max key, [1] min key (unsigned order), [5] candidates
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_xor((int)kmax, o, 64), b2 = (uint32_t)__shfl_xor((int)kmin, o, 64);
+    kmax = a > kmax ? a : kmax;
+    kmin = b2 < kmin ? b2 : kmin;
+  }
+  if (lane == 0) {
+    atomicMax((unsigned int*)&misc[0], kmax);
+    atomicMin((unsigned int*)&misc[1], kmin);
+  }
+  __syncthreads();
+  kmax = (uint32_t)misc[0];
+  kmin = (uint32_t)misc[1];
+  if (m > n) m = n;
+  if (m < 1) m = 1;
+  if (m <= 256) {
+    const uint32_t one[1] = {tmax};
+    const uint32_t t0 = radix_mth_largest<1>(one, m, kmax, kmin, hist, misc, tid, lane);   // (kmin <= every maximum <= kmax)
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (key[e] >= t0) {
+        const int pos = atomicAdd(&misc[5], 1);
+        if (pos < 1024) cand[pos] = key[e];
+      }
+    __syncthreads();
+    const int cnt = misc[5];
+    if (cnt <= 1024) {                                        // (wave-uniform; cnt >= m)
+      if (tid < cnt) {
+        const uint32_t mine = cand[tid];
+        int rank = 0;                                          // keys that sort before mine (ties: lower position first)
+        for (int j = 0; j < cnt; ++j) {
+          const uint32_t o = cand[j];
+          rank += (o > mine || (o == mine && j < tid)) ? 1 : 0;
+        }
+        if (rank == m - 1) tau[row] = ord2f(mine);
+      }
+      return;
+    }
+    __syncthreads();
+  }
+  const uint32_t prefix = radix_mth_largest<16>(key, m, kmax, kmin, hist, misc, tid, lane);
   if (tid == 0) tau[row] = ord2f(prefix);
 }
 
