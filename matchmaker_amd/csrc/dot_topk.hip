@@ -84,7 +84,9 @@ struct DotMfma<MM_F16> {
 
 __device__ __forceinline__ constexpr int drowof(int i) { return (i & 3) + 8 * (i >> 2); }
 
-// 8 x 16 B of one query row slice (256 B): chunks (2kk + h); own vmcnt(0) (prologue only)
+// 8 x 16 B of one query row slice (256 B): chunks (2kk + h).  NO wait inside: the prologue requests every slice of both query
+// tiles (96 loads per lane at dim 768) and waits once (dot_q_landed) — a wait per slice made the prologue twelve dependent round
+// trips, ~20 us per workgroup: 1 % of a filter workgroup's life, a third of a sampling workgroup's (16 blocks).
 #define MM_DOT_LOADQ(C)                                                                                 \
   asm volatile(                                                                                         \
       "global_load_dwordx4 %0, %8, off\n\t"                                                             \
@@ -94,12 +96,15 @@ __device__ __forceinline__ constexpr int drowof(int i) { return (i & 3) + 8 * (i
       "global_load_dwordx4 %4, %8, off offset:128\n\t"                                                  \
       "global_load_dwordx4 %5, %8, off offset:160\n\t"                                                  \
       "global_load_dwordx4 %6, %8, off offset:192\n\t"                                                  \
-      "global_load_dwordx4 %7, %8, off offset:224\n\t"                                                  \
-      "s_waitcnt vmcnt(0)"                                                                              \
+      "global_load_dwordx4 %7, %8, off offset:224"                                                       \
       : "=&" C(qf[0]), "=&" C(qf[1]), "=&" C(qf[2]), "=&" C(qf[3]), "=&" C(qf[4]), "=&" C(qf[5]),       \
         "=&" C(qf[6]), "=&" C(qf[7])                                                                    \
       : "v"(base)                                                                                       \
       : "memory")
+// the slice's registers are defined (again) HERE: placed behind the one s_waitcnt of the prologue, every use of the fragments
+// depends on this statement and so stays behind the wait (volatile statements keep their order; no instruction is emitted)
+#define MM_DOT_LANDQ(C)                                                                                 \
+  asm volatile("" : "+" C(qf[0]), "+" C(qf[1]), "+" C(qf[2]), "+" C(qf[3]), "+" C(qf[4]), "+" C(qf[5]), "+" C(qf[6]), "+" C(qf[7]))
 // AGPR = true: the fragments are loaded straight into accumulator registers and STAY there — the MFMA reads its B operand
 // from AGPRs directly.  Left to itself the register allocator treats the fragments that do not fit the 256 VGPRs as
 // spills and reloads them with four v_accvgpr_read before every use (192 of the 387 instructions of the K loop).
@@ -115,7 +120,20 @@ __device__ __forceinline__ void dot_load_q(const char* base, short8 (&qf)[8]) {
 #undef MM_C_V
   }
 }
+template <bool AGPR>
+__device__ __forceinline__ void dot_q_landed(short8 (&qf)[8]) {
+  if constexpr (AGPR) {
+#define MM_C_A(x) "a"(x)
+    MM_DOT_LANDQ(MM_C_A);
+#undef MM_C_A
+  } else {
+#define MM_C_V(x) "v"(x)
+    MM_DOT_LANDQ(MM_C_V);
+#undef MM_C_V
+  }
+}
 #undef MM_DOT_LOADQ
+#undef MM_DOT_LANDQ
 
 // NSL LDS-DMA instructions: 4 document rows x 256 B of every 128-dim slice -> 1 KiB of LDS each, the
 // slices 8 KiB apart (m0 walks).  The per-slice source offsets come in VGPRs: an instruction offset
@@ -234,6 +252,14 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
       else dot_load_q<false>(qrow + sl * 256, qf[n][sl]);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every fragment of the query tiles
+#pragma unroll
+  for (int n = 0; n < NQT; ++n)
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      if (NSL == 6 && NQT == 2 && n == 1) dot_q_landed<true>(qf[n][sl]);
+      else dot_q_landed<false>(qf[n][sl]);
+    }
   float tau[NQT];
 #pragma unroll
   for (int n = 0; n < NQT; ++n) tau[n] = (MODE == DOT_FILTER && qid[n] >= 0) ? a.tau[qid[n]] : __builtin_huge_valf();
