@@ -166,11 +166,20 @@ __device__ __forceinline__ void dot_issue(const char* gbase, uint32_t voff, uint
 // rides behind the MFMAs instead.  No lgkmcnt wait: the slot written is the one block b - 1 used, every read of which
 // was consumed before the barrier.
 __device__ __forceinline__ void dot_issue_one(const char* gbase, uint32_t voff, uint32_t lds_dst) {
+#if defined(MM_DOT_M0_KEEP)
+  // M0 is left holding the destination (declared clobbered): a write to M0 straight behind the request — the restore of the
+  // old value — has to wait until the request has read it
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(gbase), "s"(lds_dst)
+               : "memory", "m0");
+#else
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(gbase), "s"(lds_dst)
                : "memory");
+#endif
 }
 
 template <int N>
@@ -440,10 +449,15 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
     short8 av[AHEAD + 1];
 #pragma unroll
     for (int s = 0; s < AHEAD; ++s) av[s] = a_frag(abase, s);
+#if defined(MM_DOT_CUT) && MM_DOT_CUT == 10
+    av[AHEAD] = av[0];
+#endif
     __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);  // the first AHEAD reads go out together
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
+#if !defined(MM_DOT_CUT) || MM_DOT_CUT != 10
       if (s + AHEAD < STEPS) av[(s + AHEAD) % (AHEAD + 1)] = a_frag(abase, s + AHEAD);
+#endif
 #pragma unroll
 #if defined(MM_DOT_CUT) && MM_DOT_CUT == 7   // no matrix work: every fourth step keeps the operands alive
       for (int n = 0; n < NQT; ++n) if ((s & 3) == 0) acc[n] = DotMfma<DT>::run(av[s % (AHEAD + 1)], qf[n][s >> 3][s & 7], acc[n]); else asm volatile("" :: "v"(av[s % (AHEAD + 1)]), "v"(qf[n][s >> 3][s & 7]));
@@ -456,14 +470,14 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
         const int u = (s >> 1) / NSL, sl = (s >> 1) % NSL;
         // (fenced: without the two barriers the scheduler gathers the twelve requests at the head of the loop)
         __builtin_amdgcn_sched_barrier(0);
-#if !defined(MM_DOT_CUT) || MM_DOT_CUT != 8
+#if !defined(MM_DOT_CUT) || (MM_DOT_CUT != 8 && MM_DOT_CUT != 11)
         dot_issue_one(gbn, nvo[u] + (uint32_t)(sl * 256), ndst + (uint32_t)(u * 4096 + sl * 0x2000));
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (DEEP) {
         // test + park of block b - 1, element pair i = 15 - s (highest first: its bit is shifted up by the ones after it)
-#if !defined(MM_DOT_CUT) || MM_DOT_CUT != 6
+#if !defined(MM_DOT_CUT) || (MM_DOT_CUT != 6 && MM_DOT_CUT != 9)
         if (s < 16) {
           const int i = 15 - s;
           // [e = 16 n + i][lane]: the two tiles' slots are 16 x 256 B apart — one ds_write2st64_b32.  (Tried: the store and the
@@ -482,7 +496,7 @@ __global__ void __launch_bounds__(256) dot_stream_kernel(const DotArgs a) {
         if (s == 16) {
           pmask_prev = dpm[0] | (dpm[1] << 16);
           if (b == b_lo) pmask_prev = 0;   // (no block behind the first one: the other set holds zeros)
-#if defined(MM_DOT_CUT) && MM_DOT_CUT == 1
+#if defined(MM_DOT_CUT) && (MM_DOT_CUT == 1 || MM_DOT_CUT == 9 || MM_DOT_CUT == 10 || MM_DOT_CUT == 11)
           pmask_prev = 0;
 #endif
         }
