@@ -47,7 +47,7 @@ const EnvCfg& env() {
     c.kp_bwd_nsplit = env_int("MM_KP_BWD_NSPLIT", 0);
     c.tkl_stage1_slices = env_int("MM_TKL_STAGE1_SLICES", 0);
     c.tkl_stage1_ksplit = env_int("MM_TKL_STAGE1_KSPLIT", 0);
-    c.kp_multi_loop = env_int("MM_KP_MULTI_LOOP", 0);
+    c.kp_multi_loop = env_int("MM_KP_MULTI_LOOP", -1);
     c.kp_bwd_threads = env_int("MM_KP_BWD_THREADS", 1024);
     return c;
   }();

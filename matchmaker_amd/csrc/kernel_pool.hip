@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) kernel_pool_stream_kernel(const KpArgs a) 
   const uint32_t a_off = (uint32_t)(r * (kSC * 16) + h * 16);  // this lane's A-fragment base inside a slice
 
   Rbf rbf;
-  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+  load_rbf<K, false>(a.mu, a.sigma, a.alpha, a.w, rbf);   // (the exact-fp32 twin keeps the direct RBF form)
 
   const char* dbase = (const char*)a.d;
   auto doc_len = [&](int64_t p) -> int {
@@ -719,17 +719,14 @@ __global__ void __launch_bounds__(64 * WPP) kernel_pool_split_kernel(const KpArg
     if (!TKL && wv == 0) {
       float pk[kMaxK];
       if (np > 2) {  // np consecutive lanes hold the partial sums of one query token
-#pragma unroll
-        for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
+        pk_get<K>(pk, pk2, rbf);
         redist_reduce<K>(pk, np, lane);
         const bool count = rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u);
         finish_pool<K>(a, pair, pk, count, lane, rbf, rsub == 0 ? rtk : -1);
       } else {
+        pk_get<K>(pk, pk2, rbf);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          pk[k] = pk2[k >> 1][k & 1];
-          pk[k] += __shfl_xor(pk[k], 32, 64);
-        }
+        for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
         finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1);
       }
     }
@@ -854,7 +851,7 @@ __global__ void __launch_bounds__(64) tkl_stage1_run_kernel(const KpArgs a) {
   const uint32_t l_off = (uint32_t)(r * (kSC * 16) + 24 * 16);
 
   Rbf rbf;
-  if constexpr (!COS) load_rbf<K>(a.mu, a.sigma, nullptr, nullptr, rbf);   // (the cosine hand-off evaluates no kernels here)
+  if constexpr (!COS) load_rbf<K, false>(a.mu, a.sigma, nullptr, nullptr, rbf);   // (the cosine hand-off evaluates no kernels here)
 
   const char* dbase = (const char*)a.d;
   // run of up to 4 consecutive packed chunks of one document starting at chunk p (inside [p, p1))

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
     for (int j = 0; j < 2; ++j) aoff[p][j] = (uint32_t)(r * 256 + (((4 * p + 2 * h + j) ^ (r & 15)) << 4));
 
   Rbf rbf;
-  if constexpr (!MX) load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+  if constexpr (!MX) load_rbf<K, KS == 1>(a.mu, a.sigma, a.alpha, a.w, rbf);   // (the K-split pair shares the epilogue by kernel pairs: direct form)
 
   const char* dbase = (const char*)a.d;
   auto doc_len = [&](int64_t p) -> int {
@@ -385,17 +385,14 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
     }
     float pk[kMaxK];
     if (KS == 1 && np > 2) {  // np consecutive lanes hold the partial sums of one query token
-#pragma unroll
-      for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
+      pk_get<K>(pk, pk2, rbf);
       redist_reduce<K>(pk, np, lane);
       finish_pool<K>(a, pair, pk, rsub == 0 && rtk < qn && ((qbits >> rtk) & 1u), lane, rbf, rsub == 0 ? rtk : -1);
       continue;
     }
+    pk_get<K>(pk, pk2, rbf);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      pk[k] = pk2[k >> 1][k & 1];
-      pk[k] += __shfl_xor(pk[k], 32, 64);
-    }
+    for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
     if constexpr (KS == 1) {
       finish_pool<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, lane < 32 ? lane : -1);
     } else {
@@ -424,10 +421,10 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
 // (i, t) order by the same kp_sum_blocks_kernel.  One wavefront per SIMD (the fragments need the register file).
 // MEASURED (64 x 1000 pairs, Q30 / D200 / E128, same box, round-robin; tools/conv_knrm_ab.sh): FETCH_SIZE 22.5 GB per launch
 // (13.7 GB of document rows + 8.8 GB of query tiles, each read by the three document-tensor wavefronts of its pair) against
-// 47.3 GB — and 9.68 ms against 8.65 ms.  The launch is bound by the 40.5 G RBF evaluations (5 VALU instructions per kernel
-// pair and row: ~5 ms of VALU issue at best), and ONE wavefront per SIMD cannot overlap their latencies the way the two thinner
-// wavefronts of the per-combination form do; saving 25 GB of traffic the HBM was not saturated by buys nothing.  Kept as
-// MM_KP_MULTI_LOOP=1 for A/B runs; the per-combination form stays the default.
+// 47.3 GB.  With the direct RBF form (twelve v_exp_f32 per cosine) it was the slower form all the same, 9.68 against 8.65 ms:
+// ONE wavefront per SIMD cannot overlap its epilogue with anything.  With the middle-out recurrence (kp_device.h rbf_geo_one:
+// two thirds of the epilogue's issue cycles) it is 8.38 ms, the per-combination form — which sits on its 47 GB of traffic, not
+// on the epilogue — stays at 8.66: this form is the default for launches of >= 2,048 pairs (kp128_launch).
 template <int NSL, int K, int NQ>
 __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -610,11 +607,9 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
       float pk[kMaxK];
+      pk_get<K>(pk, pk2[iq], rbf);
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        pk[k] = pk2[iq][k >> 1][k & 1];
-        pk[k] += __shfl_xor(pk[k], 32, 64);
-      }
+      for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
       const int y = iq * a.n_md + td;                                  // combination (i, t): its bin weights, its partial row
       sload_vec<K>(a.w + y * K, rbf.w);
       const float total = pool_partial<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, -1);
@@ -715,8 +710,12 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
     return dim3((unsigned)(flat * (a.n_mblk / a.n_md)), 1u);
   };
   // Conv-KNRM's multi launch at E <= 128 with three query tensors: one wavefront per (pair range, document tensor) looping over
-  // the query tensors (kernel_pool_multi128_kernel): every document block crosses HBM once — and slower, see there (MM_KP_MULTI_LOOP=1: A/B only).
-  if (a.n_md > 0 && !gated && nsl <= 2 && a.n_mblk / a.n_md == 3 && env().kp_multi_loop && !a.pair_q) {
+  // the query tensors (kernel_pool_multi128_kernel): every document block crosses HBM once.  The default once every SIMD's
+  // wavefront has a few pairs of its own (with the recurrence epilogue: 8.38 vs 8.66 ms and half the traffic, see there); smaller
+  // launches keep the per-combination form, which has n_mq times the wavefronts.  MM_KP_MULTI_LOOP = 0 / 1 forces either (A/B runs).
+  const bool loop_auto = a.n_pairs >= (int64_t)kCUs * 4 * 2;
+  if (a.n_md > 0 && !gated && nsl <= 2 && a.n_mblk / a.n_md == 3 && !a.pair_q &&
+      (env().kp_multi_loop == 1 || (env().kp_multi_loop < 0 && loop_auto))) {
     const int ldsm = kp128_lds_fixed(1);
     int64_t groups = (int64_t)kCUs * 4 / a.n_md;
     if (groups < 1) groups = 1;

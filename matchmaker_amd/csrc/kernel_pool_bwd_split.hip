@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) kp_bwd_split_kernel(const KpBwdArgs a,
   bf16x8 qah[NGW], qal[NGW];     // cosine product: B[k = column][n = token]: this lane = token r, columns 16 g + 8 h + 0..7
   bf16x8 qbh[NGW], qbl[NGW];     // grad_d product (16x16x32): B[k = token][n = column]: this lane = column lane & 15 of the granule, tokens 8 (lane >> 4) + 0..7
   Rbf rbf;
-  load_rbf<K>(a.mu, a.sigma, a.alpha, a.w, rbf);
+  load_rbf<K, false>(a.mu, a.sigma, a.alpha, a.w, rbf);
   const float g = MODE ? a.go[pair] : 0.0f;
   float pkv[K];                                               // MODE 1: the forward's pooled sums of this lane's token
 #pragma unroll

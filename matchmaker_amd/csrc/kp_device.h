@@ -134,6 +134,15 @@ struct Rbf {
   // kernels are processed two at a time, an odd K gets a dummy partner (sq = 0) whose sum is ignored
   f32x2 sq2[kMaxK / 2];
   f32x2 msq2[kMaxK / 2];
+  // Equally spaced kernels of one width (the reference's ten soft-match kernels, mu = 0.9 .. -0.9, sigma = 0.1, behind the
+  // exact-match kernel 0): evaluated middle-out by recurrence instead of one exp2 each (rbf_block_geo below).  `geo` is decided
+  // per launch from the parameter VALUES (load_rbf): any other kernel set runs the direct form.  The recurrence's constants
+  // take the PLACE of the direct form's (no register beside them — the two-wavefront E = 128 kernel has none to spare):
+  //   sq2[0], msq2[0][0]: as in the direct form (kernel 0 stays direct; sq2[0][1] = s of kernels 1 .. 10)
+  //   sq2[1] = {-mu5 s, -mu6 s}: t = c s + sq2[1] = the scaled distances to the two middle kernels
+  //   sq2[2] = {2 delta, -2 delta}, delta = (mu5 - mu6) s: exponent slope of the neighbour ratios;  sq2[3][0] = -delta^2
+  //   msq2[1][0], msq2[1][1], msq2[2][0] = g, g^3, g^6, g = 2^(-2 delta^2): what the running sums of steps 3 .. 5 are short of
+  bool geo = false;
 };
 
 // nk <= K real kernels (nk < K: the generic kernel's run-time kernel count); the rest are dummies
@@ -186,7 +195,36 @@ __device__ __forceinline__ void sload_vec(const float* base, float (&out)[kMaxK]
 
 // Kernel parameters are wave-uniform: fetch them through the scalar cache (SGPRs, no vmcnt traffic
 // that would make the compiler drain the LDS-DMA queue inside the block loop).
+// Is the kernel set the middle-out recurrence's (K = 11: kernel 0 anything, kernels 1 .. 10 of ONE width and equally spaced,
+// descending)?  Wave-uniform, decided from the parameter values once per wavefront.  Also required: the two middle kernels
+// must not underflow for any cosine in [-1, 1] (every other kernel is reached from them by multiplication: a zero there would
+// zero kernels that are not), and the neighbour ratios must stay finite under the clamp |t| <= kGeoClamp.
 template <int K>
+__device__ __forceinline__ void detect_geo(Rbf& rbf, const float (&sg)[kMaxK]) {
+  rbf.geo = false;
+  if constexpr (K == 11 && MM_RBF_GEO) {
+    const float dmu = rbf.mu[5] - rbf.mu[6];
+    bool ok = dmu > 0.0f;
+#pragma unroll
+    for (int k = 1; k < 10; ++k) ok = ok && fabsf((rbf.mu[k] - rbf.mu[k + 1]) - dmu) <= 1.0e-6f && sg[k] == sg[k + 1];
+    const float s = rbf.sq2[0][1];
+    const float delta = dmu * s;
+    const float reach = (1.0f + fmaxf(fabsf(rbf.mu[5]), fabsf(rbf.mu[6]))) * s;   // largest |t| of a middle kernel over [-1, 1]
+    ok = ok && reach * reach < 120.0f && 2.0f * delta * kGeoClamp < 100.0f;
+    const bool on = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+    rbf.geo = on;
+    if (on) {   // wave-uniform
+      rbf.sq2[1] = f32x2{-rbf.mu[5] * s, -rbf.mu[6] * s};
+      rbf.sq2[2] = f32x2{2.0f * delta, -2.0f * delta};
+      rbf.sq2[3][0] = -delta * delta;
+      const float l2g = -2.0f * delta * delta;
+      rbf.msq2[1] = f32x2{__builtin_amdgcn_exp2f(l2g), __builtin_amdgcn_exp2f(3.0f * l2g)};
+      rbf.msq2[2][0] = __builtin_amdgcn_exp2f(6.0f * l2g);
+    }
+  }
+}
+
+template <int K, bool GEO = true>
 __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, const float* alpha, const float* w, Rbf& rbf) {
   float sg[kMaxK];
   if constexpr (K == 11) {
@@ -209,6 +247,7 @@ __device__ __forceinline__ void load_rbf(const float* mu, const float* sigma, co
     rbf.c2[k] = -1.4426950408889634f / (2.0f * sg[k] * sg[k]);
   }
   pack_rbf<K>(rbf);
+  if constexpr (GEO) detect_geo<K>(rbf, sg);
 }
 
 // Epilogue of one 32-token document block: cosine scaling + K RBF kernels, summed into pk[k].
@@ -229,9 +268,88 @@ struct RbfPk {
   f32x2 msq2[kMaxK / 2];
 };
 
+
+// ---- middle-out recurrence over equally spaced kernels (Rbf::Geo) ----------------------------------------------------------
+// exp2(-(t - j delta)^2) = exp2(-t^2) * u^j * g^(j (j - 1) / 2) with u = exp2(2 delta t - delta^2), g = exp2(-2 delta^2): from the
+// two middle kernels (5, 6) the pairs (4, 7), (3, 8), (2, 9), (1, 10) are each ONE packed multiply by the running ratio pair
+// (u, d) away — the constant factor g^(j (j - 1) / 2) is left out of the running sums and applied once per pair (pk_get) —
+// so a cosine costs 4 + 1 v_exp_f32 and 12 packed + 5 plain VALU instead of 12 v_exp_f32 and 18 packed (by the per-instruction
+// issue costs of profiles/r01_inst_cost_ubench.txt: ~134 instead of ~206 cycles).  Kernel 0 (the exact-match kernel, sigma
+// 1e-3) keeps the direct form.  Sums land in geo order: pk2[0] = (k0, -), pk2[j] = (k(6 - j), k(5 + j)), j = 1 .. 5.
+// A masked row arrives as cosine 1e5: its t is clamped to kGeoClamp, where exp2(-t^2) is exactly 0 and the ratios are finite:
+// 0 x finite = exactly 0 in every kernel, as in the direct form.  Real cosines (|c| <= 1) never reach the clamp.
+// Accuracy: the kernel j steps from the middle carries j ratio roundings, ~5e-6 relative at j = 4 against ~4e-7 direct — a
+// twentieth of what the split-bf16 cosine itself contributes to an activation (1e-4), above the exact-fp32 twins' own error:
+// those load their constants with load_rbf<K, false> and stay direct.
+template <bool W>
+__device__ __forceinline__ void rbf_geo_one(f32x2 (&pk2)[kMaxK / 2], float c, float lw, const Rbf& rbf) {
+  const f32x2 cc = {c, c};
+  const float s = rbf.sq2[0][1];
+  f32x2 t = cc * f32x2{s, s} + rbf.sq2[1];
+  t = f32x2{__builtin_amdgcn_fmed3f(t[0], -kGeoClamp, kGeoClamp), __builtin_amdgcn_fmed3f(t[1], -kGeoClamp, kGeoClamp)};
+  const f32x2 lwv = {lw, lw};
+  const f32x2 av = W ? lwv - t * t : -(t * t);
+  const f32x2 rv = t * rbf.sq2[2] + f32x2{rbf.sq2[3][0], rbf.sq2[3][0]};
+  f32x2 e = {__builtin_amdgcn_exp2f(av[0]), __builtin_amdgcn_exp2f(av[1])};
+  const f32x2 ud = {__builtin_amdgcn_exp2f(rv[0]), __builtin_amdgcn_exp2f(rv[1])};
+  pk2[1] += e;
+#pragma unroll
+  for (int j = 2; j <= 5; ++j) {
+    e *= ud;
+    pk2[j] += e;
+  }
+  const float sv = c * rbf.sq2[0][0] - rbf.msq2[0][0];
+  const float a0 = W ? lw - sv * sv : -(sv * sv);
+  pk2[0][0] += __builtin_amdgcn_exp2f(a0);
+}
+
+template <bool W, int G0 = 0, int G1 = 4>
+__device__ __forceinline__ void rbf_block_geo(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
+                                              uint32_t va, int h, const Rbf& rbf, const float* lw) {
+  const uint32_t vbits = va >> (4 * h);
+#pragma unroll
+  for (int g = G0; g < G1; ++g) {
+    const uint32_t gm = (va >> (8 * g)) & 0xffu;
+    if (gm == 0) continue;
+    const bool full = gm == 0xffu;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = 4 * g + ii;
+      float c = (acc[i] * rq) * rdr[i];
+      if (!full) c = ((vbits >> rowof(i)) & 1u) ? c : 1.0e5f;
+      rbf_geo_one<W>(pk2, c, W ? lw[i] : 0.0f, rbf);
+    }
+  }
+}
+
+// kernel k's pooled sum out of the running sums, in whichever order the epilogue filed them
+template <int K>
+__device__ __forceinline__ void pk_get(float (&pk)[kMaxK], const f32x2 (&pk2)[kMaxK / 2], const Rbf& rbf) {
+  if constexpr (K == 11 && MM_RBF_GEO) {
+    if (rbf.geo) {
+      const float gs[5] = {1.0f, 1.0f, rbf.msq2[1][0], rbf.msq2[1][1], rbf.msq2[2][0]};
+      pk[0] = pk2[0][0];
+#pragma unroll
+      for (int j = 1; j <= 5; ++j) {
+        pk[6 - j] = j > 2 ? pk2[j][0] * gs[j - 1] : pk2[j][0];
+        pk[5 + j] = j > 2 ? pk2[j][1] * gs[j - 1] : pk2[j][1];
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) pk[k] = pk2[k >> 1][k & 1];
+}
+
 template <int K, bool W = false, int KP0 = 0, int KP1 = (K + 1) / 2, int G0 = 0, int G1 = 4, typename R = Rbf>
 __device__ __forceinline__ void rbf_block(f32x2 (&pk2)[kMaxK / 2], const f32x16& acc, const float (&rdr)[16], float rq,
                                           uint32_t va, int h, const R& rbf, const float* lw = nullptr) {
+  if constexpr (K == 11 && MM_RBF_GEO && KP0 == 0 && KP1 == (K + 1) / 2 && __is_same(R, Rbf)) {
+    if (rbf.geo) {   // wave-uniform
+      rbf_block_geo<W, G0, G1>(pk2, acc, rdr, rq, va, h, rbf, lw);
+      return;
+    }
+  }
   // va (wave-uniform): bit r set <=> row r of the block is a real token.  Accumulator registers
   // 4g..4g+3 hold rows 8g..8g+7 (both lane halves), so a group with no real row is skipped as a
   // whole (the last block of a document: D = 200 -> 8 of 32 rows) and a group of 8 real rows needs
@@ -270,6 +388,13 @@ __device__ __forceinline__ float gate_log2(float g) { return __builtin_amdgcn_lo
 template <int K, bool W, int ROWS, typename R = Rbf>
 __device__ __forceinline__ void rbf_rows(f32x2 (&pk2)[kMaxK / 2], const float (&c)[ROWS], uint32_t bits, const R& rbf,
                                          const float (&lw)[ROWS]) {
+  if constexpr (K == 11 && MM_RBF_GEO && __is_same(R, Rbf)) {
+    if (rbf.geo) {   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) rbf_geo_one<W>(pk2, ((bits >> j) & 1u) ? c[j] : 1.0e5f, lw[j], rbf);
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < ROWS; ++j) {
     const float cj = ((bits >> j) & 1u) ? c[j] : 1.0e5f;

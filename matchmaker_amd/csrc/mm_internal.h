@@ -45,9 +45,9 @@ struct EnvCfg {
   int kp_multi_wg = 0;        // MM_KP_MULTI_WG=1: the multi launch as one workgroup per (pair range, document tensor) with a wavefront per query
                               // tensor and a rate barrier per block, instead of independent workgroups in flat XCD-grouped order (A/B runs:
                               // measured SLOWER, 9.19 vs 8.40 ms for Conv-KNRM 3 x 3 — six wavefronts per CU instead of eight)
-  int kp_multi_loop = 0;      // MM_KP_MULTI_LOOP=1: Conv-KNRM's multi launch as one wavefront per (pair range, document tensor) looping over the query
-                              // tensors (kernel_pool_multi128_kernel, round 6: every document block crosses HBM once — 22.5 GB fetched instead of
-                              // 47.3 — but 9.68 vs 8.65 ms: one wavefront per SIMD cannot hide the RBF epilogue that bounds the launch; A/B runs)
+  int kp_multi_loop = -1;     // MM_KP_MULTI_LOOP: Conv-KNRM's multi launch as one wavefront per (pair range, document tensor) looping over the query
+                              // tensors (kernel_pool_multi128_kernel: every document block crosses HBM once, 22.5 GB fetched instead of 47.3).
+                              // -1 = by launch size (>= 2,048 pairs), 0 / 1 = never / always (A/B runs)
   int kp_multi_2d = 0;        // MM_KP_MULTI_2D=1: Conv-KNRM's multi launch on the 2-D grid of rounds 1-4 instead of the flat XCD-grouped order (A/B runs)
   int kp128_occ = 0;          // MM_KP128_OCC: 0 = choose by shape, 1 / 2 = wavefronts per SIMD of the 64n-wide pooling kernel (A/B runs)
   int tkl_bwd_nosplit = 0;    // MM_TKL_BWD_NOSPLIT=1: TKL's backward with one workgroup per document at every batch size (A/B runs)
@@ -85,6 +85,13 @@ int resolve_mask_pair(const void* m0, int kind0, int64_t rows0, int L0, PackedMa
 
 constexpr int kK = 11;   // RBF kernels of TK / TKL (tk.yaml:18-19, tkl.yaml)
 constexpr int kKC = 12;  // K + the non-zero-count channel of TKL's pair sums
+
+// RBF kernels by middle-out recurrence where the kernel set allows it (kp_device.h rbf_geo_one, tkl.hip's window staging);
+// -DMM_RBF_GEO=0 builds the direct form everywhere (A/B libraries).
+#ifndef MM_RBF_GEO
+#define MM_RBF_GEO 1
+#endif
+constexpr float kGeoClamp = 13.0f;   // exp2(-13^2) = 0 exactly (below the smallest denormal): a clamped masked row adds exactly 0
 
 struct TklParams {            // offsets into the packed float parameter vector (see mm_native.h)
   __host__ __device__ static int mu() { return 0; }
