@@ -1175,7 +1175,7 @@ def extra_variants(steps, cpu_budget):
         if not subset or name in subset:
             _one(name, *a, **kw)
     one("knrm", 30, 200, 300, kern="kernel_pool_split_kernel<3, 11, 3, false, false, false, 1>", ref="models/knrm.py:52-84 (alpha = 1, x 0.01 folded into the weights)")
-    one("conv_knrm_3x3", 30, 200, 128, n_d=3, n_q=3, kern="kernel_pool_split128_kernel<2, 11, false, 1, 0, 2", pats=("r06*conv_knrm*pmc*.json",), ref="models/conv_knrm.py:144-170: n_grams^2 = 9 poolings + dense, one launch (pair-per-row)")
+    one("conv_knrm_3x3", 30, 200, 128, n_d=3, n_q=3, kern="kernel_pool_multi128_kernel<2, 11, 3>", pats=("r06*conv_knrm*pmc*.json",), ref="models/conv_knrm.py:144-170: n_grams^2 = 9 poolings + dense, one launch (pair-per-row)")
     one("tk_sparse", 30, 200, 300, gate=True, kern="kernel_pool_split_kernel<3, 11, 3, false, false, true, 1>", ref="published/cikm20_tk_sparse.py:106-146 (stop-word gate)")
     one("idcm_sampler_ck", 30, 64, 768, clamp=1e-4, kern="kernel_pool_split128_kernel<6,", ref="published/sigir21_idcm.py:182-186, sample_context ck (768-d)")
     one("idcm_sampler_ck_small", 30, 64, 128, clamp=1e-4, kern="kernel_pool_split128_kernel<2,", ref="published/sigir21_idcm.py:182-186, sample_context ck-small (128-d)")

@@ -551,3 +551,102 @@ def test_multi_launch_in_flat_xcd_order_with_two_wavefronts_per_simd(tmp_path):
             ref += O.tk_kernel_pool(qs[i][sample].numpy(), ds[j][sample].numpy(), qm[sample].numpy(), dm[sample].numpy(), MU, SIGMA,
                                     np.ones(11, np.float32), w[i * 3 + j].numpy(), dtype=np.float64)
     np.testing.assert_allclose(got.cpu().numpy()[sample], ref, atol=util.TOL_FP32, rtol=1e-5)
+
+
+# ---- the ten equally spaced kernels by middle-out recurrence (kp_device.h rbf_geo_one) ---------------------------------------
+# The recurrence is chosen per launch from the parameter VALUES: a sigma one part in 10^6 off leaves the equal-width test
+# and makes the same launch run the direct form (twelve exp2 per cosine) — the two must tell the same story.
+
+@pytest.mark.parametrize("Q,D,E,ppq,nq,gated", [(20, 200, 300, 8, 3, False),    # redistributed rows (3 lanes x 11) on the E = 100n kernel
+                                                  (30, 180, 300, 1, 10, False),   # MFMA-layout epilogue
+                                                  (20, 200, 300, 8, 3, True),     # TK-Sparse gate in the exponent
+                                                  (30, 70, 128, 5, 4, False),     # 64n-wide kernel (Conv-KNRM's tensors, IDCM's ck-small)
+                                                  (8, 64, 128, 16, 6, False),     # short query, short documents: two wavefronts per SIMD
+                                                  (32, 100, 384, 3, 4, True)])
+def test_rbf_recurrence_agrees_with_the_direct_form(Q, D, E, ppq, nq, gated):
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(Q * 977 + D + E)
+    B = nq * ppq
+    q = torch.randn(nq, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g) * 0.5
+    for b in range(B):            # cosines over the whole range, both ends included: d = +-q (c = +-1), mixtures in between
+        qq = q[b // ppq]
+        d[b, 0] = qq[b % Q] * 3.0
+        d[b, 1 % D] = -qq[(b + 1) % Q] * 0.25
+        for j in range(2, min(D, 24)):
+            lam = (j - 2) / 21.0 * 2.0 - 1.0
+            n = torch.randn(E, generator=g)
+            d[b, j] = lam * qq[(b + j) % Q] / qq[(b + j) % Q].norm() + (1 - abs(lam)) * n / n.norm()
+    q_len = torch.randint(max(1, Q // 2), Q + 1, (nq,), generator=g)
+    d_len = torch.randint(D // 3, D + 1, (B,), generator=g)
+    d_len[0] = D
+    d_len[-1] = 0                 # an empty document: every pooled sum exactly 0 in both forms
+    qm = (torch.arange(Q)[None] < q_len[:, None]).float()
+    dm = (torch.arange(D)[None] < d_len[:, None]).float()
+    dm[0, D // 2] = 0.0
+    dm[1, 0] = 0.0                # the exact match of pair 1 is masked
+    gate = (torch.rand(B, D, generator=g) * 1.5).clamp(min=0.0) if gated else None
+    if gated:
+        gate[:, 3] = 0.0
+    alpha = torch.rand(11, generator=g) + 0.5
+    w = (torch.rand(11, generator=g) - 0.5) * 0.03
+    mu = torch.tensor(MU)
+    sigma = torch.tensor(SIGMA)
+    sigma_off = sigma.clone()
+    sigma_off[3] = 0.1 * (1.0 + 1.0e-6)                        # != its neighbours: direct form
+    assert sigma_off[3] != sigma_off[2]
+
+    def run(sg):
+        return ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), mu.to(dev), sg.to(dev), alpha.to(dev), w.to(dev),
+                               pairs_per_query=ppq, return_per_kernel=True, d_gate=None if gate is None else gate.to(dev),
+                               return_pooled=True)
+    s_geo, pk_geo, pooled_geo = run(sigma)
+    s_dir, pk_dir, pooled_dir = run(sigma_off)
+    # pooled kernel sums of real query tokens (the backward reads exactly these)
+    real = (qm[torch.arange(B) // ppq] > 0).to(dev)
+    a, b_ = pooled_geo[real].double(), pooled_dir[real].double()
+    rel = ((a - b_).abs() / (b_.abs() + 1e-6)).max().item()
+    assert rel < 1e-4, f"pooled kernel sums differ by {rel:.2e} relative between the recurrence and the direct form"
+    np.testing.assert_allclose(pk_geo.cpu().numpy(), pk_dir.cpu().numpy(), atol=2e-4, rtol=2e-5)
+    np.testing.assert_allclose(s_geo.cpu().numpy(), s_dir.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    # the empty document and masked rows add exactly nothing: log(clamp_min) per real token in every kernel, both forms
+    assert torch.equal(pk_geo[-1], pk_dir[-1])
+    assert float(pooled_geo[-1][real[-1]].abs().max()) == 0.0
+    # and both against the fp64 oracle
+    qi = np.arange(B) // ppq
+    if gate is None:
+        ref = O.tk_kernel_pool(q.numpy()[qi], d.numpy(), qm.numpy()[qi], dm.numpy(), MU, SIGMA, alpha.numpy(), w.numpy(),
+                               dtype=np.float64)
+        np.testing.assert_allclose(s_geo.cpu().numpy(), ref, atol=util.TOL_FP32)
+
+
+def test_rbf_recurrence_only_for_the_kernel_sets_it_was_derived_for():
+    """Unequal spacing, unequal widths, ascending order, a width too small for the middle kernels to stay representable over
+    [-1, 1]: each leaves the launch on the direct form, which the fp64 oracle pins (a recurrence over any of these would be
+    wrong by orders of magnitude, not by rounding)."""
+    from matchmaker_amd import ops
+    dev = util.require_gpu()
+    g = torch.Generator().manual_seed(77)
+    Q, D, E, B = 30, 96, 128, 12
+    q = torch.randn(B, Q, E, generator=g)
+    d = torch.randn(B, D, E, generator=g)
+    for b in range(B):
+        d[b, b] = q[b, b] * 2.0
+        d[b, b + 1] = -q[b, b + 1]
+    qm = torch.ones(B, Q)
+    dm = torch.ones(B, D)
+    alpha = torch.ones(11)
+    w = (torch.rand(11, generator=g) - 0.5) * 0.03
+    sets = {
+        "unequal spacing": (MU[:4] + [0.35] + MU[5:], SIGMA),
+        "unequal widths": (MU, SIGMA[:6] + [0.15] + SIGMA[7:]),
+        "ascending": ([1.0] + MU[:0:-1], SIGMA),
+        "narrow": (MU, [0.001] + [0.04] * 10),
+        "shifted": ([1.0] + [m + 0.5 for m in MU[1:]], SIGMA),
+    }
+    for name, (mu, sg) in sets.items():
+        out = ops.kernel_pool(q.to(dev), d.to(dev), qm.to(dev), dm.to(dev), torch.tensor(mu).to(dev), torch.tensor(sg).to(dev),
+                              alpha.to(dev), w.to(dev))
+        ref = O.tk_kernel_pool(q.numpy(), d.numpy(), qm.numpy(), dm.numpy(), mu, sg, alpha.numpy(), w.numpy(), dtype=np.float64)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, atol=util.TOL_FP32, err_msg=name)
