@@ -139,6 +139,59 @@ def cosine_matrix_split_bf16(a, b, lolo=False):
     return (dot * ra) * np.swapaxes(rb, -1, -2)
 
 
+def rbf_recurrence_fp32(c, mu, sigma):
+    """Emulation of the DEVICE arithmetic of the pooling epilogue's recurrence form (matchmaker_amd/csrc/kp_device.h
+    rbf_geo_one / detect_geo): the reference's kernel set — kernel 0 anything, kernels 1 .. 10 equally spaced (descending)
+    with one width — evaluated from the two middle kernels outwards, exp2(-(t - j delta)^2) = exp2(-t^2) u^j g^(j (j - 1) / 2),
+    every operation rounded to fp32 in the kernel's order; kernel 0 in the direct form.  c: cosines (any shape), masked
+    positions as 1e5.  Returns [..., 11] float32 activations, or None when the kernel set is not one the device would run
+    this way (it then evaluates exp2(-(c sq - mu sq)^2) per kernel: `rbf_direct_fp32`).  Not a reference restatement: it
+    lets the CPU suite bound the recurrence's rounding against the exact kernel values without a GPU."""
+    f = np.float32
+    mu = np.asarray(mu, dtype=f)
+    sg = np.asarray(sigma, dtype=f)
+    if mu.shape[0] != 11:
+        return None
+    dmu = f(mu[5] - mu[6])
+    ok = dmu > 0
+    for k in range(1, 10):
+        ok = ok and abs(f(f(mu[k] - mu[k + 1]) - dmu)) <= f(1e-6) and sg[k] == sg[k + 1]
+    c2 = f(-1.4426950408889634) / (f(2.0) * sg * sg)
+    sq = np.sqrt(-c2).astype(f)
+    s = sq[1]
+    delta = f(dmu * s)
+    reach = f((f(1.0) + max(abs(mu[5]), abs(mu[6]))) * s)
+    ok = ok and reach * reach < f(120.0) and f(2.0) * delta * f(13.0) < f(100.0)
+    if not ok:
+        return None
+    c = np.asarray(c, dtype=f)
+    t = np.stack([c * s + f(-mu[5] * s), c * s + f(-mu[6] * s)], -1).astype(f)
+    t = np.clip(t, f(-13.0), f(13.0))
+    e = np.exp2(-(t * t).astype(f)).astype(f)
+    ud = np.exp2((t * np.array([f(2.0) * delta, f(-2.0) * delta], dtype=f) + f(-delta * delta)).astype(f)).astype(f)
+    l2g = f(f(-2.0) * delta * delta)
+    gs = [f(1), f(1), np.exp2(l2g).astype(f), np.exp2(f(3.0) * l2g).astype(f), np.exp2(f(6.0) * l2g).astype(f)]
+    out = np.zeros(c.shape + (11,), dtype=f)
+    out[..., 5], out[..., 6] = e[..., 0], e[..., 1]
+    for j in range(2, 6):
+        e = (e * ud).astype(f)
+        out[..., 6 - j] = (e[..., 0] * gs[j - 1]).astype(f)     # (the device scales the pair's SUM once; same factor)
+        out[..., 5 + j] = (e[..., 1] * gs[j - 1]).astype(f)
+    sv = (c * sq[0] - f(mu[0] * sq[0])).astype(f)
+    out[..., 0] = np.exp2(-(sv * sv).astype(f)).astype(f)
+    return out
+
+
+def rbf_direct_fp32(c, mu, sigma):
+    """The direct device form, exp2(-(c sq - mu sq)^2) with sq = sqrt(log2(e) / (2 sigma^2)) (kp_device.h pack_rbf / rbf_block)."""
+    f = np.float32
+    mu = np.asarray(mu, dtype=f)
+    sg = np.asarray(sigma, dtype=f)
+    sq = np.sqrt(f(1.4426950408889634) / (f(2.0) * sg * sg)).astype(f)
+    sv = (np.asarray(c, dtype=f)[..., None] * sq - (mu * sq).astype(f)).astype(f)
+    return np.exp2(-(sv * sv).astype(f)).astype(f)
+
+
 def maxsim_paired_split_bf16(q, d, q_mask, d_mask):
     """Emulation of the DEVICE arithmetic of the fp32 MaxSim path (kernel_pool128.hip, MX = true): every fp32
     operand x = hi + lo (two bf16), dot = hi.hi + lo.hi + hi.lo + lo.lo with exact products and fp32-class

@@ -510,14 +510,17 @@ def _multi_case(dev, seed=5):
     ds = [torch.relu(torch.randn(B, D, E, generator=g)) for _ in range(n)]
     qm = (torch.arange(Q)[None] < torch.randint(1, Q + 1, (B,), generator=g)[:, None]).float()
     dm = (torch.arange(D)[None] < torch.randint(0, D + 1, (B,), generator=g)[:, None]).float()
+    if seed != 5:                 # holes: the masks travel as bit words instead of lengths
+        dm[torch.arange(0, B, 7), torch.randint(0, D, (len(range(0, B, 7)),), generator=g)] = 0.0
+        qm[torch.arange(0, B, 11), 0] = 0.0
     w = torch.randn(n * n, 11, generator=g) * 0.01
     return qs, ds, qm, dm, w
 
 
-def _multi_run(path=None):
+def _multi_run(path=None, seed=5):
     from matchmaker_amd import ops
     dev = util.require_gpu()
-    qs, ds, qm, dm, w = _multi_case(dev)
+    qs, ds, qm, dm, w = _multi_case(dev, seed)
     t = lambda x: x.to(dev)
     got = ops.kernel_pool_multi([t(x) for x in qs], [t(x) for x in ds], t(qm), t(dm), t(torch.tensor(MU)), t(torch.tensor(SIGMA)),
                                 t(torch.ones(11)), t(w))
@@ -526,24 +529,30 @@ def _multi_run(path=None):
     return got
 
 
-def test_multi_launch_in_flat_xcd_order_with_two_wavefronts_per_simd(tmp_path):
-    """Conv-KNRM's 3 x 3 match matrices at a size where kp128_launch picks the round-5 form (>= 8,192 pairs, E = 128): flat
-    XCD-grouped workgroup order (kp_block_args) + two wavefronts per SIMD.  9,000 pairs vs the fp64 oracle; and BIT-EQUAL to
-    the form of rounds 1-4 (2-D grid, one wavefront per SIMD: MM_KP_MULTI_2D=1 MM_KP128_OCC=1 in a child process) — the order
-    in which workgroups run and the wavefronts per SIMD must not reach the arithmetic."""
+@pytest.mark.parametrize("seed", [5, 6])
+def test_multi_launch_in_flat_xcd_order_with_two_wavefronts_per_simd(tmp_path, seed):
+    """Conv-KNRM's 3 x 3 match matrices at a size where kp128_launch picks the block-once form (>= 2,048 pairs, E = 128,
+    three query tensors: one wavefront per document tensor looping over the query tensors, kernel_pool_multi128_kernel).
+    9,000 pairs vs the fp64 oracle; and BIT-EQUAL, each in a child process, to every other form of the launch — the flat
+    XCD-grouped per-combination order with two wavefronts per SIMD (round 5's default: MM_KP_MULTI_LOOP=0), the 2-D grid with
+    one wavefront per SIMD of rounds 1-4 (+ MM_KP_MULTI_2D=1 MM_KP128_OCC=1), the wavefront-per-query-tensor workgroups with a
+    rate barrier per block (+ MM_KP_MULTI_WG=1): which wavefront scores a combination, in which order workgroups run and
+    how many share a SIMD must not reach the arithmetic.  seed 5: prefix masks (lengths), seed 6: masks with holes (bit words)."""
     import os, subprocess, sys
     dev = util.require_gpu()
-    got = _multi_run()
+    got = _multi_run(seed=seed)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # ... and to the wavefront-per-query-tensor workgroups with a rate barrier per block (MM_KP_MULTI_WG=1: built, measured
-    # slower, kept for A/B)
-    for name, env in (("old_form", {"MM_KP_MULTI_2D": "1", "MM_KP128_OCC": "1"}), ("wg_form", {"MM_KP_MULTI_WG": "1"})):
+    forms = (("flat_form", {"MM_KP_MULTI_LOOP": "0"}),
+             ("old_form", {"MM_KP_MULTI_LOOP": "0", "MM_KP_MULTI_2D": "1", "MM_KP128_OCC": "1"}),
+             ("wg_form", {"MM_KP_MULTI_LOOP": "0", "MM_KP_MULTI_WG": "1"}),
+             ("loop_form", {"MM_KP_MULTI_LOOP": "1"}))
+    for name, env in forms:
         path = str(tmp_path / f"{name}.npy")
-        r = subprocess.run([sys.executable, "-c", f"from tests.test_kernel_pool_gpu import _multi_run; _multi_run({path!r})"], cwd=root,
+        r = subprocess.run([sys.executable, "-c", f"from tests.test_kernel_pool_gpu import _multi_run; _multi_run({path!r}, {seed})"], cwd=root,
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         assert got.cpu().numpy().tobytes() == np.load(path).tobytes(), name
-    qs, ds, qm, dm, w = _multi_case(dev)
+    qs, ds, qm, dm, w = _multi_case(dev, seed)
     sample = np.arange(0, 9000, 9)                                   # every ninth pair against the oracle (1,000 pairs x 9 combinations)
     ref = np.zeros(sample.size)
     for i in range(3):

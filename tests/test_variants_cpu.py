@@ -292,3 +292,39 @@ def test_the_maintainer_side_idcm_edit_of_integration_md_reproduces_the_real_cla
     finally:                                             # other tests drive the real classes
         for (ref_m, ref_attr), obj in saved.items():
             setattr(importlib.import_module(ref_m), ref_attr, obj)
+
+
+def test_rbf_recurrence_arithmetic_stays_within_rounding_of_the_exact_kernels():
+    """The pooling epilogue evaluates the reference's ten equally spaced kernels (knrm.py:33-50 kernel_mus / kernel_sigmas;
+    ecai20_tk.py:47-50) by recurrence from the two middle ones (kp_device.h rbf_geo_one).  Its fp32 arithmetic, emulated
+    operation for operation, against the exact kernel values over the whole cosine range: never more than 1e-5 relative on
+    any activation that matters (> 1e-6), i.e. within 3 x the direct form's own rounding and a tenth of what the split-bf16
+    cosine contributes; masked positions (cosine 1e5) give exact zeros; other kernel sets are refused."""
+    from oracle import np_oracle as O
+    mu = [1.0, 0.9, 0.7, 0.5, 0.3, 0.1, -0.1, -0.3, -0.5, -0.7, -0.9]
+    sg = [0.001] + [0.1] * 10
+    c = np.linspace(-1.0, 1.0, 400001).astype(np.float32)
+    geo = O.rbf_recurrence_fp32(c, mu, sg)
+    direct = O.rbf_direct_fp32(c, mu, sg)
+    assert geo is not None
+    c64 = c.astype(np.float64)
+    worst_geo = worst_direct = 0.0
+    for k in range(11):
+        true = np.exp(-(c64 - mu[k]) ** 2 / (2 * float(np.float32(sg[k])) ** 2))
+        m = true > 1e-6
+        if not m.any():
+            continue
+        worst_geo = max(worst_geo, float((np.abs(geo[m, k] - true[m]) / true[m]).max())) if k else worst_geo
+        worst_direct = max(worst_direct, float((np.abs(direct[m, k] - true[m]) / true[m]).max())) if k else worst_direct
+        if k == 0:      # the exact-match kernel is the direct form in both
+            assert np.array_equal(geo[:, 0], direct[:, 0])
+    assert worst_geo < 1.0e-5, worst_geo
+    assert worst_geo < 3.0 * worst_direct, (worst_geo, worst_direct)
+    # masked positions: exactly zero in every kernel
+    assert not O.rbf_recurrence_fp32(np.array([1.0e5, -1.0e5], np.float32), mu, sg).any()
+    # sets the device keeps on the direct form
+    assert O.rbf_recurrence_fp32(c[:4], mu[:4] + [0.35] + mu[5:], sg) is None
+    assert O.rbf_recurrence_fp32(c[:4], mu, sg[:6] + [0.15] + sg[7:]) is None
+    assert O.rbf_recurrence_fp32(c[:4], [1.0] + mu[:0:-1], sg) is None
+    assert O.rbf_recurrence_fp32(c[:4], mu, [0.001] + [0.04] * 10) is None
+    assert O.rbf_recurrence_fp32(c[:4], [1.0] + [m + 0.5 for m in mu[1:]], sg) is None
