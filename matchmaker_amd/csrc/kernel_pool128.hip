@@ -41,6 +41,15 @@ __device__ __forceinline__ void issue_slice8(const char* gbase, const uint32_t (
 #undef MM_GLDS
 }
 
+// one dword per lane through the LDS-DMA path into a 256-byte scratch row: a cache-line prefetch that owns no register
+__device__ __forceinline__ void touch_line(const char* gbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase), "s"(lds_dst)
+               : "memory");
+}
+
 // wait until at most `younger` whole slices are still in flight (extra vector loads in the queue — the
 // query tile, the gate — only make this wait longer, never shorter: completion is in order)
 __device__ __forceinline__ void wait_slices8(int younger) {
@@ -425,6 +434,11 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
 // ONE wavefront per SIMD cannot overlap its epilogue with anything.  With the middle-out recurrence (kp_device.h rbf_geo_one:
 // two thirds of the epilogue's issue cycles) it is 8.38 ms, the per-combination form — which sits on its 47 GB of traffic, not
 // on the epilogue — stays at 8.66: this form is the default for launches of >= 2,048 pairs (kp128_launch).
+#if defined(MM_KP_MULTI_PROF)   // tools only: phase clocks of the loop kernel, printed by the first wavefronts (a -D variant build)
+#define MMP_STAMP(slot) do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); prof[slot] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define MMP_STAMP(slot) do { } while (0)
+#endif
 template <int NSL, int K, int NQ>
 __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -432,6 +446,11 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
   const int fr = (int)blockIdx.x;
+#if defined(MM_KP_MULTI_PROF)
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev, tstart;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+  tstart = tprev;
+#endif
   const int bx = __builtin_amdgcn_readfirstlane(fr / a.n_md);
   const int td = __builtin_amdgcn_readfirstlane(fr - bx * a.n_md);          // this wavefront's document tensor
   const int64_t p0 = (int64_t)bx * a.pairs_per_wave;
@@ -445,6 +464,7 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
   char* ring = smem;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
   float* rdbuf = (float*)(smem + NBUF * kS128Bytes);
+  const uint32_t lds_scratch = lds0 + (uint32_t)kp128_lds_fixed(1);     // 256 B behind the fixed map (kp128_launch adds them)
 
   uint32_t voff[kS128Instr], voff_tail[kS128Instr];
 #pragma unroll
@@ -463,6 +483,11 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
 
   Rbf rbf;
   load_rbf<K>(a.mu, a.sigma, a.alpha, nullptr, rbf);
+  // bin weights of this wavefront's NQ combinations (i, td): lane k holds weight k, read back with v_readlane per pair (a
+  // scalar reload per pair and combination was a memory round trip each)
+  float wv[NQ];
+#pragma unroll
+  for (int iq = 0; iq < NQ; ++iq) wv[iq] = lane < K ? a.w[(iq * a.n_md + td) * K + lane] : 0.0f;
 
   const char* dbase = (const char*)a.md[td];
   auto doc_len = [&](int64_t p) -> int {
@@ -504,6 +529,7 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
   int64_t q_left = a.ppq - (p0 - qi * a.ppq);
 
   for (int64_t pair = p0; pair < p1; ++pair) {
+    MMP_STAMP(7);
     if (q_left == 0) {
       ++qi;
       q_left = a.ppq;
@@ -512,16 +538,33 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
     if (qi != cur_q) {
       cur_q = qi;
       const int qr = r < Q ? r : Q - 1;
+      // The three tiles are fetched tensor by tensor with the NEXT tensor's sixteen loads in flight while this one is split
+      // (one load pair -> wait -> split at a time was 24 dependent memory round trips per pair: 21.8 k of a pair's 105 k
+      // cycles, MM_KP_MULTI_PROF).  Same values, same order of the norm's additions.
+      constexpr int NX = NSL * kS128Steps * 2;
+      f32x4 xq[2][NX];
+      auto q_issue = [&](int iq, f32x4 (&dst)[NX]) {
+        const char* qrow = (const char*)a.mq[iq] + (qi * Q + qr) * RB + h * 32;
+#pragma unroll
+        for (int s = 0; s < NSL; ++s)
+#pragma unroll
+          for (int p = 0; p < kS128Steps; ++p) {
+            dst[(s * kS128Steps + p) * 2] = *(const f32x4*)(qrow + s * 256 + p * 64);
+            dst[(s * kS128Steps + p) * 2 + 1] = *(const f32x4*)(qrow + s * 256 + p * 64 + 16);
+          }
+      };
+      q_issue(0, xq[0]);
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
-        const char* qrow = (const char*)a.mq[iq] + (qi * Q + qr) * RB + h * 32;
+        if (iq + 1 < NQ) q_issue(iq + 1, xq[(iq + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
         float ss = 0.0f;
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
 #pragma unroll
           for (int p = 0; p < kS128Steps; ++p) {
-            const f32x4 x0 = *(const f32x4*)(qrow + s * 256 + p * 64);
-            const f32x4 x1 = *(const f32x4*)(qrow + s * 256 + p * 64 + 16);
+            const f32x4 x0 = xq[iq & 1][(s * kS128Steps + p) * 2];
+            const f32x4 x1 = xq[iq & 1][(s * kS128Steps + p) * 2 + 1];
             split8(x0, x1, qhi[iq][s][p], qlo[iq][s][p]);
             qhi[iq][s][p] = to_agpr(qhi[iq][s][p]);
             qlo[iq][s][p] = to_agpr(qlo[iq][s][p]);
@@ -535,6 +578,18 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
       qvalid = r < Q && r < qlen;
       if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
     }
+    if (q_left == 0 && pair + 1 < p1) {
+      // the next pair brings its own query tiles (Conv-KNRM's pair-per-row layout: 46 KB per pair): touch their cache lines now
+      // — one LDS-DMA dword per 128-byte line into a scratch row nobody reads, no register involved — so that the loads above
+      // find them in this XCD's L2 a pair later instead of in HBM
+      const uint32_t qbytes = (uint32_t)(Q * RB);
+#pragma unroll
+      for (int iq = 0; iq < NQ; ++iq) {
+        const char* g = (const char*)a.mq[iq] + (qi + 1) * (int64_t)qbytes;
+        for (uint32_t off = (uint32_t)lane * 128u; off < qbytes; off += 64u * 128u) touch_line(g, off, lds_scratch);
+      }
+    }
+    MMP_STAMP(5);      // query tiles (when the pair brought its own)
     const int len = doc_len(pair);
     const int nb = (len + 31) >> 5;
     f32x2 pk2[NQ][kMaxK / 2];
@@ -559,6 +614,7 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
           x[2 * p + 1] = *(const f32x4*)(buf + aoff[p][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        MMP_STAMP(0);    // refill + wait for the slice + its LDS reads
         cbuf = (cbuf + 1 == NBUF) ? 0 : cbuf + 1;      // the slice is in registers: its slot goes back to the producer now
         --inflight;
         top_up();
@@ -572,7 +628,23 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
           ss2 += b0 * b0;
           ss2 += b1 * b1;
         }
+        MMP_STAMP(1);    // refill + operand split + norms
       }
+      // the first query tensor's products go out BEFORE the row norms make their round trip through LDS (they do not need them)
+      f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+      auto products = [&](int iq) {
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+#pragma unroll
+          for (int p = 0; p < kS128Steps; ++p) {
+            acc_hh = mfma_bf16(ah[s][p], qhi[iq][s][p], acc_hh);
+            acc_lh = mfma_bf16(al[s][p], qhi[iq][s][p], acc_lh);
+            acc_xl = mfma_bf16(ah[s][p], qlo[iq][s][p], acc_xl);
+            acc_xl = mfma_bf16(al[s][p], qlo[iq][s][p], acc_xl);
+          }
+        }
+      };
+      products(0);
       float ss = ss2[0] + ss2[1];
       ss += __shfl_xor(ss, 32, 64);
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
@@ -585,37 +657,75 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
       const int rem = len - 32 * t;
       const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
       const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      MMP_STAMP(2);      // first tensor's products; row norms through LDS, mask word
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
-        f32x16 acc_hh = {0}, acc_lh = {0}, acc_xl = {0};
+        if (iq > 0) {
 #pragma unroll
-        for (int s = 0; s < NSL; ++s) {
-#pragma unroll
-          for (int p = 0; p < kS128Steps; ++p) {
-            acc_hh = mfma_bf16(ah[s][p], qhi[iq][s][p], acc_hh);
-            acc_lh = mfma_bf16(al[s][p], qhi[iq][s][p], acc_lh);
-            acc_xl = mfma_bf16(ah[s][p], qlo[iq][s][p], acc_xl);
-            acc_xl = mfma_bf16(al[s][p], qlo[iq][s][p], acc_xl);
-          }
+          for (int i = 0; i < 16; ++i) acc_hh[i] = acc_lh[i] = acc_xl[i] = 0.0f;
+          products(iq);
         }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+#if defined(MM_KP_MULTI_PROF)
+        asm volatile("" :: "v"(acc));
+#endif
+        MMP_STAMP(3);    // matrix products of one query tensor
         rbf_block<K>(pk2[iq], acc, rdr, rq[iq], va, h, rbf);
+#if defined(MM_KP_MULTI_PROF)
+        asm volatile("" :: "v"(pk2[iq][1]), "v"(pk2[iq][5]));
+#endif
+        MMP_STAMP(4);    // its RBF epilogue
       }
     }
+    // log pooling of the NQ combinations TOGETHER (kp_device.h pool_partial's arithmetic, operation for operation): the
+    // NQ x K wave sums share their six butterfly steps
+    float lg[NQ][K];
+    const bool count_lane = qvalid && lane < 32;
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
       float pk[kMaxK];
       pk_get<K>(pk, pk2[iq], rbf);
 #pragma unroll
-      for (int k = 0; k < K; ++k) pk[k] += __shfl_xor(pk[k], 32, 64);
+      for (int k = 0; k < K; ++k) {
+        pk[k] += __shfl_xor(pk[k], 32, 64);
+        const float v = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
+        lg[iq][k] = count_lane ? v : 0.0f;
+      }
+    }
+    // (the butterfly's first step would add the zeros of lanes 32 .. 63 — x + 0 = x: skipped; then one exchange over 16 lanes
+    // and the DPP row sum of pool_partial: lane 0 holds the same bits)
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq)
+#pragma unroll
+      for (int k = 0; k < K; ++k) lg[iq][k] += __shfl_xor(lg[iq][k], 16, 64);
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq)
+#pragma unroll
+      for (int k = 0; k < K; ++k) lg[iq][k] = row_sum_to_lane0(lg[iq][k]);
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
       const int y = iq * a.n_md + td;                                  // combination (i, t): its bin weights, its partial row
-      sload_vec<K>(a.w + y * K, rbf.w);
-      const float total = pool_partial<K>(a, pair, pk, qvalid && lane < 32, lane, rbf, -1);
+      if (a.per_kernel && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) a.per_kernel[pair * K + k] = lg[iq][k];
+      }
+      float total = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        total += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv[iq]), k)) * lg[iq][k];
       if (lane == 0) a.out[(int64_t)y * a.n_pairs + pair] = total;
     }
+    MMP_STAMP(6);        // log pooling of the pair's three combinations
   }
+#if defined(MM_KP_MULTI_PROF)
+  if (lane == 0 && (blockIdx.x % 97) == 0 && blockIdx.x < 970)
+    printf("[MM_KP_MULTI_PROF] wave %d pairs %d cycles %llu | slice wait+read %llu | split %llu | norms+mask %llu | mfma %llu | rbf %llu | query tiles %llu | pooling %llu | loop %llu\n",
+           (int)blockIdx.x, (int)(p1 - p0), (unsigned long long)(tprev - tstart), (unsigned long long)prof[0], (unsigned long long)prof[1],
+           (unsigned long long)prof[2], (unsigned long long)prof[3], (unsigned long long)prof[4], (unsigned long long)prof[5],
+           (unsigned long long)prof[6], (unsigned long long)prof[7]);
+#endif
 }
 
 bool kp128_supported(int Q, int D, int E, bool gated) {
@@ -716,7 +826,7 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
   const bool loop_auto = a.n_pairs >= (int64_t)kCUs * 4 * 2;
   if (a.n_md > 0 && !gated && nsl <= 2 && a.n_mblk / a.n_md == 3 && !a.pair_q &&
       (env().kp_multi_loop == 1 || (env().kp_multi_loop < 0 && loop_auto))) {
-    const int ldsm = kp128_lds_fixed(1);
+    const int ldsm = kp128_lds_fixed(1) + 256;      // + the scratch row of the query-tile prefetch
     int64_t groups = (int64_t)kCUs * 4 / a.n_md;
     if (groups < 1) groups = 1;
     if (groups > a.n_pairs) groups = a.n_pairs;

@@ -510,8 +510,22 @@ __device__ __forceinline__ void redist_reduce(float (&pk)[kMaxK], int np, int la
 }
 
 
+// lane i of a 16-lane row += lane i + n (DPP row_shl:n, lanes past the row read 0) for n = 8, 4, 2, 1: the row's sum in its lane 0,
+// added in the order of the xor butterfly as lane 0 sees it
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum_to_lane0(float v) {
+  v += dpp_row<0x108>(v);
+  v += dpp_row<0x104>(v);
+  v += dpp_row<0x102>(v);
+  v += dpp_row<0x101>(v);
+  return v;
+}
+
 // log-sum pooling of one pair over kernels K0..K1-1: pk[k] (this lane's query token, both halves already
-// combined); writes per_kernel, returns sum_k w_k * pooled_k (wave-uniform).
+// combined); writes per_kernel, returns sum_k w_k * pooled_k (valid in LANE 0, the lane every caller stores from).
 // tok: the query token whose sums this lane holds (-1: a lane that holds a copy or nothing) — only used to hand the sums out
 template <int K, int K0 = 0, int K1 = K>
 __device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, const float (&pk)[kMaxK], bool count_lane,
@@ -521,15 +535,45 @@ __device__ __forceinline__ float pool_partial(const KpArgs& a, int64_t pair, con
 #pragma unroll
     for (int k = K0; k < K1; ++k) dst[k] = pk[k];
   }
-  float total = 0.0f;
+  // The K wave sums run TOGETHER, butterfly step by butterfly step: K independent exchanges per step overlap their latencies.
+  // (One wave_sum per kernel inside the loop — with the per_kernel store's branch between them — was six dependent cross-lane
+  // round trips per kernel: 20 k cycles per pair for the three combinations of Conv-KNRM's loop kernel, a fifth of its time, and
+  // 6-7 k of a TK pair's ~85 k; tools/build_variant.sh mprof kernel_pool128 -DMM_KP_MULTI_PROF.)  Every value goes through the
+  // same additions in the same order as wave_sum: the sums are the same bits.
+#if defined(MM_POOL_SERIAL)   // A/B builds: one wave_sum per kernel, as up to round 6
+  float total_s = 0.0f;
 #pragma unroll
   for (int k = K0; k < K1; ++k) {
-    float lg = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
-    lg = count_lane ? lg : 0.0f;  // exactly one lane per real query token counts (the others hold copies)
-    const float s = wave_sum(lg);
-    if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = s;
-    total += rbf.w[k] * s;
+    float lgs = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
+    lgs = count_lane ? lgs : 0.0f;
+    const float ssum = wave_sum(lgs);
+    if (a.per_kernel && lane == 0) a.per_kernel[pair * K + k] = ssum;
+    total_s += rbf.w[k] * ssum;
   }
+  return total_s;
+#endif
+  float lg[K1 - K0];
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const float v = __logf(fmaxf(pk[k] * rbf.alpha[k], a.clamp_min));
+    lg[k - K0] = count_lane ? v : 0.0f;  // exactly one lane per real query token counts (the others hold copies)
+  }
+  // ... and only LANE 0's sums are used: the exchanges over 32 and 16 lanes stay butterflies (ds_bpermute), the steps inside a
+  // row of 16 are v_add_f32 with a DPP row_shl operand (no LDS round trip) — in lane 0 the same additions of the same partial sums.
+#pragma unroll
+  for (int o = 32; o >= 16; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < K1 - K0; ++k) lg[k] += __shfl_xor(lg[k], o, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < K1 - K0; ++k) lg[k] = row_sum_to_lane0(lg[k]);
+  if (a.per_kernel && lane == 0) {
+#pragma unroll
+    for (int k = K0; k < K1; ++k) a.per_kernel[pair * K + k] = lg[k - K0];
+  }
+  float total = 0.0f;
+#pragma unroll
+  for (int k = K0; k < K1; ++k) total += rbf.w[k] * lg[k - K0];
   return total;
 }
 
