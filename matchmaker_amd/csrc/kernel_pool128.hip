@@ -648,16 +648,55 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
       float ss = ss2[0] + ss2[1];
       ss += __shfl_xor(ss, 32, 64);
       if (h == 0) rdbuf[r] = 1.0f / (sqrtf(ss) + 1e-13f);
+      const int rem = len - 32 * t;
+      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
+      MMP_STAMP(2);      // first tensor's products; row norms into LDS, mask word
+#if MM_RBF_GEO && defined(MM_KP_MULTI_OVERLAP)
+      if (rbf.geo && va == 0xffffffffu) {
+        // A/B builds only (-DMM_KP_MULTI_OVERLAP).  Full block, recurrence epilogue: one straight-line stretch in which the
+        // products of query tensor iq + 1 (the same MFMAs in the same order: same bits) are spread, NSL per row, between the RBF
+        // evaluations of tensor iq, so that the matrix pipe works under the VALU stream of the ONE wavefront this SIMD has
+        // (products behind one another are 2.9 k of a block's 17.6 k cycles).  The ISA shows the interleave (an MFMA every
+        // ~5 v_exp_f32) — and the launch takes 7.03 ms instead of 6.93: the epilogue is packed-fp32 math, which does not run
+        // beside the matrix pipe for free (the guide's "anti-lever beside MFMAs"), and the stretch spills 16 registers.
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq) {
+          f32x16 acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = acc_hh[i] + (acc_lh[i] + acc_xl[i]);
+          if (iq + 1 < NQ) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc_hh[i] = acc_lh[i] = acc_xl[i] = 0.0f;
+          }
+          f32x4 rv = {0, 0, 0, 0};                 // 1 / |row| of four rows at a time (re-read from LDS per tensor: sixteen held
+                                                   // across the stretch were the registers that spilled)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if ((i & 3) == 0) rv = *(const f32x4*)(rdbuf + 8 * (i >> 2) + 4 * h);
+            if (iq + 1 < NQ) {
+#pragma unroll
+              for (int n = i * NSL; n < (i + 1) * NSL; ++n) {          // 16 NSL products over 16 rows
+                const int sn = n / 16, pn = (n % 16) / 4, jn = n % 4;
+                if (jn == 0) acc_hh = mfma_bf16(ah[sn][pn], qhi[iq + 1][sn][pn], acc_hh);
+                else if (jn == 1) acc_lh = mfma_bf16(al[sn][pn], qhi[iq + 1][sn][pn], acc_lh);
+                else if (jn == 2) acc_xl = mfma_bf16(ah[sn][pn], qlo[iq + 1][sn][pn], acc_xl);
+                else acc_xl = mfma_bf16(al[sn][pn], qlo[iq + 1][sn][pn], acc_xl);
+              }
+            }
+            rbf_geo_one<false>(pk2[iq], (acc[i] * rq[iq]) * rv[i & 3], 0.0f, rbf);
+          }
+        }
+        MMP_STAMP(4);
+        continue;
+      }
+#endif
       float rdr[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 v = *(const f32x4*)(rdbuf + 8 * g + 4 * h);
         rdr[4 * g + 0] = v[0]; rdr[4 * g + 1] = v[1]; rdr[4 * g + 2] = v[2]; rdr[4 * g + 3] = v[3];
       }
-      const int rem = len - 32 * t;
-      const uint32_t ex = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
-      const uint32_t va = a.dm.bits ? (sload_u32(a.dm.bits, pair * nblk_tot + t) & ex) : ex;
-      MMP_STAMP(2);      // first tensor's products; row norms through LDS, mask word
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
         if (iq > 0) {
