@@ -426,14 +426,19 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
 // Here a block crosses HBM and the operand split ONCE: the wavefront keeps the n_mq query tiles of its pair as B fragments
 // (AGPRs: 3 x 64 registers at E = 128), splits the block's rows once (64 registers of A fragments), and runs products +
 // RBF epilogue for the query tensors back to back, n_mq sets of running kernel sums in registers.  Same MFMA order, same
-// epilogue as kernel_pool_split128_kernel: every combination's score is the same bits; the partial rows are summed in
-// (i, t) order by the same kp_sum_blocks_kernel.  One wavefront per SIMD (the fragments need the register file).
+// epilogue as kernel_pool_split128_kernel; the partial rows are summed in (i, t) order by the same kp_sum_blocks_kernel.  The
+// scores agree with the per-combination forms' to fp32 rounding (<= 6e-6 on scores of order 1; a different instruction stream,
+// different multiply-add contraction), NOT bit for bit as this comment claimed until it was measured
+// (tests/test_kernel_pool_gpu.py::test_multi_launch_*).  One wavefront per SIMD (the fragments need the register file).
 // MEASURED (64 x 1000 pairs, Q30 / D200 / E128, same box, round-robin; tools/conv_knrm_ab.sh): FETCH_SIZE 22.5 GB per launch
 // (13.7 GB of document rows + 8.8 GB of query tiles, each read by the three document-tensor wavefronts of its pair) against
 // 47.3 GB.  With the direct RBF form (twelve v_exp_f32 per cosine) it was the slower form all the same, 9.68 against 8.65 ms:
 // ONE wavefront per SIMD cannot overlap its epilogue with anything.  With the middle-out recurrence (kp_device.h rbf_geo_one:
 // two thirds of the epilogue's issue cycles) it is 8.38 ms, the per-combination form — which sits on its 47 GB of traffic, not
-// on the epilogue — stays at 8.66: this form is the default for launches of >= 2,048 pairs (kp128_launch).
+// on the epilogue — stays at 8.66: this form is the default for launches of >= 2,048 pairs (kp128_launch).  Then by its phase
+// clocks (-DMM_KP_MULTI_PROF below; profiles/r06_experiments/rbf_recurrence_ab.txt 6): two fifths of a pair's 105 k cycles were
+// per-PAIR work — 24 dependent load -> split round trips for the pair's own query tiles, 33 serial wave sums in the pooling —
+// now 7 k + 7 k of 78 k: 6.85 ms.
 #if defined(MM_KP_MULTI_PROF)   // tools only: phase clocks of the loop kernel, printed by the first wavefronts (a -D variant build)
 #define MMP_STAMP(slot) do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); prof[slot] += t_ - tprev; tprev = t_; } while (0)
 #else
@@ -578,16 +583,24 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
       qvalid = r < Q && r < qlen;
       if (a.qm.bits) qvalid = qvalid && ((sload_u32(a.qm.bits, qi) >> r) & 1u);
     }
-    if (q_left == 0 && pair + 1 < p1) {
-      // the next pair brings its own query tiles (Conv-KNRM's pair-per-row layout: 46 KB per pair): touch their cache lines now
-      // — one LDS-DMA dword per 128-byte line into a scratch row nobody reads, no register involved — so that the loads above
-      // find them in this XCD's L2 a pair later instead of in HBM
+    // Prefetch of the NEXT pair's query tiles by LDS-DMA touches (one dword per 128-byte line into a scratch row): built,
+    // measured, OFF.  Same box, round-robin (tools/scratch/touch_ab.sh): none 6.82 / 6.87 ms, 22.5 GB fetched; at the head of
+    // the pair 7.06 / 7.07 ms, 31.2 GB (a pair later the lines have left this XCD's L2: the tiles cross HBM twice); at the pair's
+    // last block 7.01 ms, 24.3 GB.  What made the query phase cheap is the double-buffered fetch above, not the prefetch.
+#ifndef MM_KP_MULTI_TOUCH
+#define MM_KP_MULTI_TOUCH 0     // 0: no prefetch; 1: at the head of the pair; 2: at the pair's last block (A/B builds)
+#endif
+    auto touch_next = [&]() {
       const uint32_t qbytes = (uint32_t)(Q * RB);
 #pragma unroll
       for (int iq = 0; iq < NQ; ++iq) {
         const char* g = (const char*)a.mq[iq] + (qi + 1) * (int64_t)qbytes;
         for (uint32_t off = (uint32_t)lane * 128u; off < qbytes; off += 64u * 128u) touch_line(g, off, lds_scratch);
       }
+    };
+    const bool next_own = q_left == 0 && pair + 1 < p1;
+    if (MM_KP_MULTI_TOUCH == 1 && next_own) {
+      touch_next();
     }
     MMP_STAMP(5);      // query tiles (when the pair brought its own)
     const int len = doc_len(pair);
@@ -598,7 +611,9 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
 #pragma unroll
       for (int k = 0; k < kMaxK / 2; ++k) pk2[iq][k] = f32x2{0.0f, 0.0f};
 
+    if (MM_KP_MULTI_TOUCH == 2 && next_own && nb == 0) touch_next();
     for (int t = 0; t < nb; ++t) {
+      if (MM_KP_MULTI_TOUCH == 2 && next_own && t == nb - 1) touch_next();
       // the block's rows: LDS -> registers -> bf16 hi / lo A fragments, ONCE for all query tensors; row norms on the way
       bf16x8 ah[NSL][kS128Steps], al[NSL][kS128Steps];
       f32x2 ss2 = {0.0f, 0.0f};
