@@ -456,8 +456,19 @@ __global__ void __launch_bounds__(64, 1) kernel_pool_multi128_kernel(const KpArg
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
   tstart = tprev;
 #endif
-  const int bx = __builtin_amdgcn_readfirstlane(fr / a.n_md);
-  const int td = __builtin_amdgcn_readfirstlane(fr - bx * a.n_md);          // this wavefront's document tensor
+  // m_flat = 3 (the default): the n_md wavefronts of a pair range get the ids g, g + 8, g + 16 — same XCD (workgroup b runs on
+  // XCD b % 8: observed, used for speed only) — so the pair's query tiles, which all of them read, cross HBM once per range
+  // instead of once per document tensor (8.8 -> 2.95 GB of the launch's 22.5 GB fetched).  Otherwise consecutive ids.
+  int bx, td;
+  if (a.m_flat == 3) {
+    const int period = 8 * a.n_md, blk = fr / period, rr = fr - blk * period;
+    bx = __builtin_amdgcn_readfirstlane(blk * 8 + (rr & 7));
+    td = __builtin_amdgcn_readfirstlane(rr >> 3);                            // this wavefront's document tensor
+    if (bx >= a.m_ranges) return;
+  } else {
+    bx = __builtin_amdgcn_readfirstlane(fr / a.n_md);
+    td = __builtin_amdgcn_readfirstlane(fr - bx * a.n_md);
+  }
   const int64_t p0 = (int64_t)bx * a.pairs_per_wave;
   const int64_t p1 = (p0 + a.pairs_per_wave < a.n_pairs) ? p0 + a.pairs_per_wave : a.n_pairs;
   if (p0 >= p1) return;
@@ -882,11 +893,15 @@ int kp128_launch(const KpArgs& a0, hipStream_t stream) {
       (env().kp_multi_loop == 1 || (env().kp_multi_loop < 0 && loop_auto))) {
     const int ldsm = kp128_lds_fixed(1) + 256;      // + the scratch row of the query-tile prefetch
     int64_t groups = (int64_t)kCUs * 4 / a.n_md;
+    const bool xcd = !env().kp_multi_2d && groups >= 8;   // XCD-grouped ids (see the kernel); MM_KP_MULTI_2D=1: consecutive ids (A/B runs)
+    if (xcd) groups = groups / 8 * 8;                     // whole groups of 8 ranges, all resident at once (one wavefront per SIMD)
     if (groups < 1) groups = 1;
     if (groups > a.n_pairs) groups = a.n_pairs;
     a.pairs_per_wave = (a.n_pairs + groups - 1) / groups;
     groups = (a.n_pairs + a.pairs_per_wave - 1) / a.pairs_per_wave;
-    const dim3 grid((unsigned)(groups * a.n_md));
+    a.m_flat = xcd ? 3 : 0;
+    a.m_ranges = (int)groups;
+    const dim3 grid((unsigned)((xcd ? (groups + 7) / 8 * 8 : groups) * a.n_md));
     if (nsl == 1) hipLaunchKernelGGL((kernel_pool_multi128_kernel<1, 11, 3>), grid, dim3(64), ldsm, stream, a);
     else hipLaunchKernelGGL((kernel_pool_multi128_kernel<2, 11, 3>), grid, dim3(64), ldsm, stream, a);
     return check_launch("kernel_pool_multi128_kernel");
