@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(64 * KS * MW, OCC) kernel_pool_split128_kernel
 // on the epilogue — stays at 8.66: this form is the default for launches of >= 2,048 pairs (kp128_launch).  Then by its phase
 // clocks (-DMM_KP_MULTI_PROF below; profiles/r06_experiments/rbf_recurrence_ab.txt 6): two fifths of a pair's 105 k cycles were
 // per-PAIR work — 24 dependent load -> split round trips for the pair's own query tiles, 33 serial wave sums in the pooling —
-// now 7 k + 7 k of 78 k: 6.85 ms.
+// now 7 k + 7 k of 78 k: 6.85 ms; with the wavefronts that share query tiles on one XCD 6.65 ms and 16.6 GB fetched = the needed bytes.
 #if defined(MM_KP_MULTI_PROF)   // tools only: phase clocks of the loop kernel, printed by the first wavefronts (a -D variant build)
 #define MMP_STAMP(slot) do { uint64_t t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); prof[slot] += t_ - tprev; tprev = t_; } while (0)
 #else
