@@ -136,11 +136,14 @@ def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
         except Exception:
             use_ref = False
 
+    prepared = {}       # per query: the reference-layout tensors, built once (untimed; rebuilding them per call was 55 of the leg's 75 s)
+
     def run(i):
-        dn = d_cpu[i * cands:(i + 1) * cands].float()
-        dm = synth.len_to_mask(d_len[i * cands:(i + 1) * cands], D)
-        qr = qn[i:i + 1].expand(cands, -1, -1).contiguous()
-        qm = synth.len_to_mask(q_len[i:i + 1], Q).expand(cands, -1).contiguous()
+        if i not in prepared:
+            prepared[i] = (qn[i:i + 1].expand(cands, -1, -1).contiguous(), d_cpu[i * cands:(i + 1) * cands].float(),
+                           synth.len_to_mask(q_len[i:i + 1], Q).expand(cands, -1).contiguous(),
+                           synth.len_to_mask(d_len[i * cands:(i + 1) * cands], D))
+        qr, dn, qm, dm = prepared[i]
         t0 = time.perf_counter()
         if use_ref:
             RH.colbert_forward(qr, dn, qm, dm)
