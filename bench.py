@@ -136,9 +136,10 @@ def cpu_baseline(q_cpu, d_cpu, q_len, d_len, cands, budget_s=12.0):
         except Exception:
             use_ref = False
 
-    # The reference hands the scoring block tensors its encoder has just produced: the fp32 document tensor is written per call
-    # (untimed) into ONE preallocated buffer.  (A fresh 92 MB tensor per call cost 30 ms of page faults around a 7 ms call: 55 of
-    # the leg's 75 s; tensors prepared once per query and read back from DRAM halve the 128-thread rate — 81 k vs 148 k pairs/s.)
+    # The reference hands the scoring block tensors its encoder has just produced: the fp32 tensors are written per call (untimed)
+    # into ONE preallocated pair of buffers.  (A fresh 92 MB tensor per call cost 30 ms of page faults around a 7-12 ms call: 55 of
+    # the leg's 75 s of wall clock; same box, same day: 79.6 k pairs/s that way, 80.9 k with tensors prepared once per query and
+    # read back from DRAM, 90.1 k this way.  The 128-thread rate moves 80-150 k box to box with the host's other tenants.)
     dn = torch.empty((cands,) + tuple(d_cpu.shape[1:]), dtype=torch.float32)
     qr = torch.empty((cands,) + tuple(qn.shape[1:]), dtype=torch.float32)
     masks = {}
