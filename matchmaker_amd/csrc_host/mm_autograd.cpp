@@ -310,6 +310,9 @@ class TklScore : public torch::autograd::Function<TklScore> {
     const at::Tensor cm = chunk_mask.to(at::kFloat).contiguous(), cs = chunk_slot.to(at::kInt).contiguous(),
                      qm = q_mask.to(at::kFloat).contiguous(), packed = packed_in.detach().to(at::kFloat).contiguous();
     TORCH_CHECK(packed.numel() == MM_TKL_NPARAMS(K, E), "mm_autograd: packed parameters have ", packed.numel(), " elements");
+    TORCH_CHECK(cm.numel() == P * 50 && cs.numel() == P && qm.numel() == B * Q && C > 0 && P <= B * C,
+                "mm_autograd: TKL masks do not fit the operands: chunk_mask ", cm.sizes(), " chunk_slot ", cs.sizes(), " q_mask ", qm.sizes(),
+                " for P = ", P, ", B = ", B, ", Q = ", Q, ", C = ", C);
     const int64_t W = (std::max<int64_t>(C * 40, 30) - 30) / 2 + 1;
     at::Tensor out = at::empty({B}, q.options()), win = at::empty({B, W}, q.options());
     if (B > 0) {

@@ -283,6 +283,26 @@ def test_cpp_autograd_node_of_tkl_equals_the_python_node(monkeypatch, sat):
     assert gq_c.abs().sum() > 0 and torch.isfinite(gq_c).all() and torch.isfinite(gd_c).all()
 
 
+def test_cpp_autograd_node_of_tkl_refuses_masks_that_do_not_fit_the_operands():
+    """TklScore hands raw pointers to mm_tkl_fwd: a query mask, chunk mask or slot list of another batch must raise before the
+    launch, not read past the tensor."""
+    from matchmaker_amd import _fast
+    from matchmaker_amd import tkl as T
+    if _fast.module() is None or not hasattr(_fast.module(), "tkl_score"):
+        pytest.skip("host extension not built (python -m matchmaker_amd.build)")
+    dev = util.require_gpu()
+    q_ctx, chunks, cmask, slot, qm, params, B, C, sat = _epilogue_inputs(dev, 6, 12, 400, 64, "embedding", 7)
+    layout = torch.zeros(3, 0, dtype=torch.int64)
+    ok = _fast.module().tkl_score(q_ctx, chunks, cmask, slot, qm, params, B, C, 11, 0, [], layout)
+    assert torch.isfinite(ok[0]).all() and ok[0].shape == (B,)
+    for bad in ((q_ctx, chunks, cmask, slot, qm[:, :-1].contiguous()), (q_ctx, chunks, cmask[:-1].contiguous(), slot, qm),
+                (q_ctx, chunks, cmask, slot[:-1].contiguous(), qm), (q_ctx[:1].contiguous(), chunks, cmask, slot, qm[:1].contiguous())):
+        n_doc = bad[0].shape[0]
+        with pytest.raises(RuntimeError):
+            _fast.module().tkl_score(*bad, params, n_doc, C, 11, 0, [], layout)
+    torch.cuda.synchronize()
+
+
 def test_backward_with_three_workgroups_per_document_equals_the_one_workgroup_launch():
     """mm_tkl_bwd: up to 85 documents (3 B <= 256 CUs; the reference trains 64) every document's three arg-max regions go to three
     workgroups whose shares tkl_bwd_combine_kernel adds in region order; larger batches walk the regions in one workgroup.  The same
