@@ -459,7 +459,10 @@ bool tkl_stage1_rows_supported(int Q, int E) { return Q <= 32 && (E == 100 || E 
 
 int tkl_stage1_rows_launch(const KpArgs& a0, hipStream_t stream) {
   KpArgs a = a0;
-  int64_t waves = (int64_t)kCUs * 4;
+#ifndef MM_S1_WAVES_PER_CU   // A/B builds only: 4 are resident (LDS); more give shorter ranges handed out as wavefronts retire
+#define MM_S1_WAVES_PER_CU 4
+#endif
+  int64_t waves = (int64_t)kCUs * MM_S1_WAVES_PER_CU;
   if (waves > a.n_pairs) waves = a.n_pairs;
   if (waves <= 0) return MM_OK;
   a.pairs_per_wave = (a.n_pairs + waves - 1) / waves;
