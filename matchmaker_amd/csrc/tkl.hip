@@ -21,7 +21,10 @@ constexpr int kU = 20;        // position pairs per chunk
 constexpr int kWinPairs = 15; // 30 positions, stride 2
 constexpr int kWT = 64;       // windows per workgroup in stage 2 (pair rows staged: kWT + 14)
 constexpr int kWThreads = 256;
-constexpr int kTokGroup = 10;  // query tokens per window workgroup (see tkl_window_kernel)
+#ifndef MM_TKL_TOK_GROUP
+#define MM_TKL_TOK_GROUP 10     // -D overrides for A/B builds only (profiles/r06_experiments/tkl_window_token_groups.txt)
+#endif
+constexpr int kTokGroup = MM_TKL_TOK_GROUP;  // query tokens per window workgroup (see tkl_window_kernel)
 #ifndef MM_TKL_EPILOGUE_ORDER
 #define MM_TKL_EPILOGUE_ORDER 1   // 0: round 4 (relaxed counter + s_waitcnt), 1: acq_rel counter by thread 0, 2: fences in every thread
 #endif
